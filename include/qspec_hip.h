@@ -1,0 +1,172 @@
+/*
+ * qspec_hip.h -- C ABI of libqspec_hip.so, the MI355X (gfx950) replacement for
+ * the native operators on the QSpec draft/verify hot path.
+ *
+ * Conventions (same as the reference's operator boundary):
+ *   - every pointer is a DEVICE pointer owned by the caller; outputs are
+ *     pre-allocated and passed in; tensors are contiguous row-major;
+ *   - fp16 tensors are `qspec_half*` (uint16_t bit patterns);
+ *   - `stream` is a hipStream_t (NULL = default stream); every call only
+ *     enqueues, never synchronises, never allocates: calls may be captured
+ *     into a hipGraph;
+ *   - return 0 on success; non-zero = error, text from qspec_last_error()
+ *     (thread-local).  The reference raises TORCH_CHECK exceptions at the same
+ *     places (shape / dtype / contiguity checks); the Python host re-raises.
+ *
+ * Each entry point names the reference interface it replaces (paths relative
+ * to the reference checkout).
+ */
+#ifndef QSPEC_HIP_H
+#define QSPEC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t qspec_half;
+
+int qspec_abi_version(void);
+const char* qspec_last_error(void);
+
+/* ---- normalisation + activation quantisation ------------------------------------------------ */
+
+/* qserve_backend.layernorm_ops.rms_norm_general_fuse_sum_i4(out_q, x, input_sum, scaling, eps, True)
+ *   third-party/kernels/csrc/layernorm.cpp:80-83, layernorm_kernels.cu:569-716,890-923
+ *   (called from vllm/model_executor/layers/quarot_nn/normalization.py:56-63)
+ * LayerNorm without gamma + per-token int4 quant.  hidden % 1024 == 0, hidden <= 8192.
+ * input_sum may be NULL (the reference's wrapper drops it). */
+int qspec_rms_norm_general_fuse_sum_i4(int8_t* out_q, const qspec_half* x, qspec_half* input_sum, qspec_half* scaling,
+                                       float eps, int tokens, int hidden, void* stream);
+
+/* layernorm_ops.rms_norm_general_fuse_sum_fp16(out, x, eps)   layernorm.cpp:85-87, layernorm_kernels.cu:927-957
+ *   (normalization.py:76-80) */
+int qspec_rms_norm_general_fuse_sum_fp16(qspec_half* out, const qspec_half* x, float eps, int tokens, int hidden,
+                                         void* stream);
+
+/* Fused forms used by the decoder loop: hidden_out = h(x + delta) (the fp16 residual add of
+ * vllm/model_executor/models/quarot_llama.py:380,390), then the same norm on hidden_out.
+ * delta == NULL -> plain norm of x (hidden_out ignored). */
+int qspec_add_rms_norm_i4(int8_t* out_q, qspec_half* scaling, qspec_half* hidden_out, const qspec_half* x,
+                          const qspec_half* delta, float eps, int tokens, int hidden, void* stream);
+int qspec_add_rms_norm_fp16(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const qspec_half* delta,
+                            float eps, int tokens, int hidden, void* stream);
+
+/* quarot._CUDA.fuse_sym_quant(x, scale, q, clip)   third-party/QuaRot/quarot/kernels/bindings.cpp:128-147,
+ *   quant.cu:102-186 (quarot/__init__.py:119-144, quarot_nn/quantization.py:13-19).  k even. */
+int qspec_fuse_sym_quant(const qspec_half* x, qspec_half* scale, int8_t* q, float clip_ratio, int tokens, int k,
+                         void* stream);
+
+/* ---- online Hadamard ------------------------------------------------------------------------- */
+
+/* fast_hadamard_transform_cuda.faster_fast_hadamard_transform(x, scale, out) / fast_hadamard_transform(x, scale)
+ *   third-party/fast-hadamard-transform/csrc/fast_hadamard_transform.cpp:69-154, ..._cuda.cu:124-198.
+ *   rows of length n (power of two, 2..32768); out = h(WHT(x) * scale). */
+int qspec_fast_hadamard_transform(const qspec_half* x, float scale, qspec_half* out, int64_t rows, int n,
+                                  void* stream);
+
+/* `hadK @ y.view(-1, K, m)` of quarot/functional/hadamard.py:104-108,120 (cuBLAS batched GEMM in the reference).
+ *   y, out [tokens, K, m]; hadK [K, K] fp16; fp32 accumulate in k order. */
+int qspec_hadamard_mix(const qspec_half* y, const qspec_half* hadK, qspec_half* out, int tokens, int K, int m,
+                       void* stream);
+
+/* o_proj input path of QuarotLlamaAttention.forward (quarot_llama.py:231-238): transpose -> FWHT over heads
+ * (* had_scale) -> transpose back [-> Quantizer], one kernel.  attn [tokens, heads, head_dim].
+ *   q == NULL: fp16 result in out_f16 [tokens, heads*head_dim]      (verify, OnlineHadamard w4a4=False)
+ *   q != NULL: int4 rows in q [tokens, heads*head_dim/2] + scale[tokens]  (draft; out_f16 unused) */
+int qspec_heads_hadamard(const qspec_half* attn, qspec_half* out_f16, int8_t* q, qspec_half* scale, float had_scale,
+                         float clip_ratio, int tokens, int heads, int head_dim, void* stream);
+
+/* down_proj input path of QuarotLlamaMLP.forward (quarot_llama.py:279-295): up = gate_up[:, :I],
+ * gate = gate_up[:, I:]; silu(gate)*up -> (hadK (x) H_{I/K}) * had_scale [-> Quantizer], one kernel.
+ * hadK [K,K] fp16 (ignored when K == 1).  Same q == NULL / != NULL convention. */
+int qspec_silu_mul_hadamard(const qspec_half* gate_up, const qspec_half* hadK, qspec_half* out_f16, int8_t* q,
+                            qspec_half* scale, float had_scale, float clip_ratio, int tokens, int intermediate, int K,
+                            void* stream);
+
+/* ---- linear layers over the shared packed-int4 weight buffer --------------------------------- */
+
+/* torch.ops.torchao.rowwise_scaled_linear_cutlass_s4s4_unified(xq, x_scale, wq, w_scale, bias, out)
+ *   third-party/ao/torchao/ops.py:29,600-636; ..._cutlass_s4s4.cu:25-39; ..._unified.cuh:240-488
+ *   (quarot_nn/linear.py:82).  xq [M,K/2], wq [N,K/2] int8 (two s4 per byte), xs [M], ws [N], bias [N] or NULL,
+ *   out [M,N] fp16.  N % 16 == 0, K % 128 == 0. */
+int qspec_rowwise_scaled_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
+                                     const qspec_half* bias, qspec_half* out, int M, int N, int K, void* stream);
+
+/* bitblas.Matmul.__call__(x, w ^ 0x88, output=C, scale=ws, bias=bias)  (quarot_nn/linear.py:102-124,156-211).
+ *   Takes the SAME wq buffer as the s4s4 op (no XOR copy).  x [M,K] fp16. */
+int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* ws, const qspec_half* bias,
+                       qspec_half* out, int M, int N, int K, void* stream);
+
+/* lm_head: F.linear(hidden, lm_head.weight)  (vllm/model_executor/layers/logits_processor.py:92-97). w [N,K] fp16. */
+int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, int M, int N, int K, void* stream);
+
+/* fp16 view of a packed weight with the channel scale folded in (prefill-sized M only). */
+int qspec_dequant_w4(const int8_t* wq, const qspec_half* ws, qspec_half* out, int N, int K, void* stream);
+
+/* ---- attention side --------------------------------------------------------------------------- */
+
+/* torch.ops._C.rotary_embedding(positions, q, k, head_size, cos_sin_cache, is_neox=True)
+ *   csrc/pos_encoding_kernels.cu:71-122 (quarot_llama.py:208-211).  In place. */
+int qspec_rotary_embedding(const int64_t* positions, qspec_half* q, qspec_half* k, const qspec_half* cos_sin_cache,
+                           int tokens, int num_heads, int num_kv_heads, int head_size, int rot_dim, int64_t q_stride,
+                           int64_t k_stride, void* stream);
+
+/* torch.ops._C_cache_ops.reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping, "auto", 1, 1)
+ *   csrc/cache_kernels.cu:207-303 (vllm/attention/backends/flash_attn.py:711-720).
+ *   caches [num_blocks, block_size, num_kv_heads, head_size] fp16. */
+int qspec_reshape_and_cache_flash(const qspec_half* key, const qspec_half* value, qspec_half* key_cache,
+                                  qspec_half* value_cache, const int64_t* slot_mapping, int tokens, int num_kv_heads,
+                                  int head_size, int64_t key_stride, int64_t value_stride, void* stream);
+
+/* The two above fused over the fused qkv row [tokens, (num_heads + 2*num_kv_heads) * head_size]. */
+int qspec_rope_kv_write(const int64_t* positions, qspec_half* qkv, const qspec_half* cos_sin_cache,
+                        qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping, int tokens,
+                        int num_heads, int num_kv_heads, int head_size, int rot_dim, void* stream);
+
+/* flash_attn_with_kvcache (draft, q_len 1) / flash_attn_varlen_func (verify, q_len k+1, causal) over the paged
+ * cache  (vllm/attention/backends/flash_attn.py:741-830).  q rows of sequence s are tokens q_start[s]..q_start[s+1]-1
+ * and sit at absolute positions ctx_lens[s]-q_len .. ctx_lens[s]-1.  head_size must be 128.
+ * workspace: qspec_paged_attention_workspace_bytes(n_seqs*max_q_len, ...) bytes. */
+size_t qspec_paged_attention_workspace_bytes(int max_tokens, int num_heads, int head_size, int n_splits);
+int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_half* key_cache,
+                          const qspec_half* value_cache, const int32_t* block_tables, int max_blocks_per_seq,
+                          const int32_t* ctx_lens, const int32_t* q_start, int n_seqs, int tokens, int max_q_len,
+                          int num_heads, int num_kv_heads, int head_size, int block_size, float sm_scale, int n_splits,
+                          void* workspace, qspec_half* out, void* stream);
+
+/* ---- token side ------------------------------------------------------------------------------- */
+
+/* nn.Embedding lookup (quarot_llama.py:497). */
+int qspec_embedding(const int64_t* ids, const qspec_half* table, qspec_half* out, int tokens, int hidden, int vocab,
+                    void* stream);
+
+/* Sampler.forward, greedy, modify_greedy_probs=False  (vllm/model_executor/layers/sampler.py:216-316):
+ *   probs = softmax(float(logits)) [tokens, vocab] fp32, token = argmax. */
+int qspec_softmax_argmax(const qspec_half* logits, float* probs, int64_t* token, int tokens, int vocab, void* stream);
+
+/* RejectionSampler.forward(target_with_bonus_probs, bonus_token_ids, draft_probs, draft_token_ids)
+ *   vllm/model_executor/layers/rejection_sampler.py:60-154 + spec_decode_base_sampler.py:69-131.
+ *   uniform [B,k] / exponential [B,k,V] fp32: injected random draws (tests); NULL -> Philox(seed, offset).
+ *   out_tokens [B,k+1] (-1 = no token); accepted [B,k] u8; recovered [B,k];
+ *   counters[3] += {accepted, emitted, draft} (may be NULL). */
+int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* bonus_token_ids,
+                           const float* draft_probs, const int64_t* draft_token_ids, const float* uniform,
+                           const float* exponential, uint64_t seed, uint64_t offset, int batch, int k, int vocab,
+                           int64_t* out_tokens, uint8_t* accepted, int64_t* recovered, int64_t* counters,
+                           void* stream);
+
+/* ops.advance_step_flashattn(num_seqs, num_queries, block_size, input_tokens, sampled_token_ids,
+ *   input_positions, seq_lens, slot_mapping, block_tables)   csrc/prepare_inputs/advance_step.cu:14-64,192
+ *   (vllm/attention/backends/flash_attn.py:365-373), num_seqs == num_queries. */
+int qspec_advance_step_flashattn(int num_seqs, int block_size, int64_t* input_tokens,
+                                 const int64_t* sampled_token_ids, int64_t* input_positions, int32_t* seq_lens,
+                                 int64_t* slot_mapping, const int32_t* block_tables, int64_t block_tables_stride,
+                                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QSPEC_HIP_H */

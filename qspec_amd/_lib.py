@@ -1,0 +1,85 @@
+"""ctypes binding of libqspec_hip.so (the C ABI declared in include/qspec_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, this
+module raises.  The CPU oracle under ``oracle/`` is test infrastructure and is
+never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libqspec_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "qspec_hip.h")
+
+_vp, _i, _f, _i64, _u64, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_uint64,
+                                ctypes.c_size_t)
+
+# name -> (restype, argtypes); mirrors include/qspec_hip.h one to one
+SIGNATURES = {
+    "qspec_abi_version": (_i, []),
+    "qspec_last_error": (ctypes.c_char_p, []),
+    "qspec_rms_norm_general_fuse_sum_i4": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "qspec_rms_norm_general_fuse_sum_fp16": (_i, [_vp, _vp, _f, _i, _i, _vp]),
+    "qspec_add_rms_norm_i4": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "qspec_add_rms_norm_fp16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "qspec_fuse_sym_quant": (_i, [_vp, _vp, _vp, _f, _i, _i, _vp]),
+    "qspec_fast_hadamard_transform": (_i, [_vp, _f, _vp, _i64, _i, _vp]),
+    "qspec_hadamard_mix": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qspec_heads_hadamard": (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
+    "qspec_silu_mul_hadamard": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
+    "qspec_rowwise_scaled_linear_s4s4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qspec_w4a16_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qspec_linear_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qspec_dequant_w4": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "qspec_rotary_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _vp]),
+    "qspec_reshape_and_cache_flash": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp]),
+    "qspec_rope_kv_write": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "qspec_paged_attention_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "qspec_paged_attention": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp,
+                                   _vp, _vp]),
+    "qspec_embedding": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qspec_softmax_argmax": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "qspec_rejection_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "qspec_advance_step_flashattn": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+}
+
+
+def header_symbols(path: str = HEADER_PATH):
+    """Every function name declared in include/qspec_hip.h."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qspec_[a-z0-9_]+)\s*\(", text)))
+
+
+class QSpecLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libqspec_hip.so, binding every prototype.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QSpecLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C qspec_amd/csrc`).  There is no CPU fallback for the QSpec hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, lib=None):
+    if rc != 0:
+        lib = lib or load()
+        raise QSpecLibraryError(lib.qspec_last_error().decode())

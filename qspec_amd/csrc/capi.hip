@@ -1,0 +1,234 @@
+// extern "C" boundary: argument checks, error strings, launch-error capture.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/qspec_hip.h"
+#include "kernels.h"
+
+using qspec::f16;
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+static int finish(const char* op, int rc) {
+    if (rc != 0) return fail("%s: unsupported shape/arguments (code %d)", op, rc);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("%s: launch failed: %s", op, hipGetErrorString(e));
+    return 0;
+}
+#define NONNULL(op, p) \
+    if (!(p)) return fail("%s: argument `%s` is NULL", op, #p)
+#define ST ((hipStream_t)stream)
+#define H(p) reinterpret_cast<f16*>(p)
+#define CH(p) reinterpret_cast<const f16*>(p)
+
+extern "C" {
+
+int qspec_abi_version(void) { return 1; }
+const char* qspec_last_error(void) { return g_err; }
+
+int qspec_rms_norm_general_fuse_sum_i4(int8_t* out_q, const qspec_half* x, qspec_half* input_sum, qspec_half* scaling,
+                                       float eps, int tokens, int hidden, void* stream) {
+    const char* op = "qspec_rms_norm_general_fuse_sum_i4";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, out_q); NONNULL(op, x); NONNULL(op, scaling);
+    if (hidden % 1024 || hidden > 8192 || hidden <= 0) return fail("%s: hidden=%d must be a multiple of 1024, <= 8192", op, hidden);
+    return finish(op, qspec::ln_quant_i4(CH(x), nullptr, nullptr, out_q, H(scaling), H(input_sum), eps, tokens, hidden, ST));
+}
+int qspec_rms_norm_general_fuse_sum_fp16(qspec_half* out, const qspec_half* x, float eps, int tokens, int hidden,
+                                         void* stream) {
+    const char* op = "qspec_rms_norm_general_fuse_sum_fp16";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, out); NONNULL(op, x);
+    if (hidden % 1024 || hidden > 8192 || hidden <= 0) return fail("%s: hidden=%d must be a multiple of 1024, <= 8192", op, hidden);
+    return finish(op, qspec::ln_fp16(CH(x), nullptr, nullptr, H(out), eps, tokens, hidden, ST));
+}
+int qspec_add_rms_norm_i4(int8_t* out_q, qspec_half* scaling, qspec_half* hidden_out, const qspec_half* x,
+                          const qspec_half* delta, float eps, int tokens, int hidden, void* stream) {
+    const char* op = "qspec_add_rms_norm_i4";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, out_q); NONNULL(op, x); NONNULL(op, scaling);
+    if (delta) NONNULL(op, hidden_out);
+    if (hidden % 1024 || hidden > 8192 || hidden <= 0) return fail("%s: hidden=%d must be a multiple of 1024, <= 8192", op, hidden);
+    return finish(op, qspec::ln_quant_i4(CH(x), CH(delta), H(hidden_out), out_q, H(scaling), nullptr, eps, tokens, hidden, ST));
+}
+int qspec_add_rms_norm_fp16(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const qspec_half* delta,
+                            float eps, int tokens, int hidden, void* stream) {
+    const char* op = "qspec_add_rms_norm_fp16";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, out); NONNULL(op, x);
+    if (delta) NONNULL(op, hidden_out);
+    if (hidden % 1024 || hidden > 8192 || hidden <= 0) return fail("%s: hidden=%d must be a multiple of 1024, <= 8192", op, hidden);
+    return finish(op, qspec::ln_fp16(CH(x), CH(delta), H(hidden_out), H(out), eps, tokens, hidden, ST));
+}
+int qspec_fuse_sym_quant(const qspec_half* x, qspec_half* scale, int8_t* q, float clip_ratio, int tokens, int k,
+                         void* stream) {
+    const char* op = "qspec_fuse_sym_quant";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, x); NONNULL(op, scale); NONNULL(op, q);
+    if (k <= 0 || k % 2) return fail("%s: k=%d must be positive and even", op, k);
+    return finish(op, qspec::rowabsmax_quant(CH(x), H(scale), q, clip_ratio, tokens, k, ST));
+}
+int qspec_fast_hadamard_transform(const qspec_half* x, float scale, qspec_half* out, int64_t rows, int n,
+                                  void* stream) {
+    const char* op = "qspec_fast_hadamard_transform";
+    if (rows < 0) return fail("%s: rows < 0", op);
+    if (rows == 0) return 0;
+    NONNULL(op, x); NONNULL(op, out);
+    if (n < 2 || n > 32768 || (n & (n - 1))) return fail("%s: n=%d must be a power of two in [2, 32768]", op, n);
+    if (rows > 2147483647LL) return fail("%s: too many rows", op);
+    return finish(op, qspec::fwht(CH(x), scale, H(out), rows, n, ST));
+}
+int qspec_hadamard_mix(const qspec_half* y, const qspec_half* hadK, qspec_half* out, int tokens, int K, int m,
+                       void* stream) {
+    const char* op = "qspec_hadamard_mix";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, y); NONNULL(op, hadK); NONNULL(op, out);
+    if (y == out) return fail("%s: in-place not supported", op);
+    return finish(op, qspec::hadk_mix(CH(y), CH(hadK), H(out), tokens, K, m, ST));
+}
+int qspec_heads_hadamard(const qspec_half* attn, qspec_half* out_f16, int8_t* q, qspec_half* scale, float had_scale,
+                         float clip_ratio, int tokens, int heads, int head_dim, void* stream) {
+    const char* op = "qspec_heads_hadamard";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, attn);
+    if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
+    return finish(op, qspec::heads_hadamard(CH(attn), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, heads, head_dim, ST));
+}
+int qspec_silu_mul_hadamard(const qspec_half* gate_up, const qspec_half* hadK, qspec_half* out_f16, int8_t* q,
+                            qspec_half* scale, float had_scale, float clip_ratio, int tokens, int intermediate, int K,
+                            void* stream) {
+    const char* op = "qspec_silu_mul_hadamard";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, gate_up);
+    if (K > 1) NONNULL(op, hadK);
+    if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
+    if (intermediate % 8) return fail("%s: intermediate %% 8 != 0", op);
+    return finish(op, qspec::silu_mul_hadamard(CH(gate_up), CH(hadK), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, intermediate, K, ST));
+}
+int qspec_rowwise_scaled_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
+                                     const qspec_half* bias, qspec_half* out, int M, int N, int K, void* stream) {
+    const char* op = "qspec_rowwise_scaled_linear_s4s4";
+    if (M < 0 || N < 0) return fail("%s: negative size", op);
+    if (M == 0 || N == 0) return 0;
+    NONNULL(op, xq); NONNULL(op, xs); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, out);
+    if (N % 16 || K % 128 || K <= 0) return fail("%s: need N %% 16 == 0 and K %% 128 == 0 (N=%d K=%d)", op, N, K);
+    return finish(op, qspec::gemm_w4a4(xq, CH(xs), wq, CH(ws), CH(bias), H(out), M, N, K, ST));
+}
+int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* ws, const qspec_half* bias,
+                       qspec_half* out, int M, int N, int K, void* stream) {
+    const char* op = "qspec_w4a16_linear";
+    if (M < 0 || N < 0) return fail("%s: negative size", op);
+    if (M == 0 || N == 0) return 0;
+    NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, out);
+    if (N % 16 || K % 128 || K <= 0) return fail("%s: need N %% 16 == 0 and K %% 128 == 0 (N=%d K=%d)", op, N, K);
+    return finish(op, qspec::gemm_w4a16(CH(x), wq, CH(ws), CH(bias), H(out), M, N, K, ST));
+}
+int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, int M, int N, int K, void* stream) {
+    const char* op = "qspec_linear_f16";
+    if (M < 0 || N < 0) return fail("%s: negative size", op);
+    if (M == 0 || N == 0) return 0;
+    NONNULL(op, x); NONNULL(op, w); NONNULL(op, out);
+    if (K % 32 || K <= 0) return fail("%s: need K %% 32 == 0 (K=%d)", op, K);
+    return finish(op, qspec::gemm_f16(CH(x), CH(w), H(out), M, N, K, ST));
+}
+int qspec_dequant_w4(const int8_t* wq, const qspec_half* ws, qspec_half* out, int N, int K, void* stream) {
+    const char* op = "qspec_dequant_w4";
+    if (N == 0) return 0;
+    NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, out);
+    return finish(op, qspec::dequant_w4(wq, CH(ws), H(out), N, K, ST));
+}
+int qspec_rotary_embedding(const int64_t* positions, qspec_half* q, qspec_half* k, const qspec_half* cos_sin_cache,
+                           int tokens, int num_heads, int num_kv_heads, int head_size, int rot_dim, int64_t q_stride,
+                           int64_t k_stride, void* stream) {
+    const char* op = "qspec_rotary_embedding";
+    if (tokens == 0) return 0;
+    NONNULL(op, positions); NONNULL(op, q); NONNULL(op, k); NONNULL(op, cos_sin_cache);
+    return finish(op, qspec::rotary_embedding(positions, H(q), H(k), CH(cos_sin_cache), tokens, num_heads, num_kv_heads, head_size, rot_dim, q_stride, k_stride, ST));
+}
+int qspec_reshape_and_cache_flash(const qspec_half* key, const qspec_half* value, qspec_half* key_cache,
+                                  qspec_half* value_cache, const int64_t* slot_mapping, int tokens, int num_kv_heads,
+                                  int head_size, int64_t key_stride, int64_t value_stride, void* stream) {
+    const char* op = "qspec_reshape_and_cache_flash";
+    if (tokens == 0) return 0;
+    NONNULL(op, key); NONNULL(op, value); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
+    return finish(op, qspec::reshape_and_cache_flash(CH(key), CH(value), H(key_cache), H(value_cache), slot_mapping, tokens, num_kv_heads, head_size, key_stride, value_stride, ST));
+}
+int qspec_rope_kv_write(const int64_t* positions, qspec_half* qkv, const qspec_half* cos_sin_cache,
+                        qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping, int tokens,
+                        int num_heads, int num_kv_heads, int head_size, int rot_dim, void* stream) {
+    const char* op = "qspec_rope_kv_write";
+    if (tokens == 0) return 0;
+    NONNULL(op, positions); NONNULL(op, qkv); NONNULL(op, cos_sin_cache); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
+    return finish(op, qspec::rope_kv_write(positions, H(qkv), CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, tokens, num_heads, num_kv_heads, head_size, rot_dim, ST));
+}
+size_t qspec_paged_attention_workspace_bytes(int max_tokens, int num_heads, int head_size, int n_splits) {
+    return qspec::paged_attention_ws_bytes(max_tokens, num_heads, head_size, n_splits);
+}
+int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_half* key_cache,
+                          const qspec_half* value_cache, const int32_t* block_tables, int max_blocks_per_seq,
+                          const int32_t* ctx_lens, const int32_t* q_start, int n_seqs, int tokens, int max_q_len,
+                          int num_heads, int num_kv_heads, int head_size, int block_size, float sm_scale, int n_splits,
+                          void* workspace, qspec_half* out, void* stream) {
+    const char* op = "qspec_paged_attention";
+    if (n_seqs == 0 || tokens == 0) return 0;
+    NONNULL(op, q); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, block_tables); NONNULL(op, ctx_lens);
+    NONNULL(op, q_start); NONNULL(op, workspace); NONNULL(op, out);
+    if (head_size != 128) return fail("%s: head_size=%d (only 128 is built)", op, head_size);
+    if (tokens > n_seqs * max_q_len) return fail("%s: tokens=%d > n_seqs*max_q_len=%d", op, tokens, n_seqs * max_q_len);
+    int rc = qspec::paged_attention(CH(q), q_stride, CH(key_cache), CH(value_cache), block_tables, max_blocks_per_seq, ctx_lens, q_start, n_seqs, max_q_len, num_heads, num_kv_heads, head_size, block_size, sm_scale, n_splits, (float*)workspace, H(out), ST);
+    if (rc) return finish(op, rc);
+    return finish(op, qspec::paged_attention_combine((const float*)workspace, tokens, n_seqs * max_q_len, num_heads, head_size, n_splits, H(out), ST));
+}
+int qspec_embedding(const int64_t* ids, const qspec_half* table, qspec_half* out, int tokens, int hidden, int vocab,
+                    void* stream) {
+    const char* op = "qspec_embedding";
+    if (tokens == 0) return 0;
+    NONNULL(op, ids); NONNULL(op, table); NONNULL(op, out);
+    return finish(op, qspec::embedding(ids, CH(table), H(out), tokens, hidden, vocab, ST));
+}
+int qspec_softmax_argmax(const qspec_half* logits, float* probs, int64_t* token, int tokens, int vocab, void* stream) {
+    const char* op = "qspec_softmax_argmax";
+    if (tokens == 0) return 0;
+    NONNULL(op, logits); NONNULL(op, probs); NONNULL(op, token);
+    return finish(op, qspec::softmax_argmax(CH(logits), probs, token, tokens, vocab, ST));
+}
+int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* bonus_token_ids,
+                           const float* draft_probs, const int64_t* draft_token_ids, const float* uniform,
+                           const float* exponential, uint64_t seed, uint64_t offset, int batch, int k, int vocab,
+                           int64_t* out_tokens, uint8_t* accepted, int64_t* recovered, int64_t* counters,
+                           void* stream) {
+    const char* op = "qspec_rejection_sample";
+    if (batch == 0) return 0;
+    NONNULL(op, target_with_bonus_probs); NONNULL(op, bonus_token_ids); NONNULL(op, draft_probs);
+    NONNULL(op, draft_token_ids); NONNULL(op, out_tokens); NONNULL(op, accepted); NONNULL(op, recovered);
+    if (k < 1) return fail("%s: k=%d must be >= 1", op, k);
+    return finish(op, qspec::rejection_sample(target_with_bonus_probs, draft_probs, draft_token_ids, bonus_token_ids, uniform, exponential, seed, offset, batch, k, vocab, out_tokens, accepted, recovered, counters, ST));
+}
+int qspec_advance_step_flashattn(int num_seqs, int block_size, int64_t* input_tokens,
+                                 const int64_t* sampled_token_ids, int64_t* input_positions, int32_t* seq_lens,
+                                 int64_t* slot_mapping, const int32_t* block_tables, int64_t block_tables_stride,
+                                 void* stream) {
+    const char* op = "qspec_advance_step_flashattn";
+    if (num_seqs == 0) return 0;
+    NONNULL(op, input_tokens); NONNULL(op, sampled_token_ids); NONNULL(op, input_positions); NONNULL(op, seq_lens);
+    NONNULL(op, slot_mapping); NONNULL(op, block_tables);
+    return finish(op, qspec::advance_step(num_seqs, block_size, input_tokens, sampled_token_ids, input_positions, seq_lens, slot_mapping, block_tables, block_tables_stride, ST));
+}
+
+}  // extern "C"

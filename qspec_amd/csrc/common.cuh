@@ -1,0 +1,69 @@
+// Shared device helpers for the QSpec gfx950 kernels.
+// Wave = 64 lanes everywhere; no CUDA-compat shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace qspec {
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32;
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+// fp16 <-> fp32: v_cvt_f32_f16 is exact, v_cvt_f16_f32 rounds to nearest even
+// in the default float mode hipcc sets for kernels.
+__device__ __forceinline__ float h2f(f16 h) { return (float)h; }
+__device__ __forceinline__ f16 f2h(float f) { return (f16)f; }
+__device__ __forceinline__ f16 u2h(uint16_t u) { return __builtin_bit_cast(f16, u); }
+__device__ __forceinline__ uint16_t h2u(f16 h) { return __builtin_bit_cast(uint16_t, h); }
+
+// Deterministic expf -- bit-identical to oracle/qspec_oracle.c:qexpf (only
+// v_fma_f32 / v_rndne_f32 / v_ldexp_f32, all exactly specified).
+__device__ __forceinline__ float qexpf(float x) {
+    if (x != x) return x;
+    if (x > 88.0f) return __builtin_inff();
+    if (x < -86.0f) return 0.0f;
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float z = r * r;
+    float y = __builtin_fmaf(p, z, r) + 1.0f;
+    return __builtin_ldexpf(y, (int)n);
+}
+
+// round-to-nearest-even to integer with saturation, NaN -> 0
+__device__ __forceinline__ int rni_sat(float v, int lo, int hi) {
+    if (v != v) return 0;
+    float r = __builtin_rintf(v);
+    r = r < (float)lo ? (float)lo : r;
+    r = r > (float)hi ? (float)hi : r;
+    return (int)r;
+}
+
+// cross-lane xor shuffle inside a wave64 (ds_bpermute; no LDS storage used)
+__device__ __forceinline__ float shfl_xor_f(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ int shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
+
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, shfl_xor_f(v, m));
+    return v;
+}
+
+// pack two int4 values (two's complement) into one byte: lo nibble = even index
+__device__ __forceinline__ uint32_t pack_nib(int q0, int q1) { return (uint32_t)(q0 & 0xF) | ((uint32_t)(q1 & 0xF) << 4); }
+
+}  // namespace qspec

@@ -1,0 +1,343 @@
+// Skinny GEMMs of the draft/verify path over ONE shared packed-int4 weight buffer.
+//
+// Replaces (reference, relative to /root/reference):
+//   rowwise_scaled_linear_kernel_cutlass_sm8x_unified<s4,s4>
+//       third-party/ao/torchao/csrc/cuda/rowwise_scaled_linear_cutlass/rowwise_scaled_linear_cutlass_unified.cuh:240-488
+//       (Python: vllm/model_executor/layers/quarot_nn/linear.py:67-84)            -> gemm_w4a4
+//   bitblas.Matmul (W4A16, per-channel scale, `weight ^ 0x88` copy each call)
+//       quarot_nn/linear.py:102-124,156-211                                       -> gemm_w4a16
+//   lm_head nn.Linear (vllm/model_executor/layers/logits_processor.py:92-97)      -> gemm_f16
+//
+// Weight layout is the checkpoint's own: W[N, K/2] bytes, byte j of a row =
+// (w[2j] & 0xF) | (w[2j+1] << 4), two's complement.  Both kernels read those
+// bytes directly ("two views of one buffer"): the draft view widens nibbles to
+// int8*16 with two bit-ops per dword and feeds v_mfma_i32_16x16x64_i8; the
+// verify view flips the sign bit (offset binary, what the reference does with
+// a full-weight XOR pass per call), splices nibbles into fp16 mantissas and
+// feeds v_mfma_f32_16x16x32_f16.  No repacking, no second copy.
+//
+// Decode shapes (M <= 64 tokens) are pure weight streaming, so:
+//   * one workgroup = one 16-row weight tile, its 4 waves interleave over K in
+//     64-byte steps -> the 4 waves together read 256 contiguous bytes of each
+//     of the 16 rows per trip, every byte of W is fetched exactly once;
+//   * weights go HBM -> VGPR directly (16 B per lane, deep unroll); there is
+//     no reuse inside a workgroup so an LDS round trip would be pure overhead;
+//   * the MFMA contraction index may be permuted freely as long as A and B
+//     fragments use the same permutation, so nibbles are never re-ordered:
+//     activation fragments are loaded with the same per-lane byte offsets and
+//     pushed through the same bit-ops;
+//   * cross-wave (split-K) reduction goes through 4 KB of LDS in a fixed
+//     order -> deterministic, no atomics, epilogue fused.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace qspec {
+
+#define QS_UNROLL_K 4
+
+// Two packed dwords (16 nibbles) -> one MFMA i8 operand (16 int8, each = nibble*16):
+// even nibbles land in the high half of each byte via (p << 4), odd nibbles are already there.
+__device__ __forceinline__ i32x4 widen_s4x16(u32 p0, u32 p1) {
+    return i32x4{(int)((p0 << 4) & 0xF0F0F0F0u), (int)(p0 & 0xF0F0F0F0u), (int)((p1 << 4) & 0xF0F0F0F0u),
+                 (int)(p1 & 0xF0F0F0F0u)};
+}
+
+// ------------------------------------------------------------------ W4A4
+// out[m,n] = h( (f(acc[m,n]) * f(sa[m])) * f(sw[n]) (+ f(bias[n])) ),  acc = sum_k a[m,k] w[n,k]  (int32, exact)
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_w4a4_kernel(const int8_t* __restrict__ xq, const f16* __restrict__ xs,
+                                                         const int8_t* __restrict__ wq, const f16* __restrict__ ws,
+                                                         const f16* __restrict__ bias, f16* __restrict__ out, int M,
+                                                         int N, int K, int m_base) {
+    __shared__ int red[4][MT][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int Kb = K >> 1;
+    const int nsteps = Kb >> 6;  // 64 bytes of every row per step
+    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)(n0 + r) * Kb + g * 16;
+    const uint8_t* arow[MT];
+    bool aval[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int m = m_base + mt * 16 + r;
+        aval[mt] = m < M;
+        arow[mt] = reinterpret_cast<const uint8_t*>(xq) + (size_t)(aval[mt] ? m : 0) * Kb + g * 16;
+    }
+    i32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] = i32x4{0, 0, 0, 0};
+
+    int s = wave;
+    for (; s + 4 * (QS_UNROLL_K - 1) < nsteps; s += 4 * QS_UNROLL_K) {
+        u32x4 w[QS_UNROLL_K];
+        u32x4 a[QS_UNROLL_K][MT];
+#pragma unroll
+        for (int u = 0; u < QS_UNROLL_K; u++) {
+            w[u] = *reinterpret_cast<const u32x4*>(wrow + (size_t)(s + 4 * u) * 64);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                a[u][mt] = u32x4{0, 0, 0, 0};
+                if (aval[mt]) a[u][mt] = *reinterpret_cast<const u32x4*>(arow[mt] + (size_t)(s + 4 * u) * 64);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < QS_UNROLL_K; u++) {
+            const i32x4 b0 = widen_s4x16(w[u][0], w[u][1]), b1 = widen_s4x16(w[u][2], w[u][3]);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const i32x4 a0 = widen_s4x16(a[u][mt][0], a[u][mt][1]), a1 = widen_s4x16(a[u][mt][2], a[u][mt][3]);
+                acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    for (; s < nsteps; s += 4) {
+        u32x4 w = *reinterpret_cast<const u32x4*>(wrow + (size_t)s * 64);
+        const i32x4 b0 = widen_s4x16(w[0], w[1]), b1 = widen_s4x16(w[2], w[3]);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            u32x4 a = u32x4{0, 0, 0, 0};
+            if (aval[mt]) a = *reinterpret_cast<const u32x4*>(arow[mt] + (size_t)s * 64);
+            const i32x4 a0 = widen_s4x16(a[0], a[1]), a1 = widen_s4x16(a[2], a[3]);
+            acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc[mt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) red[wave][mt][i * 64 + lane] = acc[mt][i];
+    __syncthreads();
+    // thread t owns accumulator element (reg = t>>6, lane = t&63): row = 4*(lane>>4)+reg, col = lane&15
+    const int t = threadIdx.x, el = t & 63, reg = t >> 6;
+    const int n = n0 + (el & 15);
+    const float swn = h2f(ws[n]);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int m = m_base + mt * 16 + 4 * (el >> 4) + reg;
+        if (m < M) {
+            int sum = red[0][mt][t] + red[1][mt][t] + red[2][mt][t] + red[3][mt][t];
+            float v = ((float)(sum >> 8) * h2f(xs[m])) * swn;  // both operands carried a factor 16
+            if (bias) v = v + h2f(bias[n]);
+            out[(size_t)m * N + n] = f2h(v);
+        }
+    }
+}
+
+int gemm_w4a4(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M,
+              int N, int K, hipStream_t st) {
+    if (M == 0 || N == 0) return 0;
+    if (N % 16 || K % 128 || K > (1 << 19)) return -1;
+    // up to 64 rows per pass over the weights; larger M re-streams W (prefill-sized M is not this kernel's job)
+    for (int mb = 0; mb < M; mb += 64) {
+        int rows = M - mb;
+        if (rows <= 16)
+            hipLaunchKernelGGL((gemm_w4a4_kernel<1>), dim3(N / 16), dim3(256), 0, st, xq, xs, wq, ws, bias, out, M, N, K, mb);
+        else if (rows <= 32)
+            hipLaunchKernelGGL((gemm_w4a4_kernel<2>), dim3(N / 16), dim3(256), 0, st, xq, xs, wq, ws, bias, out, M, N, K, mb);
+        else
+            hipLaunchKernelGGL((gemm_w4a4_kernel<4>), dim3(N / 16), dim3(256), 0, st, xq, xs, wq, ws, bias, out, M, N, K, mb);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ W4A16
+// One dword = 8 nibbles n0..n7.  After p ^= 0x88888888 each nibble is u = w + 8.
+//   (p & 0x000F000F) | 0x64006400  -> halves (1024+u0, 1024+u4);  - 1032        -> (w0, w4)
+//   (p & 0x00F000F0) | 0x64006400  -> halves (1024+16u1, 1024+16u5); *1/16 - 72 -> (w1, w5)
+//   same on p >> 8                 -> (w2, w6), (w3, w7)
+// so one B fragment (8 fp16) holds k-order 0,4,1,5,2,6,3,7 of its dword; the
+// activation fragment is shuffled into the same order with 4 v_perm_b32.
+__device__ __forceinline__ f16x8 dequant_s4x8(u32 p) {
+    p ^= 0x88888888u;
+    const u32 q = p >> 8;
+    u32 r0 = (p & 0x000F000Fu) | 0x64006400u;
+    u32 r1 = (p & 0x00F000F0u) | 0x64006400u;
+    u32 r2 = (q & 0x000F000Fu) | 0x64006400u;
+    u32 r3 = (q & 0x00F000F0u) | 0x64006400u;
+    const f16x2 c1032 = {(f16)1032.0f, (f16)1032.0f};
+    const f16x2 c16 = {(f16)0.0625f, (f16)0.0625f};
+    const f16x2 c72 = {(f16)72.0f, (f16)72.0f};
+    f16x2 h0 = __builtin_bit_cast(f16x2, r0) - c1032;
+    f16x2 h1 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, r1), c16, -c72);
+    f16x2 h2 = __builtin_bit_cast(f16x2, r2) - c1032;
+    f16x2 h3 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, r3), c16, -c72);
+    return f16x8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+}
+// 8 consecutive fp16 (4 dwords) -> order 0,4,1,5,2,6,3,7
+__device__ __forceinline__ f16x8 shuffle_act8(u32x4 a) {
+    u32x4 o;
+    o[0] = __builtin_amdgcn_perm(a[2], a[0], 0x05040100u);
+    o[1] = __builtin_amdgcn_perm(a[2], a[0], 0x07060302u);
+    o[2] = __builtin_amdgcn_perm(a[3], a[1], 0x05040100u);
+    o[3] = __builtin_amdgcn_perm(a[3], a[1], 0x07060302u);
+    return __builtin_bit_cast(f16x8, o);
+}
+
+// out[m,n] = h( (sum_k f(x[m,k]) * w[n,k]) * f(sw[n]) (+ f(bias[n])) ), fp32 accumulate
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_w4a16_kernel(const f16* __restrict__ x, const int8_t* __restrict__ wq,
+                                                          const f16* __restrict__ ws, const f16* __restrict__ bias,
+                                                          f16* __restrict__ out, int M, int N, int K, int m_base) {
+    __shared__ float red[4][MT][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int Kb = K >> 1;
+    const int nsteps = Kb >> 6;
+    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)(n0 + r) * Kb + g * 16;
+    const f16* arow[MT];
+    bool aval[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int m = m_base + mt * 16 + r;
+        aval[mt] = m < M;
+        arow[mt] = x + (size_t)(aval[mt] ? m : 0) * K + g * 32;  // 16 packed bytes = 32 k
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int s = wave; s < nsteps; s += 4) {
+        u32x4 w = *reinterpret_cast<const u32x4*>(wrow + (size_t)s * 64);
+        u32x4 a[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int dd = 0; dd < 4; dd++) {
+                a[mt][dd] = u32x4{0, 0, 0, 0};
+                if (aval[mt]) a[mt][dd] = *reinterpret_cast<const u32x4*>(arow[mt] + (size_t)s * 128 + dd * 8);
+            }
+#pragma unroll
+        for (int dd = 0; dd < 4; dd++) {
+            f16x8 b = dequant_s4x8(w[dd]);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(shuffle_act8(a[mt][dd]), b, acc[mt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) red[wave][mt][i * 64 + lane] = acc[mt][i];
+    __syncthreads();
+    const int t = threadIdx.x, el = t & 63, reg = t >> 6;
+    const int n = n0 + (el & 15);
+    const float swn = h2f(ws[n]);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int m = m_base + mt * 16 + 4 * (el >> 4) + reg;
+        if (m < M) {
+            float sum = ((red[0][mt][t] + red[1][mt][t]) + red[2][mt][t]) + red[3][mt][t];
+            float v = sum * swn;
+            if (bias) v = v + h2f(bias[n]);
+            out[(size_t)m * N + n] = f2h(v);
+        }
+    }
+}
+
+int gemm_w4a16(const f16* x, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M, int N, int K,
+               hipStream_t st) {
+    if (M == 0 || N == 0) return 0;
+    if (N % 16 || K % 128) return -1;
+    for (int mb = 0; mb < M; mb += 32) {
+        int rows = M - mb;
+        if (rows <= 16)
+            hipLaunchKernelGGL((gemm_w4a16_kernel<1>), dim3(N / 16), dim3(256), 0, st, x, wq, ws, bias, out, M, N, K, mb);
+        else
+            hipLaunchKernelGGL((gemm_w4a16_kernel<2>), dim3(N / 16), dim3(256), 0, st, x, wq, ws, bias, out, M, N, K, mb);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ fp16 x fp16^T (lm_head)
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_f16_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
+                                                        f16* __restrict__ out, int M, int N, int K, int m_base) {
+    __shared__ float red[4][MT][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nsteps = K >> 5;  // 32 k (64 bytes) of every row per step
+    const bool nval = n0 + r < N;
+    const f16* wrow = w + (size_t)(nval ? n0 + r : 0) * K + g * 8;
+    const f16* arow[MT];
+    bool aval[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int m = m_base + mt * 16 + r;
+        aval[mt] = m < M;
+        arow[mt] = x + (size_t)(aval[mt] ? m : 0) * K + g * 8;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+    for (int s = wave; s < nsteps; s += 4) {
+        f16x8 b = nval ? *reinterpret_cast<const f16x8*>(wrow + (size_t)s * 32) : zero8;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            f16x8 a = aval[mt] ? *reinterpret_cast<const f16x8*>(arow[mt] + (size_t)s * 32) : zero8;
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[mt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) red[wave][mt][i * 64 + lane] = acc[mt][i];
+    __syncthreads();
+    const int t = threadIdx.x, el = t & 63, reg = t >> 6;
+    const int n = n0 + (el & 15);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int m = m_base + mt * 16 + 4 * (el >> 4) + reg;
+        if (m < M && n < N) {
+            float sum = ((red[0][mt][t] + red[1][mt][t]) + red[2][mt][t]) + red[3][mt][t];
+            out[(size_t)m * N + n] = f2h(sum);
+        }
+    }
+}
+
+int gemm_f16(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st) {
+    if (M == 0 || N == 0) return 0;
+    if (K % 32) return -1;
+    const int grid = (N + 15) / 16;
+    for (int mb = 0; mb < M; mb += 32) {
+        int rows = M - mb;
+        if (rows <= 16)
+            hipLaunchKernelGGL((gemm_f16_kernel<1>), dim3(grid), dim3(256), 0, st, x, w, out, M, N, K, mb);
+        else
+            hipLaunchKernelGGL((gemm_f16_kernel<2>), dim3(grid), dim3(256), 0, st, x, w, out, M, N, K, mb);
+    }
+    return 0;
+}
+
+// fp16 view of the packed weights with the channel scale folded in: out[n,k] = h(w[n,k] * f(sw[n])).
+// Used only for prefill-sized M (library GEMM on the dequantised tile), never on the decode path.
+__global__ __launch_bounds__(256) void dequant_w4_kernel(const int8_t* __restrict__ wq, const f16* __restrict__ ws,
+                                                          f16* __restrict__ out, int Kb) {
+    const int n = blockIdx.x;
+    const float s = h2f(ws[n]);
+    const uint8_t* wr = reinterpret_cast<const uint8_t*>(wq) + (size_t)n * Kb;
+    for (int j = threadIdx.x; j < Kb / 4; j += 256) {
+        u32 p = *reinterpret_cast<const u32*>(wr + 4 * j);
+        f16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            int v = (int)((p >> (4 * c)) & 0xF);
+            v = v >= 8 ? v - 16 : v;
+            o[c] = f2h((float)v * s);
+        }
+        *reinterpret_cast<f16x8*>(out + (size_t)n * Kb * 2 + 8 * j) = o;
+    }
+}
+int dequant_w4(const int8_t* wq, const f16* ws, f16* out, int N, int K, hipStream_t st) {
+    if (N == 0) return 0;
+    if (K % 8) return -1;
+    hipLaunchKernelGGL(dequant_w4_kernel, dim3(N), dim3(256), 0, st, wq, ws, out, K / 2);
+    return 0;
+}
+
+}  // namespace qspec

@@ -1,0 +1,321 @@
+// Online Hadamard rotations (and what is fused around them).
+//
+// Replaces (reference, relative to /root/reference):
+//   fast_hadamard_transform_kernel        third-party/fast-hadamard-transform/csrc/fast_hadamard_transform_cuda.cu:124-198
+//   opt_matmul_hadU_cuda / matmul_hadU_cuda  third-party/QuaRot/quarot/functional/hadamard.py:94-124
+//   OnlineHadamard.forward                vllm/model_executor/layers/quarot_nn/hadamard.py:23-41
+//   heads transpose/FWHT/transpose        vllm/model_executor/models/quarot_llama.py:231-234
+//   silu(gate)*up                         quarot_llama.py:279-284
+//   rowAbsMaxQuantizeKernel (fused tail)  third-party/QuaRot/quarot/kernels/quant.cu:102-167
+//
+// All butterflies run in fp32 in increasing-stride order (element-index bit 0
+// first), which is the order of the reference kernel (in-thread bits, lane
+// bits, chunk bits) and of the oracle, so results are bit-identical whatever
+// the lane mapping.  The reference needs 2 transposes + .contiguous() around
+// the head transform and a cuBLAS batched GEMM for the had28 mix; here each is
+// one kernel that reads the producer's layout directly.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace qspec {
+
+// ------------------------------------------------------------ generic FWHT
+// One workgroup per row, row staged in LDS as fp32.  API-parity kernel for
+// fast_hadamard_transform(x, scale); the engine uses the fused kernels below.
+__global__ __launch_bounds__(256) void fwht_kernel(const f16* __restrict__ x, float scale, f16* __restrict__ out,
+                                                    int N) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* v = reinterpret_cast<float*>(smem_raw);
+    const size_t base = (size_t)blockIdx.x * N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) v[i] = h2f(x[base + i]);
+    __syncthreads();
+    for (int stride = 1; stride < N; stride <<= 1) {
+        for (int b = threadIdx.x; b < N / 2; b += blockDim.x) {
+            int lo = b & (stride - 1);
+            int i = ((b - lo) << 1) + lo;
+            float a = v[i], c = v[i + stride];
+            v[i] = a + c;
+            v[i + stride] = a - c;
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < N; i += blockDim.x) out[base + i] = f2h(v[i] * scale);
+}
+
+int fwht(const f16* x, float scale, f16* out, int64_t rows, int N, hipStream_t st) {
+    if (rows == 0) return 0;
+    if (N < 2 || N > 32768 || (N & (N - 1))) return -1;
+    int threads = N / 2 < 64 ? 64 : (N / 2 > 256 ? 256 : N / 2);
+    hipLaunchKernelGGL(fwht_kernel, dim3((unsigned)rows), dim3(threads), (size_t)N * sizeof(float), st, x, scale, out, N);
+    return 0;
+}
+
+// z[t,i,j] = h(sum_k f(hadK[i,k]) * f(y[t,k,j])), fp32 fma chain in k order.
+__global__ __launch_bounds__(256) void hadk_mix_kernel(const f16* __restrict__ y, const f16* __restrict__ hadK,
+                                                        f16* __restrict__ out, int K, int M) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* had = reinterpret_cast<float*>(smem_raw);
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) had[i] = h2f(hadK[i]);
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * K * M;
+    for (int j = threadIdx.x; j < M; j += blockDim.x)
+        for (int i = 0; i < K; i++) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; k++) acc = __builtin_fmaf(had[i * K + k], h2f(y[base + (size_t)k * M + j]), acc);
+            out[base + (size_t)i * M + j] = f2h(acc);
+        }
+}
+
+int hadk_mix(const f16* y, const f16* hadK, f16* out, int T, int K, int M, hipStream_t st) {
+    if (T == 0) return 0;
+    if (K < 1 || K > 172) return -1;
+    hipLaunchKernelGGL(hadk_mix_kernel, dim3(T), dim3(256), (size_t)K * K * sizeof(float), st, y, hadK, out, K, M);
+    return 0;
+}
+
+// ------------------------------------------------- heads Hadamard (o_proj)
+// attn [T, NH, d] -> y[t, h', d] = h( (sum_h H[h',h] attn[t,h,d]) * had_scale ), then either fp16 out
+// (verify) or row-absmax int4 quant of the whole [NH*d] row (draft).
+// One workgroup (d/2 lanes) per token; each lane owns a column pair and all NH heads in registers.
+template <int NH, bool QUANT>
+__global__ __launch_bounds__(128) void heads_hadamard_kernel(const f16* __restrict__ attn, f16* __restrict__ out16,
+                                                             int8_t* __restrict__ q, f16* __restrict__ scale,
+                                                             float had_scale, float clip, int d) {
+    __shared__ float red[2];
+    const int t = blockIdx.x, j = threadIdx.x;
+    const f16* ar = attn + (size_t)t * NH * d + 2 * j;
+    const bool act = 2 * j < d;  // lanes past d/2 only take part in the wave reduction
+    float v0[NH], v1[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        f16x2 a = {(f16)0.0f, (f16)0.0f};
+        if (act) a = *reinterpret_cast<const f16x2*>(ar + (size_t)h * d);
+        v0[h] = h2f(a[0]);
+        v1[h] = h2f(a[1]);
+    }
+#pragma unroll
+    for (int stride = 1; stride < NH; stride <<= 1) {
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            if (!(h & stride)) {
+                float a = v0[h], b = v0[h + stride];
+                v0[h] = a + b;
+                v0[h + stride] = a - b;
+                a = v1[h];
+                b = v1[h + stride];
+                v1[h] = a + b;
+                v1[h + stride] = a - b;
+            }
+        }
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        v0[h] = h2f(f2h(v0[h] * had_scale));
+        v1[h] = h2f(f2h(v1[h] * had_scale));
+        if (QUANT) {
+            float a0 = __builtin_fabsf(v0[h]), a1 = __builtin_fabsf(v1[h]);
+            amax = a0 > amax ? a0 : amax;
+            amax = a1 > amax ? a1 : amax;
+        }
+    }
+    if (!QUANT) {
+        if (!act) return;
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            f16x2 o = {f2h(v0[h]), f2h(v1[h])};
+            *reinterpret_cast<f16x2*>(out16 + (size_t)t * NH * d + (size_t)h * d + 2 * j) = o;
+        }
+        return;
+    }
+    amax = wave_max_f(amax);
+    if (blockDim.x > 64) {
+        if ((j & 63) == 0) red[j >> 6] = amax;
+        __syncthreads();
+        amax = fmaxf(red[0], red[1]);
+    }
+    const f16 sc = f2h(h2f(f2h(amax / 7.0f)) * h2f(f2h(clip)));
+    const float scf = h2f(sc);
+    if (j == 0) scale[t] = sc;
+    if (!act) return;
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        int q0 = rni_sat(h2f(f2h(v0[h] / scf)), -8, 7);
+        int q1 = rni_sat(h2f(f2h(v1[h] / scf)), -8, 7);
+        q[(size_t)t * (NH * d / 2) + (size_t)h * (d / 2) + j] = (int8_t)pack_nib(q0, q1);
+    }
+}
+
+int heads_hadamard(const f16* attn, f16* out_f16, int8_t* q, f16* scale, float had_scale, float clip, int T, int heads,
+                   int d, hipStream_t st) {
+    if (T == 0) return 0;
+    if (d % 2 || d / 2 > 128) return -1;
+    const int threads = ((d / 2 + 63) / 64) * 64;
+    const bool quant = q != nullptr;
+#define QS_HH(NHV)                                                                                               \
+    if (heads == NHV) {                                                                                           \
+        if (quant)                                                                                                \
+            hipLaunchKernelGGL((heads_hadamard_kernel<NHV, true>), dim3(T), dim3(threads), 0, st, attn, out_f16, q, \
+                               scale, had_scale, clip, d);                                                        \
+        else                                                                                                      \
+            hipLaunchKernelGGL((heads_hadamard_kernel<NHV, false>), dim3(T), dim3(threads), 0, st, attn, out_f16, q, \
+                               scale, had_scale, clip, d);                                                        \
+        return 0;                                                                                                 \
+    }
+    QS_HH(8) QS_HH(16) QS_HH(32) QS_HH(64)
+#undef QS_HH
+    return -1;
+}
+
+// ------------------------------------- silu*up -> (hadK (x) H_P) -> quant (down_proj)
+// gate_up [T, 2I] (up first, gate second).  I = K * P, P a power of two.
+//   g[e]    = h( h(silu(gate[e])) * up[e] )
+//   y[k,:]  = h( WHT_P(g[k,:]) * had_scale )
+//   z[i,j]  = h( sum_k hadK[i,k] y[k,j] )            (K == 1: z = y)
+//   draft: row-absmax int4 of z (index i*P + j); verify: fp16 z.
+// One 256-thread workgroup per token.  LDS: y fp16 [K][P], z fp16 [K][P], hadK fp32 [K][K].
+template <int EPL>  // elements per lane in the FWHT phase = P / 64
+__global__ __launch_bounds__(256) void silu_mul_hadamard_kernel(const f16* __restrict__ gate_up,
+                                                                const f16* __restrict__ hadK,
+                                                                f16* __restrict__ out16, int8_t* __restrict__ q,
+                                                                f16* __restrict__ scale, float had_scale, float clip,
+                                                                int I, int K) {
+    constexpr int P = EPL * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // all LDS in the one dynamic region so every carve stays 16-byte aligned
+    float* red = reinterpret_cast<float*>(smem_raw);
+    f16* ylds = reinterpret_cast<f16*>(smem_raw + 64);
+    f16* zlds = ylds + (size_t)K * P;
+    float* had = reinterpret_cast<float*>(zlds + (K > 1 ? (size_t)K * P : 0));
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const f16* up = gate_up + (size_t)t * 2 * I;
+    const f16* gate = up + I;
+    if (K > 1)
+        for (int i = tid; i < K * K; i += 256) had[i] = h2f(hadK[i]);
+
+    // phase A: one chunk of P elements per wave trip
+    for (int c = wave; c < K; c += 4) {
+        float v[EPL];
+        const int e0 = c * P + lane * EPL;
+        if (EPL >= 8) {
+#pragma unroll
+            for (int b = 0; b < EPL / 8; b++) {
+                f16x8 g8 = *reinterpret_cast<const f16x8*>(gate + e0 + 8 * b);
+                f16x8 u8 = *reinterpret_cast<const f16x8*>(up + e0 + 8 * b);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    float g = h2f(g8[i]);
+                    float a = h2f(f2h(g / (1.0f + qexpf(-g))));
+                    v[8 * b + i] = h2f(f2h(a * h2f(u8[i])));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPL; i++) {
+                float g = h2f(gate[e0 + i]);
+                float a = h2f(f2h(g / (1.0f + qexpf(-g))));
+                v[i] = h2f(f2h(a * h2f(up[e0 + i])));
+            }
+        }
+#pragma unroll
+        for (int stride = 1; stride < EPL; stride <<= 1) {
+#pragma unroll
+            for (int i = 0; i < EPL; i++)
+                if (!(i & stride)) {
+                    float a = v[i], b = v[i + stride];
+                    v[i] = a + b;
+                    v[i + stride] = a - b;
+                }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const bool hi = lane & m;
+#pragma unroll
+            for (int i = 0; i < EPL; i++) {
+                float o = shfl_xor_f(v[i], m);
+                v[i] = hi ? (o - v[i]) : (v[i] + o);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < EPL; i++) ylds[(size_t)c * P + lane * EPL + i] = f2h(v[i] * had_scale);
+    }
+    __syncthreads();
+
+    // phase B: hadK mix, two adjacent columns per trip
+    const f16* zsrc = ylds;
+    if (K > 1) {
+        zsrc = zlds;
+        for (int j2 = tid; j2 < P / 2; j2 += 256) {
+            for (int i = 0; i < K; i++) {
+                float a0 = 0.0f, a1 = 0.0f;
+                for (int k = 0; k < K; k++) {
+                    float h = had[i * K + k];
+                    f16x2 yy = *reinterpret_cast<const f16x2*>(ylds + (size_t)k * P + 2 * j2);
+                    a0 = __builtin_fmaf(h, h2f(yy[0]), a0);
+                    a1 = __builtin_fmaf(h, h2f(yy[1]), a1);
+                }
+                f16x2 zz = {f2h(a0), f2h(a1)};
+                *reinterpret_cast<f16x2*>(zlds + (size_t)i * P + 2 * j2) = zz;
+            }
+        }
+        __syncthreads();
+    }
+
+    // phase C: fp16 out, or abs-max + int4
+    const int nvec = I / 8;
+    if (q == nullptr) {
+        for (int i = tid; i < nvec; i += 256)
+            *reinterpret_cast<f16x8*>(out16 + (size_t)t * I + 8 * i) = *reinterpret_cast<const f16x8*>(zsrc + 8 * i);
+        return;
+    }
+    float amax = 0.0f;
+    for (int i = tid; i < nvec; i += 256) {
+        f16x8 a = *reinterpret_cast<const f16x8*>(zsrc + 8 * i);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            float f = __builtin_fabsf(h2f(a[c]));
+            amax = f > amax ? f : amax;
+        }
+    }
+    amax = wave_max_f(amax);
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const f16 sc = f2h(h2f(f2h(amax / 7.0f)) * h2f(f2h(clip)));
+    const float scf = h2f(sc);
+    if (tid == 0) scale[t] = sc;
+    for (int i = tid; i < nvec; i += 256) {
+        f16x8 a = *reinterpret_cast<const f16x8*>(zsrc + 8 * i);
+        uint32_t w = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            int v = rni_sat(h2f(f2h(h2f(a[c]) / scf)), -8, 7);
+            w |= (uint32_t)(v & 0xF) << (4 * c);
+        }
+        *reinterpret_cast<uint32_t*>(q + (size_t)t * (I / 2) + 4 * i) = w;
+    }
+}
+
+int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,
+                      float clip, int T, int I, int K, hipStream_t st) {
+    if (T == 0) return 0;
+    if (K < 1 || K > 172 || I % K) return -1;
+    const int P = I / K;
+    if (P & (P - 1)) return -1;
+    size_t lds = 64 + (size_t)I * 2 * (K > 1 ? 2 : 1) + (K > 1 ? (size_t)K * K * 4 : 0);
+    if (lds > 160 * 1024 - 64) return -2;
+#define QS_SMH(EPLV)                                                                                            \
+    if (P == EPLV * 64) {                                                                                        \
+        if (lds > 64 * 1024)                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&silu_mul_hadamard_kernel<EPLV>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+        hipLaunchKernelGGL((silu_mul_hadamard_kernel<EPLV>), dim3(T), dim3(256), lds, st, gate_up, hadK, out_f16, \
+                           q, scale, had_scale, clip, I, K);                                                     \
+        return 0;                                                                                                \
+    }
+    QS_SMH(2) QS_SMH(4) QS_SMH(8) QS_SMH(16) QS_SMH(32)
+#undef QS_SMH
+    return -1;
+}
+
+}  // namespace qspec

@@ -1,0 +1,58 @@
+// Internal C++ launch functions behind the C ABI (include/qspec_hip.h).
+// Every function enqueues on `st`, never synchronises, returns 0 or a
+// negative code for an unsupported shape (the C ABI turns it into an error string).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qspec {
+typedef _Float16 f16;
+
+// norm_quant.hip
+int ln_quant_i4(const f16* x, const f16* delta, f16* hidden_out, int8_t* q, f16* scale, f16* isum, float eps, int T,
+                int H, hipStream_t st);
+int ln_fp16(const f16* x, const f16* delta, f16* hidden_out, f16* out, float eps, int T, int H, hipStream_t st);
+int rowabsmax_quant(const f16* x, f16* scale, int8_t* q, float clip, int T, int K, hipStream_t st);
+
+// hadamard.hip
+int fwht(const f16* x, float scale, f16* out, int64_t rows, int N, hipStream_t st);
+int hadk_mix(const f16* y, const f16* hadK, f16* out, int T, int K, int M, hipStream_t st);
+int heads_hadamard(const f16* attn, f16* out_f16, int8_t* q, f16* scale, float had_scale, float clip, int T,
+                   int heads, int d, hipStream_t st);
+int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,
+                      float clip, int T, int I, int K, hipStream_t st);
+
+// gemm.hip
+int gemm_w4a4(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M,
+              int N, int K, hipStream_t st);
+int gemm_w4a16(const f16* x, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M, int N, int K,
+               hipStream_t st);
+int gemm_f16(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st);
+int dequant_w4(const int8_t* wq, const f16* ws, f16* out, int N, int K, hipStream_t st);
+
+// attention.hip
+int rope_kv_write(const int64_t* positions, f16* qkv, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
+                  const int64_t* slot_mapping, int T, int nq, int nkv, int d, int rot_dim, hipStream_t st);
+int rotary_embedding(const int64_t* positions, f16* q, f16* k, const f16* cos_sin_cache, int T, int nq, int nkv,
+                     int d, int rot_dim, int64_t q_stride, int64_t k_stride, hipStream_t st);
+int reshape_and_cache_flash(const f16* key, const f16* value, f16* key_cache, f16* value_cache,
+                            const int64_t* slot_mapping, int T, int nkv, int d, int64_t k_stride, int64_t v_stride,
+                            hipStream_t st);
+int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const f16* value_cache,
+                    const int32_t* block_tables, int max_blocks, const int32_t* ctx_lens, const int32_t* q_start,
+                    int n_seqs, int max_q_len, int nq, int nkv, int d, int block_size, float sm_scale, int n_splits,
+                    float* ws, f16* out, hipStream_t st);
+int paged_attention_combine(const float* ws, int T, int Tmax, int nq, int d, int n_splits, f16* out, hipStream_t st);
+size_t paged_attention_ws_bytes(int T, int nq, int d, int n_splits);
+
+// sampler.hip
+int embedding(const int64_t* ids, const f16* table, f16* out, int T, int H, int V, hipStream_t st);
+int softmax_argmax(const f16* logits, float* probs, int64_t* token, int T, int V, hipStream_t st);
+int rejection_sample(const float* target_probs, const float* draft_probs, const int64_t* draft_ids,
+                     const int64_t* bonus_ids, const float* uniform, const float* exponential, uint64_t seed,
+                     uint64_t offset, int B, int k, int V, int64_t* out_tokens, uint8_t* accepted,
+                     int64_t* recovered, int64_t* counters, hipStream_t st);
+int advance_step(int n, int block_size, int64_t* input_tokens, const int64_t* sampled, int64_t* positions,
+                 int32_t* seq_lens, int64_t* slot_mapping, const int32_t* block_tables, int64_t bt_stride,
+                 hipStream_t st);
+}  // namespace qspec

@@ -1,0 +1,249 @@
+// Token-side kernels: embedding gather, greedy sampler front end, rejection
+// sampler (accept/reject + recovered token + output assembly + counters) and
+// the on-GPU advance step of the draft loop.
+//
+// Replaces (reference, relative to /root/reference):
+//   Sampler.forward greedy path            vllm/model_executor/layers/sampler.py:216-316 (modify_greedy_probs=False :293)
+//   RejectionSampler.forward & helpers     vllm/model_executor/layers/rejection_sampler.py:60-399
+//   SpecDecodeBaseSampler._create_output   vllm/model_executor/layers/spec_decode_base_sampler.py:69-131
+//   advance_step_flashattn_kernel          csrc/prepare_inputs/advance_step.cu:14-64
+// The reference runs ~15 small torch kernels over [B,k,V] fp32 per step; here it is two.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace qspec {
+
+__global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ ids, const f16* __restrict__ table,
+                                                        f16* __restrict__ out, int H, int V) {
+    const int t = blockIdx.x;
+    int64_t id = ids[t];
+    if (id < 0 || id >= V) id = 0;  // padded slot
+    const f16* src = table + id * H;
+    for (int i = threadIdx.x; i < H / 8; i += blockDim.x)
+        *reinterpret_cast<f16x8*>(out + (size_t)t * H + 8 * i) = *reinterpret_cast<const f16x8*>(src + 8 * i);
+}
+int embedding(const int64_t* ids, const f16* table, f16* out, int T, int H, int V, hipStream_t st) {
+    if (T == 0) return 0;
+    if (H % 8) return -1;
+    hipLaunchKernelGGL(embedding_kernel, dim3(T), dim3(256), 0, st, ids, table, out, H, V);
+    return 0;
+}
+
+// block-wide helpers (1024 threads = 16 waves)
+struct ArgMax {
+    float v;
+    int i;
+};
+__device__ __forceinline__ ArgMax argmax_combine(ArgMax a, ArgMax b) {
+    // larger value wins; on ties the smaller index (first occurrence) wins; NaN never wins
+    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+__device__ __forceinline__ ArgMax block_argmax(ArgMax a, ArgMax* red) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        ArgMax o;
+        o.v = __shfl_xor(a.v, m, 64);
+        o.i = __shfl_xor(a.i, m, 64);
+        a = argmax_combine(a, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = a;
+    __syncthreads();
+    ArgMax r = red[0];
+    for (int w = 1; w < nw; w++) r = argmax_combine(r, red[w]);
+    return r;
+}
+__device__ __forceinline__ double block_sum_f64(double v, double* red) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int w = 1; w < nw; w++) r += red[w];
+    return r;
+}
+
+// probs = softmax_fp32(float(logits)); token = argmax (first index on ties).
+// exp via qexpf, denominator accumulated in fp64 and rounded once (the oracle does the same), so
+// the fp32 probabilities are the oracle's bit for bit up to a ~2^-29 chance per row.
+__global__ __launch_bounds__(1024) void softmax_argmax_kernel(const f16* __restrict__ logits, float* __restrict__ probs,
+                                                              int64_t* __restrict__ token, int V) {
+    __shared__ ArgMax red_a[16];
+    __shared__ double red_d[16];
+    const int t = blockIdx.x;
+    const f16* l = logits + (size_t)t * V;
+    ArgMax am{-__builtin_inff(), 0x7fffffff};
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        float f = h2f(l[v]);
+        if (f > am.v) {
+            am.v = f;
+            am.i = v;
+        }
+    }
+    am = block_argmax(am, red_a);
+    if (am.i == 0x7fffffff) am.i = 0;  // all -inf / NaN row
+    const float mx = am.v;
+    double den = 0.0;
+    float* p = probs + (size_t)t * V;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        float e = qexpf(h2f(l[v]) - mx);
+        p[v] = e;
+        den += (double)e;
+    }
+    den = block_sum_f64(den, red_d);
+    const float inv = (float)den;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) p[v] = p[v] / inv;
+    if (threadIdx.x == 0) token[t] = am.i;
+}
+int softmax_argmax(const f16* logits, float* probs, int64_t* token, int T, int V, hipStream_t st) {
+    if (T == 0) return 0;
+    hipLaunchKernelGGL(softmax_argmax_kernel, dim3(T), dim3(1024), 0, st, logits, probs, token, V);
+    return 0;
+}
+
+// Philox4x32-10 (counter-based; the product's own stream -- CUDA's torch.rand stream is not reproducible here)
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                           uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// One workgroup per (b, i): accepted[b,i] and recovered[b,i].
+//   accepted  = U < min(1, q[x]/p[x])
+//   recovered = argmax_v ( max(q_v - p_v, FLT_MIN) / S ) / E_v ,  S = sum_v max(q_v - p_v, FLT_MIN)
+// target_probs [B, k+1, V], draft_probs [B, k, V].  uniform [B,k] / exponential [B,k,V] may be injected
+// (tests); when null they come from Philox keyed by (seed, offset).
+__global__ __launch_bounds__(1024) void rejection_core_kernel(const float* __restrict__ target_probs,
+                                                              const float* __restrict__ draft_probs,
+                                                              const int64_t* __restrict__ draft_ids,
+                                                              const float* __restrict__ uniform,
+                                                              const float* __restrict__ exponential, uint64_t seed,
+                                                              uint64_t offset, int k, int V,
+                                                              uint8_t* __restrict__ accepted,
+                                                              int64_t* __restrict__ recovered) {
+    __shared__ ArgMax red_a[16];
+    __shared__ double red_d[16];
+    const int b = blockIdx.x / k, i = blockIdx.x % k;
+    const float* q = target_probs + ((size_t)b * (k + 1) + i) * V;
+    const float* p = draft_probs + ((size_t)b * k + i) * V;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const float tiny = 1.17549435e-38f;
+    double s = 0.0;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) s += (double)fmaxf(q[v] - p[v], tiny);
+    s = block_sum_f64(s, red_d);
+    const float S = (float)s;
+    ArgMax am{-__builtin_inff(), 0x7fffffff};
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        float f = fmaxf(q[v] - p[v], tiny) / S;
+        float e;
+        if (exponential) {
+            e = exponential[((size_t)b * k + i) * V + v];
+        } else {
+            uint32_t r[4];
+            philox4x32((uint32_t)v, (uint32_t)blockIdx.x, (uint32_t)offset, (uint32_t)(offset >> 32), k0, k1, r);
+            e = -__logf(u01_open(r[0]));
+        }
+        float val = f / e;
+        if (val > am.v) {
+            am.v = val;
+            am.i = v;
+        }
+    }
+    am = block_argmax(am, red_a);
+    if (threadIdx.x == 0) {
+        const int64_t x = draft_ids[(size_t)b * k + i];
+        float u;
+        if (uniform) {
+            u = uniform[(size_t)b * k + i];
+        } else {
+            uint32_t r[4];
+            philox4x32(0xFFFFFFFFu, (uint32_t)blockIdx.x, (uint32_t)offset, (uint32_t)(offset >> 32), k0, k1, r);
+            u = (float)(r[0] >> 8) * (1.0f / 16777216.0f);  // [0,1) like torch.rand
+        }
+        const float rq = q[x] / p[x];
+        // torch.minimum propagates NaN (0/0) and `u < NaN` is false: such a token is rejected
+        const bool acc = (rq == rq) && (u < fminf(rq, 1.0f));
+        accepted[(size_t)b * k + i] = acc ? 1 : 0;
+        recovered[(size_t)b * k + i] = am.i == 0x7fffffff ? 0 : am.i;
+    }
+}
+
+// Output assembly + counters (spec_decode_base_sampler.py:94-131); one thread per sequence.
+// counters[0] += accepted.sum() (non-causal), counters[1] += #(out != -1), counters[2] += B*k.
+__global__ void rejection_output_kernel(const uint8_t* __restrict__ accepted, const int64_t* __restrict__ recovered,
+                                        const int64_t* __restrict__ draft_ids, const int64_t* __restrict__ bonus_ids,
+                                        int B, int k, int64_t* __restrict__ out, int64_t* __restrict__ counters) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    int acc_cnt = 0, emit_cnt = 0;
+    if (b < B) {
+        int limit = k;
+        for (int i = 0; i < k; i++) {
+            if (accepted[b * k + i]) acc_cnt++;
+            else if (limit == k) limit = i;
+        }
+        for (int i = 0; i < k; i++) {
+            int64_t v = i < limit ? draft_ids[b * k + i] : (i == limit ? recovered[b * k + i] : -1);
+            out[b * (k + 1) + i] = v;
+            emit_cnt += v != -1;
+        }
+        int64_t last = limit == k ? bonus_ids[b] : -1;
+        out[b * (k + 1) + k] = last;
+        emit_cnt += last != -1;
+    }
+    if (counters) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(counters), (unsigned long long)acc_cnt);
+        atomicAdd(reinterpret_cast<unsigned long long*>(counters + 1), (unsigned long long)emit_cnt);
+        if (b == 0) atomicAdd(reinterpret_cast<unsigned long long*>(counters + 2), (unsigned long long)B * k);
+    }
+}
+
+int rejection_sample(const float* target_probs, const float* draft_probs, const int64_t* draft_ids,
+                     const int64_t* bonus_ids, const float* uniform, const float* exponential, uint64_t seed,
+                     uint64_t offset, int B, int k, int V, int64_t* out_tokens, uint8_t* accepted, int64_t* recovered,
+                     int64_t* counters, hipStream_t st) {
+    if (B == 0) return 0;
+    if (k < 1) return -1;
+    hipLaunchKernelGGL(rejection_core_kernel, dim3(B * k), dim3(1024), 0, st, target_probs, draft_probs, draft_ids,
+                       uniform, exponential, seed, offset, k, V, accepted, recovered);
+    hipLaunchKernelGGL(rejection_output_kernel, dim3((B + 63) / 64), dim3(64), 0, st, accepted, recovered, draft_ids,
+                       bonus_ids, B, k, out_tokens, counters);
+    return 0;
+}
+
+// advance_step_flashattn_kernel without the CUDA-graph padding branch (num_seqs == num_queries).
+__global__ void advance_step_kernel(int n, int block_size, int64_t* __restrict__ input_tokens,
+                                    const int64_t* __restrict__ sampled, int64_t* __restrict__ positions,
+                                    int32_t* __restrict__ seq_lens, int64_t* __restrict__ slot_mapping,
+                                    const int32_t* __restrict__ block_tables, int64_t bt_stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    input_tokens[i] = sampled[i];
+    const int next_len = seq_lens[i] + 1;
+    const int pos = next_len - 1;
+    seq_lens[i] = next_len;
+    positions[i] = pos;
+    slot_mapping[i] = (int64_t)block_tables[bt_stride * i + pos / block_size] * block_size + pos % block_size;
+}
+int advance_step(int n, int block_size, int64_t* input_tokens, const int64_t* sampled, int64_t* positions,
+                 int32_t* seq_lens, int64_t* slot_mapping, const int32_t* block_tables, int64_t bt_stride,
+                 hipStream_t st) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(advance_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, block_size, input_tokens,
+                       sampled, positions, seq_lens, slot_mapping, block_tables, bt_stride);
+    return 0;
+}
+
+}  // namespace qspec

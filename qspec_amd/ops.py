@@ -1,0 +1,257 @@
+"""Tensor-level bindings: the operator boundary of the QSpec path.
+
+Each function mirrors the call signature of the reference extension op it
+replaces (names in the docstrings, paths relative to the reference checkout),
+takes caller-owned contiguous HIP tensors, enqueues on the current torch stream
+and never synchronises.  PyTorch is used for memory and streams only.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_F16, _I8, _U8, _I64, _I32, _F32 = torch.float16, torch.int8, torch.uint8, torch.int64, torch.int32, torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a HIP/CUDA tensor (the QSpec hot path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None:
+        ok = t.dtype in dtype if isinstance(dtype, tuple) else t.dtype == dtype
+        if not ok:
+            raise RuntimeError(f"{name} has dtype {t.dtype}, expected {dtype}")
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], name: str, dtype=None):
+    return None if t is None else _chk(t, name, dtype)
+
+
+def _call(name: str, *args):
+    lib = _lib.load()
+    _lib.check(getattr(lib, name)(*args), lib)
+
+
+# ------------------------------------------------------------------ norm + quant
+
+def rms_norm_general_fuse_sum_i4(out_q, x, input_sum, scaling, eps: float, use_per_token_quant: bool = True):
+    """qserve_backend.layernorm_ops.rms_norm_general_fuse_sum_i4 (third-party/kernels/csrc/layernorm.cpp:80-83)."""
+    if not use_per_token_quant:
+        raise RuntimeError("only per-token quantisation exists in the reference launcher (layernorm_kernels.cu:903)")
+    H = x.shape[-1]
+    T = x.numel() // H
+    _call("qspec_rms_norm_general_fuse_sum_i4", _chk(out_q, "out_q", _I8), _chk(x, "x", _F16),
+          _opt(input_sum, "input_sum", _F16), _chk(scaling, "scaling", _F16), float(eps), T, H, _stream())
+
+
+def rms_norm_general_fuse_sum_fp16(out, x, eps: float):
+    """layernorm_ops.rms_norm_general_fuse_sum_fp16 (layernorm.cpp:85-87)."""
+    H = x.shape[-1]
+    T = x.numel() // H
+    _call("qspec_rms_norm_general_fuse_sum_fp16", _chk(out, "out", _F16), _chk(x, "x", _F16), float(eps), T, H,
+          _stream())
+
+
+def add_rms_norm_i4(out_q, scaling, hidden_out, x, delta, eps: float):
+    """hidden_out = x + delta (fp16), then the i4 norm of hidden_out (quarot_llama.py:380-388 fused)."""
+    H = x.shape[-1]
+    T = x.numel() // H
+    _call("qspec_add_rms_norm_i4", _chk(out_q, "out_q", _I8), _chk(scaling, "scaling", _F16),
+          _opt(hidden_out, "hidden_out", _F16), _chk(x, "x", _F16), _opt(delta, "delta", _F16), float(eps), T, H,
+          _stream())
+
+
+def add_rms_norm_fp16(out, hidden_out, x, delta, eps: float):
+    H = x.shape[-1]
+    T = x.numel() // H
+    _call("qspec_add_rms_norm_fp16", _chk(out, "out", _F16), _opt(hidden_out, "hidden_out", _F16),
+          _chk(x, "x", _F16), _opt(delta, "delta", _F16), float(eps), T, H, _stream())
+
+
+def fuse_sym_quant(x, scale, q, clip_ratio: float = 1.0):
+    """quarot._CUDA.fuse_sym_quant(x, scale, q, clip) (third-party/QuaRot/quarot/kernels/bindings.cpp:128-147)."""
+    T, K = x.shape
+    _call("qspec_fuse_sym_quant", _chk(x, "x", _F16), _chk(scale, "scale", _F16), _chk(q, "q", _I8),
+          float(clip_ratio), T, K, _stream())
+
+
+# ------------------------------------------------------------------ hadamard
+
+def faster_fast_hadamard_transform(x, scale: float, out):
+    """fast_hadamard_transform_cuda.faster_fast_hadamard_transform(x, scale, out)
+    (third-party/fast-hadamard-transform/csrc/fast_hadamard_transform.cpp:69-110)."""
+    n = x.shape[-1]
+    rows = x.numel() // n
+    _call("qspec_fast_hadamard_transform", _chk(x, "x", _F16), float(scale), _chk(out, "out", _F16), rows, n,
+          _stream())
+    return out
+
+
+def fast_hadamard_transform(x, scale: float = 1.0):
+    """fast_hadamard_transform_cuda.fast_hadamard_transform(x, scale) -> new tensor (:113-154)."""
+    return faster_fast_hadamard_transform(x, scale, torch.empty_like(x))
+
+
+def hadamard_mix(y, hadK, out):
+    """`hadK @ y.view(-1, K, m)` (quarot/functional/hadamard.py:104-108)."""
+    T, K, m = y.shape
+    _call("qspec_hadamard_mix", _chk(y, "y", _F16), _chk(hadK, "hadK", _F16), _chk(out, "out", _F16), T, K, m,
+          _stream())
+    return out
+
+
+def heads_hadamard(attn, had_scale: float, out_f16=None, q=None, scale=None, clip_ratio: float = 1.0, heads=None):
+    """quarot_llama.py:231-238 in one kernel; attn [T, heads, d] (or [T, heads*d] with heads given)."""
+    if attn.dim() == 3:
+        T, heads, d = attn.shape
+    else:
+        T = attn.shape[0]
+        d = attn.shape[1] // heads
+    _call("qspec_heads_hadamard", _chk(attn, "attn", _F16), _opt(out_f16, "out_f16", _F16), _opt(q, "q", _I8),
+          _opt(scale, "scale", _F16), float(had_scale), float(clip_ratio), T, heads, d, _stream())
+
+
+def silu_mul_hadamard(gate_up, hadK, K: int, had_scale: float, out_f16=None, q=None, scale=None,
+                      clip_ratio: float = 1.0):
+    """quarot_llama.py:279-295 in one kernel; gate_up [T, 2I] with up first."""
+    T, two_i = gate_up.shape
+    _call("qspec_silu_mul_hadamard", _chk(gate_up, "gate_up", _F16), _opt(hadK, "hadK", _F16),
+          _opt(out_f16, "out_f16", _F16), _opt(q, "q", _I8), _opt(scale, "scale", _F16), float(had_scale),
+          float(clip_ratio), T, two_i // 2, K, _stream())
+
+
+# ------------------------------------------------------------------ linear
+
+def rowwise_scaled_linear_cutlass_s4s4_unified(xq, x_scale, wq, w_scale, bias, out):
+    """torch.ops.torchao.rowwise_scaled_linear_cutlass_s4s4_unified (third-party/ao/torchao/ops.py:600-636)."""
+    M, Kb = xq.shape
+    N = wq.shape[0]
+    if wq.shape[1] != Kb:
+        raise RuntimeError(f"xq and wq disagree on K: {xq.shape} vs {wq.shape}")
+    if out.shape[0] != M or out.shape[1] != N:
+        raise RuntimeError(f"out has shape {tuple(out.shape)}, expected ({M}, {N})")
+    _call("qspec_rowwise_scaled_linear_s4s4", _chk(xq, "xq", (_I8, _U8)), _chk(x_scale, "x_scale", _F16),
+          _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16), _opt(bias, "bias", _F16),
+          _chk(out, "out", _F16), M, N, Kb * 2, _stream())
+    return out
+
+
+def w4a16_linear(x, wq, w_scale, out, bias=None):
+    """bitblas.Matmul(x, w ^ 0x88, output=out, scale=w_scale, bias=bias) on the SAME packed buffer
+    (quarot_nn/linear.py:122)."""
+    M, K = x.shape
+    N = wq.shape[0]
+    if wq.shape[1] * 2 != K:
+        raise RuntimeError(f"x and wq disagree on K: {x.shape} vs {wq.shape}")
+    _call("qspec_w4a16_linear", _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
+          _opt(bias, "bias", _F16), _chk(out, "out", _F16), M, N, K, _stream())
+    return out
+
+
+def linear_f16(x, w, out):
+    M, K = x.shape
+    N = w.shape[0]
+    _call("qspec_linear_f16", _chk(x, "x", _F16), _chk(w, "w", _F16), _chk(out, "out", _F16), M, N, K, _stream())
+    return out
+
+
+def dequant_w4(wq, w_scale, out):
+    N, Kb = wq.shape
+    _call("qspec_dequant_w4", _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16), _chk(out, "out", _F16), N,
+          Kb * 2, _stream())
+    return out
+
+
+# ------------------------------------------------------------------ attention side
+
+def rotary_embedding(positions, query, key, head_size: int, cos_sin_cache, is_neox: bool = True):
+    """torch.ops._C.rotary_embedding (csrc/pos_encoding_kernels.cu:124); query/key [T, n*head_size], last dim contiguous."""
+    if not is_neox:
+        raise RuntimeError("only the NeoX layout is on the QSpec path (quarot_llama.py:104)")
+    T = positions.numel()
+    for t, n in ((query, "query"), (key, "key")):
+        if t.stride(-1) != 1 or t.dtype != _F16 or not t.is_cuda:
+            raise RuntimeError(f"{n}: need fp16 HIP tensor with unit inner stride")
+    nq, nk = query.shape[-1] // head_size, key.shape[-1] // head_size
+    _call("qspec_rotary_embedding", _chk(positions, "positions", _I64), query.data_ptr(), key.data_ptr(),
+          _chk(cos_sin_cache, "cos_sin_cache", _F16), T, nq, nk, head_size, cos_sin_cache.shape[-1],
+          query.stride(0), key.stride(0), _stream())
+
+
+def reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping):
+    """torch.ops._C_cache_ops.reshape_and_cache_flash (csrc/cache_kernels.cu:304); key/value [T, n_kv, d]."""
+    T, nkv, d = key.shape
+    _call("qspec_reshape_and_cache_flash", key.data_ptr(), value.data_ptr(), _chk(key_cache, "key_cache", _F16),
+          _chk(value_cache, "value_cache", _F16), _chk(slot_mapping, "slot_mapping", _I64), T, nkv, d, key.stride(0),
+          value.stride(0), _stream())
+
+
+def rope_kv_write(positions, qkv, cos_sin_cache, key_cache, value_cache, slot_mapping, num_heads, num_kv_heads,
+                  head_size):
+    T = qkv.shape[0]
+    _call("qspec_rope_kv_write", _chk(positions, "positions", _I64), _chk(qkv, "qkv", _F16),
+          _chk(cos_sin_cache, "cos_sin_cache", _F16), _chk(key_cache, "key_cache", _F16),
+          _chk(value_cache, "value_cache", _F16), _chk(slot_mapping, "slot_mapping", _I64), T, num_heads,
+          num_kv_heads, head_size, cos_sin_cache.shape[-1], _stream())
+
+
+def paged_attention_workspace_bytes(max_tokens, num_heads, head_size, n_splits) -> int:
+    return int(_lib.load().qspec_paged_attention_workspace_bytes(max_tokens, num_heads, head_size, n_splits))
+
+
+def paged_attention(q, q_stride, key_cache, value_cache, block_tables, ctx_lens, q_start, tokens, max_q_len,
+                    num_heads, sm_scale, n_splits, workspace, out):
+    """flash_attn_with_kvcache / flash_attn_varlen_func over the paged cache (flash_attn.py:741-830)."""
+    nb, bs, nkv, d = key_cache.shape
+    n_seqs = ctx_lens.numel()
+    _call("qspec_paged_attention", q.data_ptr(), q_stride, _chk(key_cache, "key_cache", _F16),
+          _chk(value_cache, "value_cache", _F16), _chk(block_tables, "block_tables", _I32), block_tables.shape[1],
+          _chk(ctx_lens, "ctx_lens", _I32), _chk(q_start, "q_start", _I32), n_seqs, tokens, max_q_len, num_heads, nkv,
+          d, bs, float(sm_scale), n_splits, workspace.data_ptr(), _chk(out, "out", _F16), _stream())
+
+
+# ------------------------------------------------------------------ token side
+
+def embedding(ids, table, out):
+    T = ids.numel()
+    V, H = table.shape
+    _call("qspec_embedding", _chk(ids, "ids", _I64), _chk(table, "table", _F16), _chk(out, "out", _F16), T, H, V,
+          _stream())
+    return out
+
+
+def softmax_argmax(logits, probs, token):
+    T, V = logits.shape
+    _call("qspec_softmax_argmax", _chk(logits, "logits", _F16), _chk(probs, "probs", _F32), _chk(token, "token", _I64),
+          T, V, _stream())
+
+
+def rejection_sample(target_with_bonus_probs, bonus_token_ids, draft_probs, draft_token_ids, out_tokens, accepted,
+                     recovered, counters=None, uniform=None, exponential=None, seed: int = 0, offset: int = 0):
+    B, k, V = draft_probs.shape
+    _call("qspec_rejection_sample", _chk(target_with_bonus_probs, "target_with_bonus_probs", _F32),
+          _chk(bonus_token_ids, "bonus_token_ids", _I64), _chk(draft_probs, "draft_probs", _F32),
+          _chk(draft_token_ids, "draft_token_ids", _I64), _opt(uniform, "uniform", _F32),
+          _opt(exponential, "exponential", _F32), seed, offset, B, k, V, _chk(out_tokens, "out_tokens", _I64),
+          _chk(accepted, "accepted", _U8), _chk(recovered, "recovered", _I64), _opt(counters, "counters", _I64),
+          _stream())
+
+
+def advance_step_flashattn(num_seqs, num_queries, block_size, input_tokens, sampled_token_ids, input_positions,
+                           seq_lens, slot_mapping, block_tables):
+    """ops.advance_step_flashattn (vllm/_custom_ops.py; csrc/prepare_inputs/advance_step.cu:192)."""
+    if num_seqs != num_queries:
+        raise RuntimeError("CUDA-graph padding (num_seqs != num_queries) is not used on this path")
+    _call("qspec_advance_step_flashattn", num_seqs, block_size, _chk(input_tokens, "input_tokens", _I64),
+          _chk(sampled_token_ids, "sampled_token_ids", _I64), _chk(input_positions, "input_positions", _I64),
+          _chk(seq_lens, "seq_lens", _I32), _chk(slot_mapping, "slot_mapping", _I64),
+          _chk(block_tables, "block_tables", _I32), block_tables.stride(0), _stream())

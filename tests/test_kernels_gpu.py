@@ -1,0 +1,449 @@
+"""Parity of every HIP kernel (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for every integer / byte / index output and for fp16 outputs whose arithmetic is fully
+specified (norm, quant, Hadamard, RoPE, W4A4 epilogue); tolerance 1e-3 (north_star) for outputs that
+contain an fp32 accumulation whose order the hardware fixes (W4A16 / fp16 GEMM through MFMA, attention).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from qspec_amd import ops as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint16)
+
+
+def rand_hidden(rng, T, H, scale=1.0):
+    x = rng.standard_normal((T, H)) * scale
+    x[:, rng.integers(0, H, 8)] *= 20.0  # a few outlier channels, as in real LLM activations
+    return x.astype(np.float16)
+
+
+# ------------------------------------------------------------------ norm / quant
+
+@pytest.mark.parametrize("T,H", [(1, 4096), (4, 4096), (16, 4096), (192, 4096), (3, 2048), (2, 5120), (5, 8192)])
+def test_ln_quant_i4_bit_exact(ops, oracle, T, H):
+    rng = np.random.default_rng(T * 131 + H)
+    x = rand_hidden(rng, T, H)
+    q0, s0, sum0 = oracle.ln_quant_i4(x, 1e-5)
+    q = torch.empty(T, H // 2, dtype=torch.int8, device=DEV)
+    s = torch.empty(T, dtype=torch.float16, device=DEV)
+    isum = torch.empty(T, dtype=torch.float16, device=DEV)
+    ops.rms_norm_general_fuse_sum_i4(q, dev(x), isum, s, 1e-5, True)
+    assert np.array_equal(host(q), q0)
+    assert np.array_equal(bits(host(s)), bits(s0))
+    assert np.array_equal(bits(host(isum)), bits(sum0))
+
+
+def test_ln_quant_edge_rows(ops, oracle):
+    H = 4096
+    x = np.zeros((5, H), np.float16)
+    x[1] = 3.0
+    x[2, ::2], x[2, 1::2] = 1.0, -1.0
+    x[3, 0] = 100.0
+    x[4] = np.float16(6e-8)  # subnormals
+    q0, s0, _ = oracle.ln_quant_i4(x, 1e-5)
+    q = torch.empty(5, H // 2, dtype=torch.int8, device=DEV)
+    s = torch.empty(5, dtype=torch.float16, device=DEV)
+    ops.rms_norm_general_fuse_sum_i4(q, dev(x), None, s, 1e-5)
+    assert np.array_equal(host(q), q0) and np.array_equal(bits(host(s)), bits(s0))
+
+
+@pytest.mark.parametrize("T,H", [(4, 4096), (16, 4096), (3, 2048)])
+def test_ln_fp16_and_fused_residual_bit_exact(ops, oracle, T, H):
+    rng = np.random.default_rng(7)
+    x, d = rand_hidden(rng, T, H), rand_hidden(rng, T, H, 0.3)
+    out = torch.empty(T, H, dtype=torch.float16, device=DEV)
+    ops.rms_norm_general_fuse_sum_fp16(out, dev(x), 1e-5)
+    assert np.array_equal(bits(host(out)), bits(oracle.ln_fp16(x, 1e-5)))
+    hid = oracle.add_f16(x, d)
+    hidden_out = torch.empty_like(out)
+    ops.add_rms_norm_fp16(out, hidden_out, dev(x), dev(d), 1e-5)
+    assert np.array_equal(bits(host(hidden_out)), bits(hid))
+    assert np.array_equal(bits(host(out)), bits(oracle.ln_fp16(hid, 1e-5)))
+    q = torch.empty(T, H // 2, dtype=torch.int8, device=DEV)
+    s = torch.empty(T, dtype=torch.float16, device=DEV)
+    ops.add_rms_norm_i4(q, s, hidden_out, dev(x), dev(d), 1e-5)
+    q0, s0, _ = oracle.ln_quant_i4(hid, 1e-5)
+    assert np.array_equal(host(q), q0) and np.array_equal(bits(host(s)), bits(s0))
+
+
+@pytest.mark.parametrize("T,K", [(4, 4096), (4, 14336), (16, 14336), (3, 250), (2, 5632)])
+def test_fuse_sym_quant_bit_exact(ops, oracle, T, K):
+    rng = np.random.default_rng(K)
+    x = rand_hidden(rng, T, K)
+    x[0] = 0  # all-zero row: 0/0 -> NaN -> 0
+    q0, s0 = oracle.rowabsmax_quant_i4(x, 1.0)
+    q = torch.empty(T, K // 2, dtype=torch.int8, device=DEV)
+    s = torch.empty(T, dtype=torch.float16, device=DEV)
+    ops.fuse_sym_quant(dev(x), s, q, 1.0)
+    assert np.array_equal(host(q), q0) and np.array_equal(bits(host(s)), bits(s0))
+    q0, s0 = oracle.rowabsmax_quant_i4(x, 0.9)
+    ops.fuse_sym_quant(dev(x), s, q, 0.9)
+    assert np.array_equal(host(q), q0) and np.array_equal(bits(host(s)), bits(s0))
+
+
+# ------------------------------------------------------------------ hadamard
+
+@pytest.mark.parametrize("rows,N", [(512, 32), (112, 512), (5, 1024), (3, 8), (2, 4096)])
+def test_fwht_bit_exact(ops, oracle, rows, N):
+    rng = np.random.default_rng(N)
+    x = (rng.standard_normal((rows, N)) * 3).astype(np.float16)
+    sc = oracle.rsqrt_scale(N)
+    out = ops.fast_hadamard_transform(dev(x), sc)
+    assert np.array_equal(bits(host(out)), bits(oracle.fwht(x, sc)))
+
+
+def test_fwht_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "hadamard.npz"))
+    for n in (32, 512):
+        out = ops.fast_hadamard_transform(dev(g[f"x_{n}"].astype(np.float16)), float(np.float32(1) / np.sqrt(np.float32(n))))
+        assert np.allclose(host(out).astype(np.float64), g[f"y_{n}"], atol=5e-3, rtol=0)
+
+
+def test_hadamard_mix_bit_exact(ops, oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, "hadamard.npz"))
+    rng = np.random.default_rng(3)
+    for K, M in ((28, 512), (108, 128), (12, 64)):
+        had = g[f"had{K}"].astype(np.float16)
+        y = rng.standard_normal((3, K, M)).astype(np.float16)
+        out = torch.empty(3, K, M, dtype=torch.float16, device=DEV)
+        ops.hadamard_mix(dev(y), dev(had), out)
+        assert np.array_equal(bits(host(out)), bits(oracle.hadk_mix(y, had)))
+
+
+@pytest.mark.parametrize("T,heads,d", [(4, 32, 128), (16, 32, 128), (3, 64, 128), (2, 32, 64)])
+def test_heads_hadamard_bit_exact(ops, oracle, T, heads, d):
+    rng = np.random.default_rng(heads + d)
+    x = rand_hidden(rng, T, heads * d)
+    sc = oracle.rsqrt_scale(heads)
+    y0 = oracle.heads_hadamard(x, heads, sc)
+    out = torch.empty(T, heads * d, dtype=torch.float16, device=DEV)
+    ops.heads_hadamard(dev(x), sc, out_f16=out, heads=heads)
+    assert np.array_equal(bits(host(out)), bits(y0))
+    q0, s0 = oracle.rowabsmax_quant_i4(y0, 1.0)
+    q = torch.empty(T, heads * d // 2, dtype=torch.int8, device=DEV)
+    s = torch.empty(T, dtype=torch.float16, device=DEV)
+    ops.heads_hadamard(dev(x), sc, q=q, scale=s, heads=heads)
+    assert np.array_equal(host(q), q0) and np.array_equal(bits(host(s)), bits(s0))
+
+
+@pytest.mark.parametrize("T,I,K", [(4, 14336, 28), (16, 14336, 28), (2, 28672, 28), (2, 13824, 108), (3, 1024, 1),
+                                   (2, 1536, 12)])
+def test_silu_mul_hadamard_bit_exact(ops, oracle, golden_dir, T, I, K):
+    g = np.load(os.path.join(golden_dir, "hadamard.npz"))
+    rng = np.random.default_rng(I + K)
+    gu = rand_hidden(rng, T, 2 * I, 2.0)
+    had = g[f"had{K}"].astype(np.float16) if K > 1 else None
+    sc = oracle.rsqrt_scale(I)
+    z0 = oracle.mlp_hadamard(oracle.silu_mul(gu, I), had, K, sc)
+    out = torch.empty(T, I, dtype=torch.float16, device=DEV)
+    hd = dev(had) if had is not None else None
+    ops.silu_mul_hadamard(dev(gu), hd, K, sc, out_f16=out)
+    assert np.array_equal(bits(host(out)), bits(z0))
+    q0, s0 = oracle.rowabsmax_quant_i4(z0, 1.0)
+    q = torch.empty(T, I // 2, dtype=torch.int8, device=DEV)
+    s = torch.empty(T, dtype=torch.float16, device=DEV)
+    ops.silu_mul_hadamard(dev(gu), hd, K, sc, q=q, scale=s)
+    assert np.array_equal(host(q), q0) and np.array_equal(bits(host(s)), bits(s0))
+
+
+# ------------------------------------------------------------------ GEMMs
+
+def rand_w4(rng, N, K):
+    return rng.integers(-8, 8, (N, K)).astype(np.int8)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 128), (4, 6144, 4096), (4, 4096, 14336), (16, 4096, 4096), (32, 512, 4096),
+                                   (33, 256, 1408), (67, 64, 1408), (192, 128, 4096), (4, 28672, 4096)])
+def test_w4a4_gemm_bit_exact(ops, oracle, M, N, K):
+    rng = np.random.default_rng(M * 7 + N + K)
+    xq = oracle.pack_i4(rand_w4(rng, M, K))
+    wq = oracle.pack_i4(rand_w4(rng, N, K))
+    xs = (rng.random(M) * 0.1 + 0.01).astype(np.float16)
+    ws = (rng.random(N) * 0.01 + 0.001).astype(np.float16)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.rowwise_scaled_linear_cutlass_s4s4_unified(dev(xq), dev(xs), dev(wq), dev(ws), None, out)
+    assert np.array_equal(bits(host(out)), bits(oracle.gemm_w4a4(xq, xs, wq, ws)))
+    if N <= 4096:
+        bias = rng.random(N).astype(np.float16)
+        ops.rowwise_scaled_linear_cutlass_s4s4_unified(dev(xq), dev(xs), dev(wq), dev(ws), dev(bias), out)
+        assert np.array_equal(bits(host(out)), bits(oracle.gemm_w4a4(xq, xs, wq, ws, bias)))
+
+
+def test_w4a4_gemm_extreme_values(ops, oracle):
+    """all -8 x -8 at the longest K: the int32 accumulator (x256 from the nibble widening) must not overflow."""
+    M, N, K = 4, 32, 14336
+    xq = oracle.pack_i4(np.full((M, K), -8, np.int8))
+    wq = oracle.pack_i4(np.full((N, K), -8, np.int8))
+    wq[1::2] = oracle.pack_i4(np.full((N // 2, K), 7, np.int8))
+    xs = np.full(M, 0.01, np.float16)
+    ws = np.full(N, 0.001, np.float16)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.rowwise_scaled_linear_cutlass_s4s4_unified(dev(xq), dev(xs), dev(wq), dev(ws), None, out)
+    assert np.array_equal(bits(host(out)), bits(oracle.gemm_w4a4(xq, xs, wq, ws)))
+
+
+def test_w4a4_gemm_golden(ops, golden_dir):
+    """The reference test's formula on its own (M, K) shapes -- committed fixture."""
+    g = np.load(os.path.join(golden_dir, "w4a4_gemm.npz"))
+    for idx in range(6):
+        xq, wq, xs, ws = (g[f"c{idx}_{k}"] for k in ("xq", "wq", "xs", "ws"))
+        M, N = xq.shape[0], wq.shape[0]
+        out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        ops.rowwise_scaled_linear_cutlass_s4s4_unified(dev(xq), dev(xs), dev(wq), dev(ws), None, out)
+        assert np.array_equal(bits(host(out)), bits(g[f"c{idx}_ref_n"])), idx
+        ops.rowwise_scaled_linear_cutlass_s4s4_unified(dev(xq), dev(xs), dev(wq), dev(ws), dev(g[f"c{idx}_bias"]), out)
+        assert np.array_equal(bits(host(out)), bits(g[f"c{idx}_ref_b"])), idx
+
+
+def assert_close_1e3(got, ref):
+    got, ref = got.astype(np.float64), ref.astype(np.float64)
+    tol = 1e-3 * np.maximum(1.0, np.abs(ref))
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), (np.abs(got - ref).max(), int(bad.sum()))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 128), (16, 6144, 4096), (16, 4096, 14336), (4, 4096, 4096), (24, 512, 4096),
+                                   (40, 128, 4096)])
+def test_w4a16_gemm_within_1e3(ops, oracle, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    x = rand_hidden(rng, M, K)
+    wq = oracle.pack_i4(rand_w4(rng, N, K))
+    ws = (rng.random(N) * 0.002 + 0.0005).astype(np.float16)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.w4a16_linear(dev(x), dev(wq), dev(ws), out)
+    assert_close_1e3(host(out), oracle.gemm_w4a16(x, wq, ws))
+
+
+def test_w4a16_exact_on_integer_data(ops, oracle):
+    """Small-integer activations make every fp32 partial sum exact, so any k-permutation or lane-map
+    error in the MFMA path shows up as a bit mismatch (asymmetric data on purpose)."""
+    rng = np.random.default_rng(5)
+    M, N, K = 16, 64, 512
+    x = rng.integers(-4, 5, (M, K)).astype(np.float16)
+    wq = oracle.pack_i4(rand_w4(rng, N, K))
+    ws = np.ones(N, np.float16)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.w4a16_linear(dev(x), dev(wq), dev(ws), out)
+    assert np.array_equal(bits(host(out)), bits(oracle.gemm_w4a16(x, wq, ws)))
+
+
+def test_both_views_read_the_same_buffer(ops, oracle):
+    """Draft and verify GEMMs take the identical device pointer; neither modifies it."""
+    rng = np.random.default_rng(9)
+    M, N, K = 4, 256, 4096
+    w = dev(oracle.pack_i4(rand_w4(rng, N, K)))
+    before = w.clone()
+    ws = dev((rng.random(N) * 0.01 + 0.001).astype(np.float16))
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.rowwise_scaled_linear_cutlass_s4s4_unified(dev(oracle.pack_i4(rand_w4(rng, M, K))), dev(np.ones(M, np.float16)), w, ws, None, out)
+    ops.w4a16_linear(dev(rand_hidden(rng, M, K)), w, ws, out)
+    torch.cuda.synchronize()
+    assert torch.equal(w, before)
+
+
+@pytest.mark.parametrize("M,N,K", [(4, 1000, 4096), (16, 128256, 256), (20, 2048, 2048)])
+def test_linear_f16_within_1e3(ops, oracle, M, N, K):
+    rng = np.random.default_rng(N)
+    x = rand_hidden(rng, M, K)
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float16)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.linear_f16(dev(x), dev(w), out)
+    assert_close_1e3(host(out), oracle.gemm_f16(x, w))
+
+
+def test_dequant_w4(ops, oracle):
+    rng = np.random.default_rng(2)
+    N, K = 48, 512
+    w = rand_w4(rng, N, K)
+    ws = (rng.random(N) * 0.01 + 0.001).astype(np.float16)
+    out = torch.empty(N, K, dtype=torch.float16, device=DEV)
+    ops.dequant_w4(dev(oracle.pack_i4(w)), dev(ws), out)
+    ref = (w.astype(np.float32) * ws.astype(np.float32)[:, None]).astype(np.float16)
+    assert np.array_equal(bits(host(out)), bits(ref))
+
+
+# ------------------------------------------------------------------ attention side
+
+def make_paged(rng, n_seqs, ctx_lens, nkv, d, block_size):
+    max_blocks = max((c + block_size - 1) // block_size for c in ctx_lens) + 1
+    nb = n_seqs * max_blocks + 3
+    perm = rng.permutation(nb)[: n_seqs * max_blocks].reshape(n_seqs, max_blocks).astype(np.int32)
+    kc = (rng.standard_normal((nb, block_size, nkv, d)) * 0.5).astype(np.float16)
+    vc = (rng.standard_normal((nb, block_size, nkv, d)) * 0.5).astype(np.float16)
+    return perm, kc, vc
+
+
+def test_rope_and_cache_write_bit_exact(ops, oracle):
+    rng = np.random.default_rng(11)
+    T, nq, nkv, d, bs = 6, 32, 8, 128, 16
+    cs = oracle.make_cos_sin_cache(d, 4096, 500000.0)
+    pos = rng.integers(0, 4096, T).astype(np.int64)
+    qkv = (rng.standard_normal((T, (nq + 2 * nkv) * d))).astype(np.float16)
+    q0, k0 = oracle.rope_neox(pos, qkv[:, : nq * d], qkv[:, nq * d:(nq + nkv) * d], cs, d)
+    # standalone ops on strided views of the fused buffer
+    t = dev(qkv)
+    ops.rotary_embedding(dev(pos), t[:, : nq * d], t[:, nq * d:(nq + nkv) * d], d, dev(cs))
+    got = host(t)
+    assert np.array_equal(bits(got[:, : nq * d]), bits(q0)) and np.array_equal(bits(got[:, nq * d:(nq + nkv) * d]), bits(k0))
+    nb = 8
+    kc = torch.zeros(nb, bs, nkv, d, dtype=torch.float16, device=DEV)
+    vc = torch.zeros_like(kc)
+    slots = np.array([5, 17, 18, -1, 100, 127], np.int64)
+    ops.reshape_and_cache_flash(t[:, nq * d:(nq + nkv) * d].view(T, nkv, d), t[:, (nq + nkv) * d:].view(T, nkv, d), kc, vc, dev(slots))
+    kc0 = np.zeros((nb, bs, nkv, d), np.float16)
+    vc0 = np.zeros_like(kc0)
+    oracle.reshape_and_cache_flash(k0.reshape(T, nkv, d), qkv[:, (nq + nkv) * d:].reshape(T, nkv, d), kc0, vc0, slots)
+    assert np.array_equal(bits(host(kc)), bits(kc0)) and np.array_equal(bits(host(vc)), bits(vc0))
+    # fused kernel
+    t2 = dev(qkv)
+    kc.zero_(); vc.zero_()
+    ops.rope_kv_write(dev(pos), t2, dev(cs), kc, vc, dev(slots), nq, nkv, d)
+    got2 = host(t2)
+    assert np.array_equal(bits(got2[:, : (nq + nkv) * d]), bits(got[:, : (nq + nkv) * d]))
+    assert np.array_equal(bits(host(kc)), bits(kc0)) and np.array_equal(bits(host(vc)), bits(vc0))
+
+
+@pytest.mark.parametrize("ctx_lens,q_len", [([37, 128, 129, 500], 1), ([37, 130, 260, 515], 4), ([700], 6), ([5, 9], 4)])
+def test_paged_attention_within_1e3(ops, oracle, ctx_lens, q_len):
+    rng = np.random.default_rng(sum(ctx_lens) + q_len)
+    nq, nkv, d, bs = 32, 8, 128, 16
+    n_seqs = len(ctx_lens)
+    bt, kc, vc = make_paged(rng, n_seqs, ctx_lens, nkv, d, bs)
+    T = n_seqs * q_len
+    row = (nq + 2 * nkv) * d
+    qkv = (rng.standard_normal((T, row)) * 0.5).astype(np.float16)
+    q_start = (np.arange(n_seqs + 1) * q_len).astype(np.int32)
+    ctx = np.array(ctx_lens, np.int32)
+    scale = d ** -0.5
+    ref = oracle.paged_attention(qkv[:, : nq * d], kc, vc, bt, ctx, q_start, scale)
+    n_splits = (max(ctx_lens) + 127) // 128 + 1
+    ws = torch.empty(ops.paged_attention_workspace_bytes(T, nq, d, n_splits), dtype=torch.uint8, device=DEV)
+    out = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
+    ops.paged_attention(dev(qkv), row, dev(kc), dev(vc), dev(bt), dev(ctx), dev(q_start), T, q_len, nq, scale,
+                        n_splits, ws, out)
+    assert_close_1e3(host(out), ref)
+
+
+# ------------------------------------------------------------------ token side
+
+def test_embedding(ops):
+    rng = np.random.default_rng(0)
+    V, H = 1000, 4096
+    table = rng.standard_normal((V, H)).astype(np.float16)
+    ids = np.array([0, 999, 5, 5], np.int64)
+    out = torch.empty(4, H, dtype=torch.float16, device=DEV)
+    ops.embedding(dev(ids), dev(table), out)
+    assert np.array_equal(bits(host(out)), bits(table[ids]))
+
+
+@pytest.mark.parametrize("T,V", [(4, 128256), (16, 32000), (3, 1000)])
+def test_softmax_argmax(ops, oracle, T, V):
+    rng = np.random.default_rng(V)
+    logits = (rng.standard_normal((T, V)) * 3).astype(np.float16)
+    logits[0, 7] = logits[0, 9] = np.float16(30.0)  # tie -> first index
+    p0, t0 = oracle.softmax_argmax(logits)
+    probs = torch.empty(T, V, dtype=torch.float32, device=DEV)
+    tok = torch.empty(T, dtype=torch.int64, device=DEV)
+    ops.softmax_argmax(dev(logits), probs, tok)
+    assert np.array_equal(host(tok), t0) and t0[0] == 7
+    assert np.array_equal(host(probs).view(np.uint32), p0.view(np.uint32))
+
+
+def test_rejection_sampler_golden_bit_exact(ops, golden_dir):
+    """Outputs of the REFERENCE sampler run on CPU with recorded draws: masks, recovered ids, layout, counters."""
+    g = np.load(os.path.join(golden_dir, "rejection.npz"))
+    for idx in range(5):
+        for flavour in ("random", "agree", "onehot"):
+            key = f"c{idx}_{flavour}"
+            tq, dp, ids, bonus, U, E = (g[key + s] for s in ("_tq", "_dp", "_ids", "_bonus", "_U", "_E"))
+            B, k, V = dp.shape
+            out = torch.empty(B, k + 1, dtype=torch.int64, device=DEV)
+            acc = torch.empty(B, k, dtype=torch.uint8, device=DEV)
+            rec = torch.empty(B, k, dtype=torch.int64, device=DEV)
+            counters = torch.zeros(3, dtype=torch.int64, device=DEV)
+            ops.rejection_sample(dev(tq), dev(bonus.reshape(-1)), dev(dp), dev(ids), out, acc, rec, counters,
+                                 uniform=dev(U), exponential=dev(E))
+            assert np.array_equal(host(out), g[key + "_out"]), key
+            assert np.array_equal(host(counters), g[key + "_counters"]), key
+
+
+def test_rejection_sampler_vs_oracle_full_vocab(ops, oracle):
+    rng = np.random.default_rng(4)
+    B, k, V = 4, 3, 128256
+    logits = rng.standard_normal((B, k + 1, V)).astype(np.float32) * 4
+    tq = np.exp(logits - logits.max(-1, keepdims=True)); tq /= tq.sum(-1, keepdims=True)
+    dl = logits[:, :k] + rng.standard_normal((B, k, V)).astype(np.float32)
+    dp = np.exp(dl - dl.max(-1, keepdims=True)); dp /= dp.sum(-1, keepdims=True)
+    tq, dp = tq.astype(np.float32), dp.astype(np.float32)
+    ids = dp.argmax(-1).astype(np.int64)
+    bonus = tq[:, -1].argmax(-1).astype(np.int64)
+    U = rng.random((B, k)).astype(np.float32)
+    E = rng.exponential(1.0, (B, k, V)).astype(np.float32)
+    o0, a0, r0, c0 = oracle.rejection_sample(tq, bonus, dp, ids, U, E)
+    out = torch.empty(B, k + 1, dtype=torch.int64, device=DEV)
+    acc = torch.empty(B, k, dtype=torch.uint8, device=DEV)
+    rec = torch.empty(B, k, dtype=torch.int64, device=DEV)
+    counters = torch.zeros(3, dtype=torch.int64, device=DEV)
+    ops.rejection_sample(dev(tq), dev(bonus), dev(dp), dev(ids), out, acc, rec, counters, uniform=dev(U), exponential=dev(E))
+    assert np.array_equal(host(acc).astype(bool), a0) and np.array_equal(host(rec), r0)
+    assert np.array_equal(host(out), o0) and list(host(counters)) == list(c0)
+
+
+def test_rejection_sampler_philox_path(ops):
+    """Without injected draws: deterministic per (seed, offset), structurally valid, and target-distributed
+    in the one-hot construction of tests/samplers/test_rejection_sampler.py."""
+    B, k, V = 64, 3, 512
+    rng = np.random.default_rng(0)
+    tq = np.zeros((B, k + 1, V), np.float32); tgt = rng.integers(0, V, (B, k + 1)); np.put_along_axis(tq, tgt[..., None], 1.0, -1)
+    dp = np.zeros((B, k, V), np.float32); ids = rng.integers(0, V, (B, k)); np.put_along_axis(dp, ids[..., None], 1.0, -1)
+    bonus = tgt[:, -1].astype(np.int64)
+    outs = []
+    for seed in (1, 1, 2):
+        out = torch.empty(B, k + 1, dtype=torch.int64, device=DEV)
+        acc = torch.empty(B, k, dtype=torch.uint8, device=DEV)
+        rec = torch.empty(B, k, dtype=torch.int64, device=DEV)
+        ops.rejection_sample(dev(tq), dev(bonus), dev(dp), dev(ids.astype(np.int64)), out, acc, rec, None, seed=seed, offset=7)
+        outs.append((host(out), host(acc), host(rec)))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    # one-hot: accepted iff draft == target; the recovered token is the target token
+    assert np.array_equal(outs[0][1].astype(bool), ids == tgt[:, :k])
+    rej = ~(ids == tgt[:, :k])
+    assert np.array_equal(outs[0][2][rej], tgt[:, :k][rej])
+
+
+def test_advance_step(ops, oracle):
+    rng = np.random.default_rng(1)
+    n, bs, mb = 4, 16, 10
+    bt = rng.integers(0, 1000, (n, mb)).astype(np.int32)
+    seq_lens = np.array([1, 16, 31, 100], np.int32)
+    sampled = rng.integers(0, 32000, n).astype(np.int64)
+    it, pos, sl, sm = np.zeros(n, np.int64), np.zeros(n, np.int64), seq_lens.copy(), np.zeros(n, np.int64)
+    oracle.advance_step(it, sampled, pos, sl, sm, bt, bs)
+    d_it, d_pos, d_sl, d_sm = dev(np.zeros(n, np.int64)), dev(np.zeros(n, np.int64)), dev(seq_lens), dev(np.zeros(n, np.int64))
+    ops.advance_step_flashattn(n, n, bs, d_it, dev(sampled), d_pos, d_sl, d_sm, dev(bt))
+    assert np.array_equal(host(d_it), it) and np.array_equal(host(d_pos), pos)
+    assert np.array_equal(host(d_sl), sl) and np.array_equal(host(d_sm), sm)

@@ -1,0 +1,154 @@
+"""Pin the CPU oracle against the golden vectors produced by running the
+importable parts of the reference (tests/golden/make_golden.py) and against the
+reference tests' own known-answer constructions.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_pack_unpack_matches_reference(oracle, golden_dir):
+    g = _load(golden_dir, "pack_i4.npz")
+    assert np.array_equal(oracle.pack_i4(g["q"]).view(np.uint8), g["packed"])
+    assert np.array_equal(oracle.unpack_i4(g["packed"]), g["unpacked"].astype(np.int8))
+    # every nibble value, both positions
+    q = np.array([[a, b] for a in range(-8, 8) for b in range(-8, 8)], np.int8)
+    assert np.array_equal(oracle.unpack_i4(oracle.pack_i4(q)), q)
+
+
+def test_hadK_tables_are_hadamard(golden_dir):
+    g = _load(golden_dir, "hadamard.npz")
+    for K in (12, 20, 28, 36, 40, 52, 60, 108):
+        h = g[f"had{K}"].astype(np.int64)
+        assert set(np.unique(h)) == {-1, 1}
+        assert np.array_equal(h @ h.T, K * np.eye(K, dtype=np.int64))
+
+
+@pytest.mark.parametrize("n", [32, 512])
+def test_fwht_matches_reference_matmul_hadU(oracle, golden_dir, n):
+    """fast-hadamard-transform's own test compares with scipy.linalg.hadamard at atol 5e-3 (fp16)
+    (third-party/fast-hadamard-transform/tests/test_fast_hadamard_transform.py:13-38)."""
+    from scipy.linalg import hadamard
+    g = _load(golden_dir, "hadamard.npz")
+    x, y = g[f"x_{n}"], g[f"y_{n}"]
+    out = oracle.fwht(x.astype(np.float16), oracle.rsqrt_scale(n)).astype(np.float64)
+    assert np.allclose(out, y, atol=5e-3, rtol=0)
+    assert np.allclose(x @ hadamard(n).T / np.sqrt(n), y, atol=1e-9)  # Sylvester order
+
+
+@pytest.mark.parametrize("n,K", [(14336, 28), (28672, 28), (13824, 108)])
+def test_mlp_hadamard_matches_reference_matmul_hadU(oracle, golden_dir, n, K):
+    """(hadK (x) H_{n/K}) / sqrt(n) with element index k*(n/K)+j, as quarot/functional/hadamard.py:59-80."""
+    g = _load(golden_dir, "hadamard.npz")
+    x, y = g[f"x_{n}"], g[f"y_{n}"]
+    hadK = g[f"had{K}"].astype(np.float16)
+    out = oracle.mlp_hadamard(x.astype(np.float16), hadK, K).astype(np.float64)
+    assert np.allclose(out, y, atol=5e-3, rtol=0), np.abs(out - y).max()
+
+
+def test_heads_hadamard_is_transpose_fwht_transpose(oracle):
+    from scipy.linalg import hadamard
+    rng = np.random.default_rng(0)
+    T, heads, d = 3, 32, 128
+    x = rng.standard_normal((T, heads * d)).astype(np.float16)
+    out = oracle.heads_hadamard(x, heads).astype(np.float64)
+    ref = np.einsum("gh,thd->tgd", hadamard(heads) / np.sqrt(heads), x.reshape(T, heads, d).astype(np.float64))
+    assert np.allclose(out, ref.reshape(T, -1), atol=5e-3, rtol=0)
+
+
+def test_w4a4_gemm_bit_exact_with_reference_formula(oracle, golden_dir):
+    """third-party/ao/test/test_rowwise_scaled_linear_cutlass.py:64-84: the fp32 formula is exact for
+    int4 products, so the oracle must reproduce it bit for bit."""
+    g = _load(golden_dir, "w4a4_gemm.npz")
+    idx = 0
+    while f"c{idx}_xq" in g:
+        xq, wq, xs, ws = g[f"c{idx}_xq"], g[f"c{idx}_wq"], g[f"c{idx}_xs"], g[f"c{idx}_ws"]
+        out = oracle.gemm_w4a4(xq, xs, wq, ws)
+        assert np.array_equal(out.view(np.uint16), g[f"c{idx}_ref_n"].view(np.uint16)), idx
+        out = oracle.gemm_w4a4(xq, xs, wq, ws, g[f"c{idx}_bias"])
+        assert np.array_equal(out.view(np.uint16), g[f"c{idx}_ref_b"].view(np.uint16)), idx
+        idx += 1
+    assert idx == 6
+
+
+def test_w4a16_matches_dequantised_matmul(oracle):
+    """Second statements of the W4A16 semantics in the reference: unpack * scale then fp16 matmul
+    (quarot_nn/linear.py:111-119) and the fp32-accumulate Triton kernel (quarot_nn/qspec_gemm.py:20-88)."""
+    rng = np.random.default_rng(1)
+    M, N, K = 5, 64, 256
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    w = rng.integers(-8, 8, (N, K)).astype(np.int8)
+    ws = (rng.random(N) * 0.01 + 0.001).astype(np.float16)
+    out = oracle.gemm_w4a16(x, oracle.pack_i4(w), ws).astype(np.float64)
+    ref = (x.astype(np.float64) @ w.astype(np.float64).T) * ws.astype(np.float64)
+    assert np.allclose(out, ref, rtol=1e-3, atol=1e-4)
+
+
+def test_rejection_sampler_matches_reference_run(oracle, golden_dir):
+    """The reference RejectionSampler itself, run on CPU with recorded uniform / exponential draws."""
+    g = _load(golden_dir, "rejection.npz")
+    n = 0
+    for idx in range(5):
+        for flavour in ("random", "agree", "onehot"):
+            key = f"c{idx}_{flavour}"
+            out, accepted, recovered, counters = oracle.rejection_sample(
+                g[key + "_tq"], g[key + "_bonus"], g[key + "_dp"], g[key + "_ids"], g[key + "_U"], g[key + "_E"])
+            assert np.array_equal(out, g[key + "_out"]), key
+            assert list(counters) == list(g[key + "_counters"]), key
+            n += 1
+    assert n == 15
+
+
+@pytest.mark.parametrize("name", ["all", "none", "some"])
+def test_create_output_known_answers(oracle, golden_dir, name):
+    """tests/samplers/test_rejection_sampler.py:48-127 (exact output layout)."""
+    g = _load(golden_dir, "rejection.npz")
+    acc, rec, ids, bonus = (g[f"co_{name}_{k}"] for k in ("accepted", "rec", "ids", "bonus"))
+    out, _ = oracle.create_output(acc, rec, ids, bonus.reshape(-1))
+    assert np.array_equal(out, g[f"co_{name}_out"])
+    if name == "all":
+        assert np.array_equal(out[:, :-1], ids) and np.array_equal(out[:, -1], bonus.reshape(-1))
+    if name == "none":
+        assert np.array_equal(out[:, 0], rec[:, 0]) and (out[:, 1:] == -1).all()
+
+
+def test_spec_metrics_formulas(oracle):
+    """vllm/spec_decode/metrics.py:164-188 on the numbers of the reference's screenshot:
+    3931 accepted / 4092 draft / 5161 emitted at k=3 -> 0.961 / 0.946."""
+    rate, eff = oracle.spec_metrics(3931, 5161, 4092, 3)
+    assert abs(rate - 0.9607) < 1e-3 and abs(eff - 0.9460) < 1e-3
+
+
+# ----------------------------------------------------------------- edge rows of the unpinned restatements
+
+def test_ln_quant_edge_rows(oracle):
+    H = 4096
+    x = np.zeros((4, H), np.float16)
+    x[1] = 3.0                                  # constant row: var = 0, values 0 -> amax floor 1e-6
+    x[2, ::2], x[2, 1::2] = 1.0, -1.0           # +-1: normalised +-1 -> q = +-7
+    x[3, 0] = 100.0                             # one outlier
+    q, scale, isum = oracle.ln_quant_i4(x, 1e-5)
+    u = oracle.unpack_i4(q)
+    assert (u[0] == 0).all() and (u[1] == 0).all()
+    assert scale[0] == np.float16(np.float32(np.float16(1e-6)) / 7) == scale[1]
+    assert set(np.unique(u[2])) == {-7, 7}
+    assert u[3, 0] == 7 and np.abs(u[3, 1:]).max() == 0
+    out = oracle.ln_fp16(x, 1e-5)
+    assert np.allclose(out[2].astype(np.float32), x[2].astype(np.float32), atol=1e-3)
+
+
+def test_rowabsmax_edge_rows(oracle):
+    K = 256
+    x = np.zeros((3, K), np.float16)            # row 0 all zero -> scale 0 -> 0/0 = NaN -> 0
+    x[1] = np.linspace(-7, 7, K).astype(np.float16)
+    x[2, :4] = [3.5, 2.5, -2.5, -3.5]           # exact .5 ties at scale 1 -> round half to even
+    x[2, 4] = 7.0
+    q, scale = oracle.rowabsmax_quant_i4(x, 1.0)
+    u = oracle.unpack_i4(q)
+    assert (u[0] == 0).all() and scale[0] == 0
+    assert scale[1] == np.float16(1.0) and u[1, 0] == -7 and u[1, -1] == 7
+    assert list(u[2, :5]) == [4, 2, -2, -4, 7]
