@@ -20,7 +20,13 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 // fp16 <-> fp32: v_cvt_f32_f16 is exact, v_cvt_f16_f32 rounds to nearest even
 // in the default float mode hipcc sets for kernels.
 __device__ __forceinline__ float h2f(f16 h) { return (float)h; }
-__device__ __forceinline__ f16 f2h(float f) { return (f16)f; }
+// The empty asm keeps the fp32 value opaque: without it hipcc (even at -ffp-contract=off) may fold
+// `(f16)(a * b)` into v_fma_mixlo_f16, which rounds the exact product ONCE to fp16, whereas the
+// reference (and the oracle) round to fp32 first and then to fp16.
+__device__ __forceinline__ f16 f2h(float f) {
+    asm("" : "+v"(f));
+    return (f16)f;
+}
 __device__ __forceinline__ f16 u2h(uint16_t u) { return __builtin_bit_cast(f16, u); }
 __device__ __forceinline__ uint16_t h2u(f16 h) { return __builtin_bit_cast(uint16_t, h); }
 
