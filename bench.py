@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- accepted tokens/s + draft-accept-rate of the QSpec draft/verify cycle on MI355X.
+
+    python bench.py --gpus 1 --steps 100 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one speculative cycle of the whole batch: k W4A4 draft forwards + one W4A16 verify forward over
+k+1 tokens per sequence + rejection sampling + commit (one hipGraph replay).  Workload = BASELINE.json
+configs[1]: Llama-3-8B QSpec, k=3, bs=4, synthetic weights and prompts.  Prefill is outside
+the timed region (inputs resident in HBM when timing starts).
+
+One JSON line on rank 0: metric/value (accepted = emitted tokens per second, whole job), plus
+  roofline      dominant kernel (the W4A4 weight-streaming GEMM): algorithmic bytes / measured launch time
+  cpu_baseline  the CPU oracle ("port" of the reference arithmetic) timed on this host's cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--model", default="llama-3-8b")
+    p.add_argument("--k", type=int, default=3)
+    p.add_argument("--batch", type=int, default=4)
+    p.add_argument("--prompt-len", type=int, default=512)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--lm-head-std", type=float, default=0.02)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--cpu-layers", type=int, default=4, help="layers of the model the CPU baseline sample runs")
+    p.add_argument("--cpu-cycles", type=int, default=2)
+    return p.parse_args()
+
+
+def dist_setup(n):
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    assert world == n, f"--gpus {n} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    return rank, world, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def measure_dominant_kernel(model, engine, reps=3):
+    """Launch the dominant kernel (W4A4 GEMM, M = batch) eagerly on the real weights in model order, each launch
+    bracketed by HIP events recorded on the launching (= current torch) stream.  Returns per-shape and overall
+    algorithmic bytes and seconds."""
+    from qspec_amd import ops
+    cfg = model.config
+    B = engine.B
+    s = engine.scratch_draft
+    shapes = {}
+    ev = []
+    torch.cuda.synchronize()
+    for _ in range(reps):
+        for layer in model.layers:
+            for name, lin, xq, out in (("qkv", layer.qkv_proj, s.quantized_buffer_qkv, s.act_buffer_qkv),
+                                       ("o", layer.o_proj, s.quantized_buffer_qkv, s.act_buffer_output),
+                                       ("gate_up", layer.gate_up, s.quantized_buffer_qkv, s.act_buffer_gate_up),
+                                       ("down", layer.down_proj, s.quantized_buffer_mlp, s.act_buffer_output)):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq[:B], s.scale_buffer[:B], lin.weight, lin._scales(), None, out[:B])
+                b.record()
+                n, kb = lin.weight.shape
+                nbytes = n * kb + 2 * n + B * kb + 2 * B + 2 * B * n   # weights + scales + activations in/out
+                ev.append((name, nbytes, a, b))
+    torch.cuda.synchronize()
+    tot_b = tot_t = 0.0
+    for name, nbytes, a, b in ev:
+        t = a.elapsed_time(b) * 1e-3
+        d = shapes.setdefault(name, [0.0, 0.0, 0])
+        d[0] += nbytes
+        d[1] += t
+        d[2] += 1
+        tot_b += nbytes
+        tot_t += t
+    per_shape = {k: {"GB/s": round(v[0] / v[1] / 1e9, 1), "us": round(v[1] / v[2] * 1e6, 2)} for k, v in shapes.items()}
+    return tot_b, tot_t, len(ev), per_shape
+
+
+def cpu_baseline(model, args):
+    """The CPU oracle (port of the reference arithmetic) on this host: `cpu_layers` full-width layers + lm_head,
+    same k / batch, short prompts; layer time extrapolated to the full depth."""
+    import numpy as np
+    import oracle as O
+    from oracle.model import OracleEngine, OracleModel
+    O.build()
+    cfg = model.config
+    L = min(args.cpu_layers, cfg.num_hidden_layers)
+    om = OracleModel.from_torch_model(model, 16)
+    om.layers = om.layers[:L]
+    import copy
+    om.cfg = copy.copy(cfg)
+    om.cfg.num_hidden_layers = L
+    rng = np.random.default_rng(0)
+    cores = os.cpu_count() or 1
+    eng = OracleEngine(om, args.k, args.batch, 64, 16)
+    prompts = [rng.integers(0, cfg.vocab_size, 8).tolist() for _ in range(args.batch)]
+    eng.add_sequences(prompts)
+    V = cfg.vocab_size
+    # time the lm_head + sampler share separately so that only the layer share is scaled by depth
+    t0 = time.perf_counter()
+    emitted0 = sum(len(g) for g in eng.generated)
+    for _ in range(args.cpu_cycles):
+        eng.step(rng.random((args.batch, args.k)).astype(np.float32),
+                 rng.exponential(1.0, (args.batch, args.k, V)).astype(np.float32))
+    dt = (time.perf_counter() - t0) / args.cpu_cycles
+    emitted = (sum(len(g) for g in eng.generated) - emitted0) / args.cpu_cycles
+    x = (rng.standard_normal((args.batch, cfg.hidden_size))).astype(np.float16)
+    t1 = time.perf_counter()
+    O.softmax_argmax(om.logits(x))
+    head = time.perf_counter() - t1
+    head_cycle = head * (args.k + (args.k + 1))          # k draft heads at T=B, one verify head at T=B(k+1)
+    layers_cycle = max(dt - head_cycle, 0.0)
+    full = layers_cycle * cfg.num_hidden_layers / L + head_cycle
+    return {"value": round(emitted / full, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_cycles} cycles of the CPU oracle on {L}/{cfg.num_hidden_layers} full-width layers + lm_head, "
+                      f"k={args.k} bs={args.batch}, 8-token prompts; layer time x{cfg.num_hidden_layers // L} "
+                      f"extrapolated ({dt:.2f} s/cycle measured -> {full:.2f} s/cycle full depth), OpenMP {cores} threads"}
+
+
+def main():
+    args = parse()
+    rank, world, local = dist_setup(args.gpus)
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(dev)
+    from qspec_amd.model import CONFIGS, QuarotLlamaForCausalLM
+    from qspec_amd.spec_decode import QSpecEngine
+    cfg = CONFIGS[args.model]
+    if world > 1:
+        from qspec_amd import parallel
+        model = parallel.build_tp_model(cfg, dev, world, rank, seed=args.seed, lm_head_std=args.lm_head_std)
+    else:
+        model = QuarotLlamaForCausalLM(cfg, dev).init_synthetic(args.seed, args.lm_head_std)
+    cycles_total = args.warmup + args.steps + 2
+    max_len = args.prompt_len + cycles_total * (args.k + 1) + 32
+    eng = QSpecEngine(model, args.k, args.batch, max_model_len=max_len, block_size=16,
+                      max_new_tokens=cycles_total * (args.k + 1) + 8, use_graph=True, seed=args.seed)
+    g = torch.Generator().manual_seed(args.seed)
+    prompts = [torch.randint(0, cfg.vocab_size, (args.prompt_len,), generator=g).tolist() for _ in range(args.batch)]
+    eng.add_sequences(prompts)                   # prefill, untimed
+    for _ in range(args.warmup):
+        eng.step()
+    barrier(world)
+    c0 = eng.sampler.counters.clone()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    barrier(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    c1 = eng.sampler.counters
+    acc, emit, draft = (int(v) for v in (c1 - c0).tolist())
+    rate = acc / draft if draft else float("nan")
+    eff = emit / ((draft // args.k) * (args.k + 1)) if draft else float("nan")
+    alg_bytes_cycle = (args.k + 1) * cfg.algorithmic_bytes_per_forward()
+    out = {
+        "metric": "accepted_tokens_per_s", "value": round(emit / dt, 2), "unit": "tokens/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "w4a4: s4 x s4 -> i32 (i8 MFMA); w4a16: f16 x s4 -> f32 (f16 MFMA)", "data": "synthetic",
+        "config": {"workload": f"{cfg.name} QSpec W4A4-draft/W4A16-verify k={args.k} bs={args.batch} TP={world} "
+                               f"prompt_len={args.prompt_len} greedy, synthetic int4 weights (SURVEY 8d), 1 cycle = "
+                               f"{args.k} draft fwd + 1 verify fwd + rejection sampling",
+                   "num_speculative_tokens": args.k, "batch": args.batch, "parallelism": f"tp{world}"},
+        "draft_acceptance_rate": round(rate, 4), "system_efficiency": round(eff, 4),
+        "accepted_tokens": acc, "emitted_tokens": emit, "draft_tokens": draft,
+        "cycle_hbm_GBps_algorithmic": round(alg_bytes_cycle / (dt / args.steps) / 1e9, 1),
+    }
+    if rank == 0 and world == 1 and not args.no_roofline:
+        tot_b, tot_t, n, per_shape = measure_dominant_kernel(model, eng)
+        achieved = tot_b / tot_t / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(achieved / 8000.0, 4), "traffic": None,
+                           "kernel": "qspec::gemm_w4a4_kernel<1> (all four decoder GEMM shapes, M = batch)",
+                           "launches": n, "avg_launch_us": round(tot_t / n * 1e6, 2),
+                           "bytes_per_launch_avg": int(tot_b / n), "per_shape": per_shape}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,10 @@ int qspec_hadamard_mix(const qspec_half* y, const qspec_half* hadK, qspec_half* 
 int qspec_heads_hadamard(const qspec_half* attn, qspec_half* out_f16, int8_t* q, qspec_half* scale, float had_scale,
                          float clip_ratio, int tokens, int heads, int head_dim, void* stream);
 
+/* `self.act_fn(gate) * up_proj` on the fused gate_up output (quarot_llama.py:279-284): up = [:, :I], gate = [:, I:];
+ * out [tokens, I] = h(h(silu(gate)) * up).  Stand-alone form of the first stage of qspec_silu_mul_hadamard. */
+int qspec_silu_mul(const qspec_half* gate_up, qspec_half* out, int tokens, int intermediate, void* stream);
+
 /* down_proj input path of QuarotLlamaMLP.forward (quarot_llama.py:279-295): up = gate_up[:, :I],
  * gate = gate_up[:, I:]; silu(gate)*up -> (hadK (x) H_{I/K}) * had_scale [-> Quantizer], one kernel.
  * hadK [K,K] fp16 (ignored when K == 1).  Same q == NULL / != NULL convention. */
@@ -150,11 +154,18 @@ int qspec_softmax_argmax(const qspec_half* logits, float* probs, int64_t* token,
 /* RejectionSampler.forward(target_with_bonus_probs, bonus_token_ids, draft_probs, draft_token_ids)
  *   vllm/model_executor/layers/rejection_sampler.py:60-154 + spec_decode_base_sampler.py:69-131.
  *   uniform [B,k] / exponential [B,k,V] fp32: injected random draws (tests); NULL -> Philox(seed, offset).
+ *   rng_state: NULL, or a device uint64[2] = {seed, offset} that overrides the two scalars and whose offset
+ *   is incremented by the call (so a captured graph draws fresh numbers on every replay).
+ *   draft_probs element (b,i,v) is at b*dp_stride_b + i*dp_stride_k + v, draft_token_ids (b,i) at
+ *   b*ids_stride_b + i*ids_stride_k, bonus b at b*bonus_stride (elements): contiguous [B,k,V]/[B,k]/[B] tensors
+ *   pass (k*V, V, k, 1, 1); the draft loop writes step-major buffers and passes their strides instead of copying.
  *   out_tokens [B,k+1] (-1 = no token); accepted [B,k] u8; recovered [B,k];
  *   counters[3] += {accepted, emitted, draft} (may be NULL). */
 int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* bonus_token_ids,
                            const float* draft_probs, const int64_t* draft_token_ids, const float* uniform,
-                           const float* exponential, uint64_t seed, uint64_t offset, int batch, int k, int vocab,
+                           const float* exponential, uint64_t seed, uint64_t offset, uint64_t* rng_state, int batch,
+                           int k, int vocab, int64_t dp_stride_b, int64_t dp_stride_k, int64_t ids_stride_b,
+                           int64_t ids_stride_k, int64_t bonus_stride,
                            int64_t* out_tokens, uint8_t* accepted, int64_t* recovered, int64_t* counters,
                            void* stream);
 
@@ -165,6 +176,29 @@ int qspec_advance_step_flashattn(int num_seqs, int block_size, int64_t* input_to
                                  const int64_t* sampled_token_ids, int64_t* input_positions, int32_t* seq_lens,
                                  int64_t* slot_mapping, const int32_t* block_tables, int64_t block_tables_stride,
                                  void* stream);
+
+/* ---- spec-decode cycle glue (input assembly + bookkeeping kept on the GPU) -------------------- */
+/* Sequence state: seq_lens[b] = L known tokens (KV valid below L-1), last_token[b] = token at L-1.
+
+ * First draft-step inputs (TP1DraftModelRunner.execute_model, vllm/spec_decode/draft_model_runner.py:169-262):
+ *   token = last_token, position = L-1, ctx_len = L, slot from the block table. */
+int qspec_spec_prepare_draft(int batch, int block_size, const int64_t* last_token, const int32_t* seq_lens,
+                             const int32_t* block_tables, int64_t block_tables_stride, int64_t* input_tokens,
+                             int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens, void* stream);
+
+/* MQAScorer.score_proposals (vllm/spec_decode/mqa_scorer.py:12-76): per sequence the k+1 query tokens
+ * [last_token, d_1..d_k] at positions L-1..L-1+k over the SAME block table (verify KV overwrites draft KV). */
+int qspec_spec_prepare_verify(int batch, int k, int block_size, const int64_t* last_token,
+                              const int64_t* draft_token_ids, int64_t ids_stride_b, int64_t ids_stride_k,
+                              const int32_t* seq_lens, const int32_t* block_tables,
+                              int64_t block_tables_stride, int64_t* tokens, int64_t* positions, int64_t* slot_mapping,
+                              int32_t* ctx_lens, void* stream);
+
+/* SpecDecodeWorker._create_output_sampler_list bookkeeping (vllm/spec_decode/spec_decode_worker.py:972-1063):
+ * append the emitted prefix of out_tokens[b] (-1 = nothing) to gen_tokens[b] (may be NULL), advance seq_lens,
+ * last_token = last emitted token. */
+int qspec_spec_commit(int batch, int k, const int64_t* out_tokens, int32_t* seq_lens, int64_t* last_token,
+                      int64_t* gen_tokens, int32_t* gen_lens, int gen_capacity, void* stream);
 
 #ifdef __cplusplus
 }

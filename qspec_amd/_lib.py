@@ -29,6 +29,7 @@ SIGNATURES = {
     "qspec_fast_hadamard_transform": (_i, [_vp, _f, _vp, _i64, _i, _vp]),
     "qspec_hadamard_mix": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_heads_hadamard": (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
+    "qspec_silu_mul": (_i, [_vp, _vp, _i, _i, _vp]),
     "qspec_silu_mul_hadamard": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
     "qspec_rowwise_scaled_linear_s4s4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_w4a16_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -42,8 +43,12 @@ SIGNATURES = {
                                    _vp, _vp]),
     "qspec_embedding": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_softmax_argmax": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
-    "qspec_rejection_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "qspec_rejection_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _i, _i64, _i64, _i64, _i64,
+                                    _i64, _vp, _vp, _vp, _vp, _vp]),
     "qspec_advance_step_flashattn": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "qspec_spec_prepare_draft": (_i, [_i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "qspec_spec_prepare_verify": (_i, [_i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "qspec_spec_commit": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
 }
 
 

@@ -109,6 +109,12 @@ int qspec_heads_hadamard(const qspec_half* attn, qspec_half* out_f16, int8_t* q,
     if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
     return finish(op, qspec::heads_hadamard(CH(attn), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, heads, head_dim, ST));
 }
+int qspec_silu_mul(const qspec_half* gate_up, qspec_half* out, int tokens, int intermediate, void* stream) {
+    const char* op = "qspec_silu_mul";
+    if (tokens == 0) return 0;
+    NONNULL(op, gate_up); NONNULL(op, out);
+    return finish(op, qspec::silu_mul(CH(gate_up), H(out), tokens, intermediate, ST));
+}
 int qspec_silu_mul_hadamard(const qspec_half* gate_up, const qspec_half* hadK, qspec_half* out_f16, int8_t* q,
                             qspec_half* scale, float had_scale, float clip_ratio, int tokens, int intermediate, int K,
                             void* stream) {
@@ -210,7 +216,9 @@ int qspec_softmax_argmax(const qspec_half* logits, float* probs, int64_t* token,
 }
 int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* bonus_token_ids,
                            const float* draft_probs, const int64_t* draft_token_ids, const float* uniform,
-                           const float* exponential, uint64_t seed, uint64_t offset, int batch, int k, int vocab,
+                           const float* exponential, uint64_t seed, uint64_t offset, uint64_t* rng_state, int batch,
+                           int k, int vocab, int64_t dp_stride_b, int64_t dp_stride_k, int64_t ids_stride_b,
+                           int64_t ids_stride_k, int64_t bonus_stride,
                            int64_t* out_tokens, uint8_t* accepted, int64_t* recovered, int64_t* counters,
                            void* stream) {
     const char* op = "qspec_rejection_sample";
@@ -218,7 +226,7 @@ int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* 
     NONNULL(op, target_with_bonus_probs); NONNULL(op, bonus_token_ids); NONNULL(op, draft_probs);
     NONNULL(op, draft_token_ids); NONNULL(op, out_tokens); NONNULL(op, accepted); NONNULL(op, recovered);
     if (k < 1) return fail("%s: k=%d must be >= 1", op, k);
-    return finish(op, qspec::rejection_sample(target_with_bonus_probs, draft_probs, draft_token_ids, bonus_token_ids, uniform, exponential, seed, offset, batch, k, vocab, out_tokens, accepted, recovered, counters, ST));
+    return finish(op, qspec::rejection_sample(target_with_bonus_probs, draft_probs, draft_token_ids, bonus_token_ids, uniform, exponential, seed, offset, rng_state, batch, k, vocab, dp_stride_b, dp_stride_k, ids_stride_b, ids_stride_k, bonus_stride, out_tokens, accepted, recovered, counters, ST));
 }
 int qspec_advance_step_flashattn(int num_seqs, int block_size, int64_t* input_tokens,
                                  const int64_t* sampled_token_ids, int64_t* input_positions, int32_t* seq_lens,
@@ -229,6 +237,35 @@ int qspec_advance_step_flashattn(int num_seqs, int block_size, int64_t* input_to
     NONNULL(op, input_tokens); NONNULL(op, sampled_token_ids); NONNULL(op, input_positions); NONNULL(op, seq_lens);
     NONNULL(op, slot_mapping); NONNULL(op, block_tables);
     return finish(op, qspec::advance_step(num_seqs, block_size, input_tokens, sampled_token_ids, input_positions, seq_lens, slot_mapping, block_tables, block_tables_stride, ST));
+}
+
+int qspec_spec_prepare_draft(int batch, int block_size, const int64_t* last_token, const int32_t* seq_lens,
+                             const int32_t* block_tables, int64_t block_tables_stride, int64_t* input_tokens,
+                             int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens, void* stream) {
+    const char* op = "qspec_spec_prepare_draft";
+    if (batch == 0) return 0;
+    NONNULL(op, last_token); NONNULL(op, seq_lens); NONNULL(op, block_tables); NONNULL(op, input_tokens);
+    NONNULL(op, positions); NONNULL(op, slot_mapping); NONNULL(op, ctx_lens);
+    return finish(op, qspec::spec_prepare_draft(batch, block_size, last_token, seq_lens, block_tables, block_tables_stride, input_tokens, positions, slot_mapping, ctx_lens, ST));
+}
+int qspec_spec_prepare_verify(int batch, int k, int block_size, const int64_t* last_token,
+                              const int64_t* draft_token_ids, int64_t ids_stride_b, int64_t ids_stride_k,
+                              const int32_t* seq_lens, const int32_t* block_tables,
+                              int64_t block_tables_stride, int64_t* tokens, int64_t* positions, int64_t* slot_mapping,
+                              int32_t* ctx_lens, void* stream) {
+    const char* op = "qspec_spec_prepare_verify";
+    if (batch == 0) return 0;
+    NONNULL(op, last_token); NONNULL(op, draft_token_ids); NONNULL(op, seq_lens); NONNULL(op, block_tables);
+    NONNULL(op, tokens); NONNULL(op, positions); NONNULL(op, slot_mapping); NONNULL(op, ctx_lens);
+    return finish(op, qspec::spec_prepare_verify(batch, k, block_size, last_token, draft_token_ids, ids_stride_b, ids_stride_k, seq_lens, block_tables, block_tables_stride, tokens, positions, slot_mapping, ctx_lens, ST));
+}
+int qspec_spec_commit(int batch, int k, const int64_t* out_tokens, int32_t* seq_lens, int64_t* last_token,
+                      int64_t* gen_tokens, int32_t* gen_lens, int gen_capacity, void* stream) {
+    const char* op = "qspec_spec_commit";
+    if (batch == 0) return 0;
+    NONNULL(op, out_tokens); NONNULL(op, seq_lens); NONNULL(op, last_token);
+    if (gen_tokens) NONNULL(op, gen_lens);
+    return finish(op, qspec::spec_commit(batch, k, out_tokens, seq_lens, last_token, gen_tokens, gen_lens, gen_capacity, ST));
 }
 
 }  // extern "C"

@@ -167,6 +167,23 @@ int heads_hadamard(const f16* attn, f16* out_f16, int8_t* q, f16* scale, float h
     return -1;
 }
 
+// standalone silu(gate)*up (API-parity op for the module-wise path; the engine uses the fused kernel below)
+__global__ __launch_bounds__(256) void silu_mul_kernel(const f16* __restrict__ gate_up, f16* __restrict__ out, int I) {
+    const int t = blockIdx.x;
+    const f16* up = gate_up + (size_t)t * 2 * I;
+    const f16* gate = up + I;
+    for (int i = threadIdx.x; i < I; i += 256) {
+        float g = h2f(gate[i]);
+        float a = h2f(f2h(g / (1.0f + qexpf(-g))));
+        out[(size_t)t * I + i] = f2h(a * h2f(up[i]));
+    }
+}
+int silu_mul(const f16* gate_up, f16* out, int T, int I, hipStream_t st) {
+    if (T == 0) return 0;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3(T), dim3(256), 0, st, gate_up, out, I);
+    return 0;
+}
+
 // ------------------------------------- silu*up -> (hadK (x) H_P) -> quant (down_proj)
 // gate_up [T, 2I] (up first, gate second).  I = K * P, P a power of two.
 //   g[e]    = h( h(silu(gate[e])) * up[e] )

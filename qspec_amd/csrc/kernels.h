@@ -19,6 +19,7 @@ int fwht(const f16* x, float scale, f16* out, int64_t rows, int N, hipStream_t s
 int hadk_mix(const f16* y, const f16* hadK, f16* out, int T, int K, int M, hipStream_t st);
 int heads_hadamard(const f16* attn, f16* out_f16, int8_t* q, f16* scale, float had_scale, float clip, int T,
                    int heads, int d, hipStream_t st);
+int silu_mul(const f16* gate_up, f16* out, int T, int I, hipStream_t st);
 int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,
                       float clip, int T, int I, int K, hipStream_t st);
 
@@ -50,9 +51,18 @@ int embedding(const int64_t* ids, const f16* table, f16* out, int T, int H, int 
 int softmax_argmax(const f16* logits, float* probs, int64_t* token, int T, int V, hipStream_t st);
 int rejection_sample(const float* target_probs, const float* draft_probs, const int64_t* draft_ids,
                      const int64_t* bonus_ids, const float* uniform, const float* exponential, uint64_t seed,
-                     uint64_t offset, int B, int k, int V, int64_t* out_tokens, uint8_t* accepted,
+                     uint64_t offset, uint64_t* rng_state, int B, int k, int V, int64_t dp_sb, int64_t dp_sk,
+                     int64_t di_sb, int64_t di_sk, int64_t bonus_stride, int64_t* out_tokens, uint8_t* accepted,
                      int64_t* recovered, int64_t* counters, hipStream_t st);
 int advance_step(int n, int block_size, int64_t* input_tokens, const int64_t* sampled, int64_t* positions,
                  int32_t* seq_lens, int64_t* slot_mapping, const int32_t* block_tables, int64_t bt_stride,
                  hipStream_t st);
+int spec_prepare_draft(int B, int block_size, const int64_t* last_token, const int32_t* seq_lens,
+                       const int32_t* block_tables, int64_t bt_stride, int64_t* input_tokens, int64_t* positions,
+                       int64_t* slot_mapping, int32_t* ctx_lens, hipStream_t st);
+int spec_prepare_verify(int B, int k, int block_size, const int64_t* last_token, const int64_t* draft_ids,
+                        int64_t di_sb, int64_t di_sk, const int32_t* seq_lens, const int32_t* block_tables, int64_t bt_stride, int64_t* v_tokens,
+                        int64_t* v_positions, int64_t* v_slots, int32_t* v_ctx_lens, hipStream_t st);
+int spec_commit(int B, int k, const int64_t* out_tokens, int32_t* seq_lens, int64_t* last_token, int64_t* gen_tokens,
+                int32_t* gen_lens, int gen_cap, hipStream_t st);
 }  // namespace qspec

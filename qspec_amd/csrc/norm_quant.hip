@@ -52,8 +52,8 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
 // If delta != nullptr the row is first formed as h(f(x) + f(delta)) (the fp16
 // residual add of quarot_llama.py:380,390) and written to hidden_out.
 template <int NI, int MODE>
-__global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, const f16* __restrict__ delta,
-                                                 f16* __restrict__ hidden_out, f16* __restrict__ out,
+__global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __restrict__ delta,
+                                                 f16* hidden_out /* may alias x */, f16* __restrict__ out,
                                                  int8_t* __restrict__ q, f16* __restrict__ scale,
                                                  f16* __restrict__ input_sum, float eps, int H) {
     __shared__ float red[32];

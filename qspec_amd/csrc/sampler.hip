@@ -131,14 +131,20 @@ __global__ __launch_bounds__(1024) void rejection_core_kernel(const float* __res
                                                               const int64_t* __restrict__ draft_ids,
                                                               const float* __restrict__ uniform,
                                                               const float* __restrict__ exponential, uint64_t seed,
-                                                              uint64_t offset, int k, int V,
+                                                              uint64_t offset, const uint64_t* __restrict__ rng_state,
+                                                              int k, int V, int64_t dp_sb, int64_t dp_sk,
+                                                              int64_t di_sb, int64_t di_sk,
                                                               uint8_t* __restrict__ accepted,
                                                               int64_t* __restrict__ recovered) {
     __shared__ ArgMax red_a[16];
     __shared__ double red_d[16];
     const int b = blockIdx.x / k, i = blockIdx.x % k;
     const float* q = target_probs + ((size_t)b * (k + 1) + i) * V;
-    const float* p = draft_probs + ((size_t)b * k + i) * V;
+    const float* p = draft_probs + b * dp_sb + i * dp_sk;
+    if (rng_state) {  // device-resident (seed, offset): lets a captured graph draw fresh numbers every replay
+        seed = rng_state[0];
+        offset = rng_state[1];
+    }
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const float tiny = 1.17549435e-38f;
     double s = 0.0;
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(1024) void rejection_core_kernel(const float* __res
     }
     am = block_argmax(am, red_a);
     if (threadIdx.x == 0) {
-        const int64_t x = draft_ids[(size_t)b * k + i];
+        const int64_t x = draft_ids[b * di_sb + i * di_sk];
         float u;
         if (uniform) {
             u = uniform[(size_t)b * k + i];
@@ -185,8 +191,11 @@ __global__ __launch_bounds__(1024) void rejection_core_kernel(const float* __res
 // counters[0] += accepted.sum() (non-causal), counters[1] += #(out != -1), counters[2] += B*k.
 __global__ void rejection_output_kernel(const uint8_t* __restrict__ accepted, const int64_t* __restrict__ recovered,
                                         const int64_t* __restrict__ draft_ids, const int64_t* __restrict__ bonus_ids,
-                                        int B, int k, int64_t* __restrict__ out, int64_t* __restrict__ counters) {
+                                        int B, int k, int64_t di_sb, int64_t di_sk, int64_t bonus_stride,
+                                        int64_t* __restrict__ out, int64_t* __restrict__ counters,
+                                        uint64_t* __restrict__ rng_state) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rng_state && b == 0) rng_state[1] += 1;  // runs after the core kernel on the same stream
     int acc_cnt = 0, emit_cnt = 0;
     if (b < B) {
         int limit = k;
@@ -195,11 +204,11 @@ __global__ void rejection_output_kernel(const uint8_t* __restrict__ accepted, co
             else if (limit == k) limit = i;
         }
         for (int i = 0; i < k; i++) {
-            int64_t v = i < limit ? draft_ids[b * k + i] : (i == limit ? recovered[b * k + i] : -1);
+            int64_t v = i < limit ? draft_ids[b * di_sb + i * di_sk] : (i == limit ? recovered[b * k + i] : -1);
             out[b * (k + 1) + i] = v;
             emit_cnt += v != -1;
         }
-        int64_t last = limit == k ? bonus_ids[b] : -1;
+        int64_t last = limit == k ? bonus_ids[b * bonus_stride] : -1;
         out[b * (k + 1) + k] = last;
         emit_cnt += last != -1;
     }
@@ -212,14 +221,16 @@ __global__ void rejection_output_kernel(const uint8_t* __restrict__ accepted, co
 
 int rejection_sample(const float* target_probs, const float* draft_probs, const int64_t* draft_ids,
                      const int64_t* bonus_ids, const float* uniform, const float* exponential, uint64_t seed,
-                     uint64_t offset, int B, int k, int V, int64_t* out_tokens, uint8_t* accepted, int64_t* recovered,
-                     int64_t* counters, hipStream_t st) {
+                     uint64_t offset, uint64_t* rng_state, int B, int k, int V, int64_t dp_sb, int64_t dp_sk,
+                     int64_t di_sb, int64_t di_sk, int64_t bonus_stride, int64_t* out_tokens, uint8_t* accepted,
+                     int64_t* recovered, int64_t* counters, hipStream_t st) {
     if (B == 0) return 0;
     if (k < 1) return -1;
     hipLaunchKernelGGL(rejection_core_kernel, dim3(B * k), dim3(1024), 0, st, target_probs, draft_probs, draft_ids,
-                       uniform, exponential, seed, offset, k, V, accepted, recovered);
+                       uniform, exponential, seed, offset, rng_state, k, V, dp_sb, dp_sk, di_sb, di_sk, accepted,
+                       recovered);
     hipLaunchKernelGGL(rejection_output_kernel, dim3((B + 63) / 64), dim3(64), 0, st, accepted, recovered, draft_ids,
-                       bonus_ids, B, k, out_tokens, counters);
+                       bonus_ids, B, k, di_sb, di_sk, bonus_stride, out_tokens, counters, rng_state);
     return 0;
 }
 
@@ -243,6 +254,87 @@ int advance_step(int n, int block_size, int64_t* input_tokens, const int64_t* sa
     if (n == 0) return 0;
     hipLaunchKernelGGL(advance_step_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, block_size, input_tokens,
                        sampled, positions, seq_lens, slot_mapping, block_tables, bt_stride);
+    return 0;
+}
+
+
+// ---------------------------------------------------------------- spec-decode cycle glue
+// The per-cycle input assembly that the reference does on the host between GPU passes
+// (TP1DraftModelRunner first-step inputs, vllm/spec_decode/draft_model_runner.py:169-262;
+//  MQAScorer.score_proposals, vllm/spec_decode/mqa_scorer.py:12-76;
+//  SpecDecodeWorker._create_output_sampler_list bookkeeping, spec_decode_worker.py:972-1063)
+// kept on the GPU so that a whole draft+verify+accept cycle is one graph with no host sync.
+// Sequence state: seq_lens[b] = L tokens known, KV valid for positions < L-1, last_token[b] = token L-1.
+__global__ void spec_prepare_draft_kernel(int B, int block_size, const int64_t* __restrict__ last_token,
+                                          const int32_t* __restrict__ seq_lens,
+                                          const int32_t* __restrict__ block_tables, int64_t bt_stride,
+                                          int64_t* __restrict__ input_tokens, int64_t* __restrict__ positions,
+                                          int64_t* __restrict__ slot_mapping, int32_t* __restrict__ ctx_lens) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int L = seq_lens[b], pos = L - 1;
+    input_tokens[b] = last_token[b];
+    positions[b] = pos;
+    ctx_lens[b] = L;
+    slot_mapping[b] = (int64_t)block_tables[bt_stride * b + pos / block_size] * block_size + pos % block_size;
+}
+// verify query of sequence b = [last_token, d_1 .. d_k] at positions L-1 .. L-1+k (mqa_scorer.py:42-60)
+__global__ void spec_prepare_verify_kernel(int B, int k, int block_size, const int64_t* __restrict__ last_token,
+                                           const int64_t* __restrict__ draft_ids, int64_t di_sb, int64_t di_sk,
+                                           const int32_t* __restrict__ seq_lens,
+                                           const int32_t* __restrict__ block_tables, int64_t bt_stride,
+                                           int64_t* __restrict__ v_tokens, int64_t* __restrict__ v_positions,
+                                           int64_t* __restrict__ v_slots, int32_t* __restrict__ v_ctx_lens) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * (k + 1)) return;
+    const int b = i / (k + 1), j = i % (k + 1);
+    const int L = seq_lens[b], pos = L - 1 + j;
+    v_tokens[i] = j == 0 ? last_token[b] : draft_ids[b * di_sb + (j - 1) * di_sk];
+    v_positions[i] = pos;
+    v_slots[i] = (int64_t)block_tables[bt_stride * b + pos / block_size] * block_size + pos % block_size;
+    if (j == 0) v_ctx_lens[b] = L + k;
+}
+// append the emitted tokens (out != -1, a prefix of the row) and advance the sequence state
+__global__ void spec_commit_kernel(int B, int k, const int64_t* __restrict__ out_tokens,
+                                   int32_t* __restrict__ seq_lens, int64_t* __restrict__ last_token,
+                                   int64_t* __restrict__ gen_tokens, int32_t* __restrict__ gen_lens, int gen_cap) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int n = 0;
+    for (int j = 0; j <= k; j++) {
+        int64_t t = out_tokens[b * (k + 1) + j];
+        if (t == -1) break;
+        if (gen_tokens && gen_lens[b] + n < gen_cap) gen_tokens[(int64_t)b * gen_cap + gen_lens[b] + n] = t;
+        n++;
+    }
+    if (n > 0) {
+        last_token[b] = out_tokens[b * (k + 1) + n - 1];
+        seq_lens[b] += n;
+        if (gen_lens) gen_lens[b] += n;
+    }
+}
+int spec_prepare_draft(int B, int block_size, const int64_t* last_token, const int32_t* seq_lens,
+                       const int32_t* block_tables, int64_t bt_stride, int64_t* input_tokens, int64_t* positions,
+                       int64_t* slot_mapping, int32_t* ctx_lens, hipStream_t st) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(spec_prepare_draft_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, block_size, last_token,
+                       seq_lens, block_tables, bt_stride, input_tokens, positions, slot_mapping, ctx_lens);
+    return 0;
+}
+int spec_prepare_verify(int B, int k, int block_size, const int64_t* last_token, const int64_t* draft_ids,
+                        int64_t di_sb, int64_t di_sk, const int32_t* seq_lens, const int32_t* block_tables, int64_t bt_stride, int64_t* v_tokens,
+                        int64_t* v_positions, int64_t* v_slots, int32_t* v_ctx_lens, hipStream_t st) {
+    if (B == 0) return 0;
+    const int n = B * (k + 1);
+    hipLaunchKernelGGL(spec_prepare_verify_kernel, dim3((n + 63) / 64), dim3(64), 0, st, B, k, block_size, last_token,
+                       draft_ids, di_sb, di_sk, seq_lens, block_tables, bt_stride, v_tokens, v_positions, v_slots, v_ctx_lens);
+    return 0;
+}
+int spec_commit(int B, int k, const int64_t* out_tokens, int32_t* seq_lens, int64_t* last_token, int64_t* gen_tokens,
+                int32_t* gen_lens, int gen_cap, hipStream_t st) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(spec_commit_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, k, out_tokens, seq_lens,
+                       last_token, gen_tokens, gen_lens, gen_cap);
     return 0;
 }
 

@@ -1,0 +1,276 @@
+"""QuarotLlamaForCausalLM on MI355X: the model shared by the draft (W4A4) and verify (W4A16) passes.
+
+Mirror of vllm/model_executor/models/quarot_llama.py (QuarotLlamaAttention :62, QuarotLlamaMLP :247,
+QuarotDecoderLayer :319, LlamaModel :436, QuarotLlamaForCausalLM :597): same weights, same op order, same
+`forward(input_ids, positions, kv_caches, attn_metadata, **kwargs)` with the `w4a4` kwarg selecting the pass.
+One set of packed int4 weights and one paged KV cache serve both passes.
+
+Two implementations of the layer body:
+  * `forward`            -- the product path: 10 fused HIP kernels per layer, no transposes / copies;
+  * `forward_modulewise` -- module by module through qspec_amd.quarot_nn exactly in the reference's order
+                            (one reference op per call); kept for parity tests of the fusion.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import hadamard_tables, ops, quarot_nn
+
+
+@dataclass
+class QuarotLlamaConfig:
+    hidden_size: int = 4096
+    intermediate_size: int = 14336
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    num_hidden_layers: int = 32
+    vocab_size: int = 128256
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    max_position_embeddings: int = 8192
+    name: str = "llama-3-8b"
+
+    @property
+    def head_dim(self):
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def q_size(self):
+        return self.num_attention_heads * self.head_dim
+
+    @property
+    def kv_size(self):
+        return self.num_key_value_heads * self.head_dim
+
+    def packed_weight_bytes_per_layer(self):
+        H, I = self.hidden_size, self.intermediate_size
+        return ((self.q_size + 2 * self.kv_size) * H + H * H + 2 * I * H + H * I) // 2
+
+    def algorithmic_bytes_per_forward(self):
+        """packed weights + channel scales + fp16 lm_head (KV reads and activations excluded)."""
+        H, I, L = self.hidden_size, self.intermediate_size, self.num_hidden_layers
+        scales = 2 * (self.q_size + 2 * self.kv_size + H + 2 * I + H) * L
+        return self.packed_weight_bytes_per_layer() * L + scales + 2 * self.vocab_size * H
+
+
+CONFIGS = {
+    "llama-3-8b": QuarotLlamaConfig(),
+    "tinyllama-1.1b": QuarotLlamaConfig(2048, 5632, 32, 4, 22, 32000, 1e-5, 10000.0, 2048, "tinyllama-1.1b"),
+    "llama-2-13b": QuarotLlamaConfig(5120, 13824, 40, 40, 40, 32000, 1e-5, 10000.0, 4096, "llama-2-13b"),
+    "llama-3-70b": QuarotLlamaConfig(8192, 28672, 64, 8, 80, 128256, 1e-5, 500000.0, 8192, "llama-3-70b"),
+}
+
+
+@dataclass
+class AttentionMetadata:
+    """What vllm's FlashAttentionMetadata carries for this path (vllm/attention/backends/flash_attn.py:96-180)."""
+    slot_mapping: torch.Tensor          # [T] i64
+    block_tables: torch.Tensor          # [B, max_blocks] i32
+    ctx_lens: torch.Tensor              # [B] i32: keys visible to the LAST query token of each sequence
+    q_start: torch.Tensor               # [B+1] i32: query_start_loc
+    max_q_len: int
+    n_splits: int                       # context splits for the attention kernel (fixed per captured graph)
+
+
+class Scratch:
+    """Per-shape activation buffers, allocated once (the reference re-allocates ten of them every draft step,
+    vllm/spec_decode/draft_model_runner.py:279-320; names kept)."""
+
+    def __init__(self, cfg: QuarotLlamaConfig, T: int, n_seqs: int, max_q_len: int, n_splits: int, device,
+                 logits_rows: Optional[int] = None):
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        f16, i8 = torch.float16, torch.int8
+        e = lambda *s, dtype=f16: torch.empty(*s, dtype=dtype, device=device)  # noqa: E731
+        self.T = T
+        self.hidden = e(T, H)
+        self.normed = e(T, H)                                  # verify: fp16 LN output
+        self.quantized_buffer_qkv = e(T, H // 2, dtype=i8)     # draft: int4 activations of width H
+        self.quantized_buffer_mlp = e(T, I // 2, dtype=i8)
+        self.scale_buffer = e(T)
+        self.input_sum_buffer = e(T)
+        self.act_buffer_qkv = e(T, cfg.q_size + 2 * cfg.kv_size)
+        self.act_buffer_attn = e(T, cfg.q_size)
+        self.act_buffer_had = e(T, cfg.q_size)
+        self.act_buffer_output = e(T, H)
+        self.act_buffer_gate_up = e(T, 2 * I)
+        self.act_buffer_had_mlp = e(T, I)
+        self.logits = e(T if logits_rows is None else logits_rows, cfg.vocab_size)
+        ws = ops.paged_attention_workspace_bytes(n_seqs * max_q_len, cfg.num_attention_heads, cfg.head_dim, n_splits)
+        self.attn_ws = torch.empty(ws, dtype=torch.uint8, device=device)
+
+
+class DecoderLayerWeights:
+    def __init__(self, cfg: QuarotLlamaConfig, device):
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        mk = lambda i, o: quarot_nn.Linear4bit(i, o, bias=False, device=device)  # noqa: E731
+        self.qkv_proj = mk(H, cfg.q_size + 2 * cfg.kv_size)   # rows [q; k; v]   (fuse_qkv, quarot_llama.py:152-173)
+        self.o_proj = mk(H, H)
+        self.gate_up = mk(H, 2 * I)                            # rows [up; gate]  (fuse_gate_up, :301-314)
+        self.down_proj = mk(I, H)
+
+    def linears(self):
+        return (self.qkv_proj, self.o_proj, self.gate_up, self.down_proj)
+
+
+class QuarotLlamaForCausalLM:
+    def __init__(self, cfg: QuarotLlamaConfig, device="cuda:0"):
+        self.config = cfg
+        self.device = torch.device(device)
+        self.layers: List[DecoderLayerWeights] = [DecoderLayerWeights(cfg, device) for _ in range(cfg.num_hidden_layers)]
+        self.embed_tokens = torch.zeros(cfg.vocab_size, cfg.hidden_size, dtype=torch.float16, device=device)
+        self.lm_head = torch.zeros(cfg.vocab_size, cfg.hidden_size, dtype=torch.float16, device=device)
+        had, self.had_K = hadamard_tables.get_hadK(cfg.intermediate_size)
+        self.had_rem_dim = had.to(torch.float16).to(device) if had is not None else None
+        self.head_had_scale = float(1.0 / torch.tensor(cfg.num_attention_heads).sqrt())      # hadamard.py:12
+        self.mlp_had_scale = float(1.0 / torch.tensor(cfg.intermediate_size).sqrt())         # hadamard.py:13
+        self.sm_scale = cfg.head_dim ** -0.5
+        self.cos_sin_cache = make_cos_sin_cache(cfg.head_dim, cfg.max_position_embeddings, cfg.rope_theta).to(device)
+        # module-wise mirrors share the same buffers
+        self.norm = quarot_nn.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+        self.quantizer = quarot_nn.Quantizer()
+
+    # ------------------------------------------------------------------ weights
+    @torch.no_grad()
+    def init_synthetic(self, seed: int = 0, lm_head_std: float = 0.02):
+        """SURVEY.md 8d synthetic model: int4 weights U{-8..7}, scales |N(0,1)|*0.01+1e-3, embed/lm_head N(0,0.02)."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        for layer in self.layers:
+            for lin in layer.linears():
+                n, kb = lin.weight.shape
+                lin.weight.copy_(torch.randint(0, 256, (n, kb), generator=g, device=self.device, dtype=torch.int16)
+                                 .to(torch.uint8).view(torch.int8))
+                lin.weight_scales.copy_((torch.randn(n, 1, generator=g, device=self.device).abs() * 0.01 + 1e-3)
+                                        .to(torch.float16))
+        self.embed_tokens.copy_((torch.randn(self.embed_tokens.shape, generator=g, device=self.device) * 0.02)
+                                .to(torch.float16))
+        self.lm_head.copy_((torch.randn(self.lm_head.shape, generator=g, device=self.device) * lm_head_std)
+                           .to(torch.float16))
+        return self
+
+    # prefill-sized M: dequantise the tile once and use the library GEMM (not the decode hot path)
+    BIG_M = 64
+
+    def _w4a16(self, x, lin, out):
+        if x.shape[0] <= self.BIG_M:
+            return ops.w4a16_linear(x, lin.weight, lin._scales(), out)
+        key = tuple(lin.weight.shape)
+        if not hasattr(self, "_dq"):
+            self._dq = {}
+        if key not in self._dq:
+            self._dq[key] = torch.empty(key[0], key[1] * 2, dtype=torch.float16, device=self.device)
+        wd = ops.dequant_w4(lin.weight, lin._scales(), self._dq[key])
+        return torch.matmul(x, wd.t(), out=out)
+
+    def weight_bytes(self):
+        n = sum(lin.weight.numel() + lin.weight_scales.numel() * 2 for l in self.layers for lin in l.linears())
+        return n + self.embed_tokens.numel() * 2 + self.lm_head.numel() * 2
+
+    # ------------------------------------------------------------------ fused product path
+    def forward(self, input_ids, positions, kv_caches, attn_metadata: AttentionMetadata, scratch: Scratch,
+                w4a4: bool = False, **kwargs):
+        """LlamaModel.forward (quarot_llama.py:484-535) + final norm; returns the normed hidden states [T,H]."""
+        cfg, s, md = self.config, scratch, attn_metadata
+        T = input_ids.numel()
+        eps = cfg.rms_norm_eps
+        hidden = s.hidden[:T]
+        ops.embedding(input_ids, self.embed_tokens, hidden)
+        delta = None
+        qkv, attn, o, gu = s.act_buffer_qkv[:T], s.act_buffer_attn[:T], s.act_buffer_output[:T], s.act_buffer_gate_up[:T]
+        q1, q3, sc = s.quantized_buffer_qkv[:T], s.quantized_buffer_mlp[:T], s.scale_buffer[:T]
+        normed, had, had_mlp = s.normed[:T], s.act_buffer_had[:T], s.act_buffer_had_mlp[:T]
+        row = cfg.q_size + 2 * cfg.kv_size
+        for li, layer in enumerate(self.layers):
+            kc, vc = kv_caches[li]
+            # input_layernorm (+ residual add of the previous MLP)            quarot_llama.py:373-374,390
+            if w4a4:
+                ops.add_rms_norm_i4(q1, sc, hidden, hidden, delta, eps)
+                ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, layer.qkv_proj.weight, layer.qkv_proj._scales(), None, qkv)
+            else:
+                ops.add_rms_norm_fp16(normed, hidden, hidden, delta, eps)
+                self._w4a16(normed, layer.qkv_proj, qkv)
+            # rope + kv write + attention                                     :207-226
+            ops.rope_kv_write(positions, qkv, self.cos_sin_cache, kc, vc, md.slot_mapping, cfg.num_attention_heads,
+                              cfg.num_key_value_heads, cfg.head_dim)
+            ops.paged_attention(qkv, row, kc, vc, md.block_tables, md.ctx_lens, md.q_start, T, md.max_q_len,
+                                cfg.num_attention_heads, self.sm_scale, md.n_splits, s.attn_ws, attn)
+            # heads hadamard (+ quant) + o_proj                               :231-243
+            if w4a4:
+                ops.heads_hadamard(attn, self.head_had_scale, q=q1, scale=sc, heads=cfg.num_attention_heads)
+                ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, layer.o_proj.weight, layer.o_proj._scales(), None, o)
+                ops.add_rms_norm_i4(q1, sc, hidden, hidden, o, eps)                        # :380,387
+                ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, layer.gate_up.weight, layer.gate_up._scales(), None, gu)
+                ops.silu_mul_hadamard(gu, self.had_rem_dim, self.had_K, self.mlp_had_scale, q=q3, scale=sc)   # :279-295
+                ops.rowwise_scaled_linear_cutlass_s4s4_unified(q3, sc, layer.down_proj.weight, layer.down_proj._scales(), None, o)
+            else:
+                ops.heads_hadamard(attn, self.head_had_scale, out_f16=had, heads=cfg.num_attention_heads)
+                self._w4a16(had, layer.o_proj, o)
+                ops.add_rms_norm_fp16(normed, hidden, hidden, o, eps)
+                self._w4a16(normed, layer.gate_up, gu)
+                ops.silu_mul_hadamard(gu, self.had_rem_dim, self.had_K, self.mlp_had_scale, out_f16=had_mlp)
+                self._w4a16(had_mlp, layer.down_proj, o)
+            delta = o
+        # final norm is always fp16, in both passes (self.norm(hidden_states) without kwargs, :533)
+        ops.add_rms_norm_fp16(normed, hidden, hidden, delta, eps)
+        return normed
+
+    def compute_logits(self, hidden_states, scratch: Scratch):
+        """LogitsProcessor with a plain nn.Linear lm_head (vllm/model_executor/layers/logits_processor.py:92-97)."""
+        T = hidden_states.shape[0]
+        logits = scratch.logits[:T]
+        ops.linear_f16(hidden_states, self.lm_head, logits)
+        return logits
+
+    # ------------------------------------------------------------------ module-wise path (reference op order)
+    def forward_modulewise(self, input_ids, positions, kv_caches, attn_metadata: AttentionMetadata, w4a4=False):
+        cfg, md = self.config, attn_metadata
+        kw = {"w4a4": w4a4}
+        T = input_ids.numel()
+        hidden = torch.empty(T, cfg.hidden_size, dtype=torch.float16, device=self.device)
+        ops.embedding(input_ids, self.embed_tokens, hidden)
+        head_had = quarot_nn.OnlineHadamard(cfg.num_attention_heads, device=self.device)
+        mlp_had = quarot_nn.OnlineHadamard(cfg.intermediate_size, device=self.device)
+        if self.had_rem_dim is not None:
+            mlp_had.had_rem_dim = self.had_rem_dim
+        ws = torch.empty(ops.paged_attention_workspace_bytes(md.q_start.numel() * md.max_q_len, cfg.num_attention_heads,
+                                                             cfg.head_dim, md.n_splits), dtype=torch.uint8, device=self.device)
+        for li, layer in enumerate(self.layers):
+            kc, vc = kv_caches[li]
+            residual = hidden
+            x = self.norm(hidden, **kw)
+            qkv = layer.qkv_proj(x, **kw)
+            q, k, v = qkv.split([cfg.q_size, cfg.kv_size, cfg.kv_size], dim=-1)
+            ops.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin_cache)
+            ops.reshape_and_cache_flash(k.view(T, cfg.num_key_value_heads, cfg.head_dim),
+                                        v.view(T, cfg.num_key_value_heads, cfg.head_dim), kc, vc, md.slot_mapping)
+            attn = torch.empty(T, cfg.q_size, dtype=torch.float16, device=self.device)
+            ops.paged_attention(qkv, qkv.shape[1], kc, vc, md.block_tables, md.ctx_lens, md.q_start, T, md.max_q_len,
+                                cfg.num_attention_heads, self.sm_scale, md.n_splits, ws, attn)
+            a = attn.view(-1, cfg.num_attention_heads, cfg.head_dim)
+            a = head_had(a.transpose(-1, -2).reshape(-1, cfg.num_attention_heads), **kw)          # :231
+            a = a.view(-1, cfg.head_dim, cfg.num_attention_heads).transpose(-1, -2).reshape(T, cfg.hidden_size).contiguous()
+            a = self.quantizer(a, **kw)
+            hidden = ops_add(residual, layer.o_proj(a, **kw))                                      # :380
+            residual = hidden
+            x = self.norm(hidden, **kw)
+            gu = layer.gate_up(x, **kw)
+            g = ops.silu_mul(gu, torch.empty(T, cfg.intermediate_size, dtype=torch.float16, device=self.device))  # :279-284
+            g = mlp_had(g, **kw).view(-1, cfg.intermediate_size)
+            g = self.quantizer(g, **kw)
+            hidden = ops_add(residual, layer.down_proj(g, **kw))                                   # :390
+        return self.norm(hidden)
+
+
+def ops_add(a, b):
+    return a + b  # fp16 tensor add: one rounding per element, as in the reference
+
+
+def make_cos_sin_cache(head_size: int, max_pos: int, base: float) -> torch.Tensor:
+    """RotaryEmbedding._compute_cos_sin_cache (vllm/model_executor/layers/rotary_embedding.py), cast to fp16
+    as quarot_llama.py:120 does; rope_scaling is ignored there and here."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_size, 2, dtype=torch.float32) / head_size))
+    t = torch.arange(max_pos, dtype=torch.float32)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(torch.float16)

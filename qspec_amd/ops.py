@@ -120,6 +120,13 @@ def heads_hadamard(attn, had_scale: float, out_f16=None, q=None, scale=None, cli
           _opt(scale, "scale", _F16), float(had_scale), float(clip_ratio), T, heads, d, _stream())
 
 
+def silu_mul(gate_up, out):
+    """`act_fn(gate) * up` over the fused gate_up row (quarot_llama.py:279-284)."""
+    T, two_i = gate_up.shape
+    _call("qspec_silu_mul", _chk(gate_up, "gate_up", _F16), _chk(out, "out", _F16), T, two_i // 2, _stream())
+    return out
+
+
 def silu_mul_hadamard(gate_up, hadK, K: int, had_scale: float, out_f16=None, q=None, scale=None,
                       clip_ratio: float = 1.0):
     """quarot_llama.py:279-295 in one kernel; gate_up [T, 2I] with up first."""
@@ -236,12 +243,19 @@ def softmax_argmax(logits, probs, token):
 
 
 def rejection_sample(target_with_bonus_probs, bonus_token_ids, draft_probs, draft_token_ids, out_tokens, accepted,
-                     recovered, counters=None, uniform=None, exponential=None, seed: int = 0, offset: int = 0):
+                     recovered, counters=None, uniform=None, exponential=None, seed: int = 0, offset: int = 0,
+                     rng_state=None):
     B, k, V = draft_probs.shape
+    # draft_probs / draft_token_ids / bonus_token_ids may be strided views (step-major draft buffers)
+    if draft_probs.stride(2) != 1 or draft_probs.dtype != _F32 or draft_token_ids.dtype != _I64 \
+            or bonus_token_ids.dtype != _I64 or not draft_probs.is_cuda:
+        raise RuntimeError("draft_probs must be fp32 with unit inner stride; ids int64; all on the GPU")
     _call("qspec_rejection_sample", _chk(target_with_bonus_probs, "target_with_bonus_probs", _F32),
-          _chk(bonus_token_ids, "bonus_token_ids", _I64), _chk(draft_probs, "draft_probs", _F32),
-          _chk(draft_token_ids, "draft_token_ids", _I64), _opt(uniform, "uniform", _F32),
-          _opt(exponential, "exponential", _F32), seed, offset, B, k, V, _chk(out_tokens, "out_tokens", _I64),
+          bonus_token_ids.data_ptr(), draft_probs.data_ptr(), draft_token_ids.data_ptr(),
+          _opt(uniform, "uniform", _F32), _opt(exponential, "exponential", _F32), seed, offset,
+          _opt(rng_state, "rng_state", _I64), B, k, V, draft_probs.stride(0), draft_probs.stride(1),
+          draft_token_ids.stride(0), draft_token_ids.stride(1),
+          bonus_token_ids.stride(0) if bonus_token_ids.numel() > 1 else 1, _chk(out_tokens, "out_tokens", _I64),
           _chk(accepted, "accepted", _U8), _chk(recovered, "recovered", _I64), _opt(counters, "counters", _I64),
           _stream())
 
@@ -255,3 +269,33 @@ def advance_step_flashattn(num_seqs, num_queries, block_size, input_tokens, samp
           _chk(sampled_token_ids, "sampled_token_ids", _I64), _chk(input_positions, "input_positions", _I64),
           _chk(seq_lens, "seq_lens", _I32), _chk(slot_mapping, "slot_mapping", _I64),
           _chk(block_tables, "block_tables", _I32), block_tables.stride(0), _stream())
+
+
+# ------------------------------------------------------------------ spec-decode cycle glue
+
+def spec_prepare_draft(last_token, seq_lens, block_tables, block_size, input_tokens, positions, slot_mapping,
+                       ctx_lens):
+    B = seq_lens.numel()
+    _call("qspec_spec_prepare_draft", B, block_size, _chk(last_token, "last_token", _I64),
+          _chk(seq_lens, "seq_lens", _I32), _chk(block_tables, "block_tables", _I32), block_tables.stride(0),
+          _chk(input_tokens, "input_tokens", _I64), _chk(positions, "positions", _I64),
+          _chk(slot_mapping, "slot_mapping", _I64), _chk(ctx_lens, "ctx_lens", _I32), _stream())
+
+
+def spec_prepare_verify(last_token, draft_token_ids, seq_lens, block_tables, block_size, tokens, positions,
+                        slot_mapping, ctx_lens):
+    B, k = draft_token_ids.shape
+    _call("qspec_spec_prepare_verify", B, k, block_size, _chk(last_token, "last_token", _I64),
+          draft_token_ids.data_ptr(), draft_token_ids.stride(0), draft_token_ids.stride(1),
+          _chk(seq_lens, "seq_lens", _I32),
+          _chk(block_tables, "block_tables", _I32), block_tables.stride(0), _chk(tokens, "tokens", _I64),
+          _chk(positions, "positions", _I64), _chk(slot_mapping, "slot_mapping", _I64),
+          _chk(ctx_lens, "ctx_lens", _I32), _stream())
+
+
+def spec_commit(out_tokens, seq_lens, last_token, gen_tokens=None, gen_lens=None):
+    B, k1 = out_tokens.shape
+    cap = gen_tokens.shape[1] if gen_tokens is not None else 0
+    _call("qspec_spec_commit", B, k1 - 1, _chk(out_tokens, "out_tokens", _I64), _chk(seq_lens, "seq_lens", _I32),
+          _chk(last_token, "last_token", _I64), _opt(gen_tokens, "gen_tokens", _I64),
+          _opt(gen_lens, "gen_lens", _I32), cap, _stream())
