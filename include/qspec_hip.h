@@ -90,6 +90,11 @@ int qspec_silu_mul_hadamard(const qspec_half* gate_up, const qspec_half* hadK, q
                             qspec_half* scale, float had_scale, float clip_ratio, int tokens, int intermediate, int K,
                             void* stream);
 
+/* The Hadamard + quantiser tail of qspec_silu_mul_hadamard on an input that is ALREADY silu(gate)*up
+ * (act [tokens, I], produced by qspec_gate_up_silu_linear_*). */
+int qspec_mlp_hadamard(const qspec_half* act, const qspec_half* hadK, qspec_half* out_f16, int8_t* q, qspec_half* scale,
+                       float had_scale, float clip_ratio, int tokens, int intermediate, int K, void* stream);
+
 /* ---- linear layers over the shared packed-int4 weight buffer --------------------------------- */
 
 /* torch.ops.torchao.rowwise_scaled_linear_cutlass_s4s4_unified(xq, x_scale, wq, w_scale, bias, out)
@@ -103,6 +108,28 @@ int qspec_rowwise_scaled_linear_s4s4(const int8_t* xq, const qspec_half* xs, con
  *   Takes the SAME wq buffer as the s4s4 op (no XOR copy).  x [M,K] fp16. */
 int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* ws, const qspec_half* bias,
                        qspec_half* out, int M, int N, int K, void* stream);
+
+/* qkv_proj fused with what follows it in QuarotLlamaAttention.forward (quarot_llama.py:183-226): the GEMM
+ * (s4s4: linear.py:82 / w4a16: linear.py:122) -> ops.rotary_embedding on q,k (csrc/pos_encoding_kernels.cu:71-122)
+ * -> reshape_and_cache_flash of k,v (csrc/cache_kernels.cu:207-303).  wq rows are [q; k; v] (fuse_qkv,
+ * quarot_llama.py:152-173).  qkv [M, (num_heads + 2 num_kv_heads) * 128] receives rotated q,k and v;
+ * head_size = rot_dim = 128 only.  Bit-identical to running the three ops one after the other. */
+int qspec_qkv_rope_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
+                               qspec_half* qkv, int M, int N, int K, const int64_t* positions,
+                               const qspec_half* cos_sin_cache, qspec_half* key_cache, qspec_half* value_cache,
+                               const int64_t* slot_mapping, int num_heads, int num_kv_heads, int head_size,
+                               int rot_dim, void* stream);
+int qspec_qkv_rope_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M,
+                                int N, int K, const int64_t* positions, const qspec_half* cos_sin_cache,
+                                qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
+                                int num_heads, int num_kv_heads, int head_size, int rot_dim, void* stream);
+
+/* gate_up GEMM fused with `act_fn(gate) * up` (quarot_llama.py:276-284): wq rows are [up; gate] (fuse_gate_up,
+ * :301-314), act [M, I] = h(h(silu(gate)) * up).  Bit-identical to GEMM followed by qspec_silu_mul. */
+int qspec_gate_up_silu_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
+                                   qspec_half* act, int M, int intermediate, int K, void* stream);
+int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
+                                    int intermediate, int K, void* stream);
 
 /* lm_head: F.linear(hidden, lm_head.weight)  (vllm/model_executor/layers/logits_processor.py:92-97). w [N,K] fp16. */
 int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, int M, int N, int K, void* stream);
@@ -133,7 +160,8 @@ int qspec_rope_kv_write(const int64_t* positions, qspec_half* qkv, const qspec_h
 /* flash_attn_with_kvcache (draft, q_len 1) / flash_attn_varlen_func (verify, q_len k+1, causal) over the paged
  * cache  (vllm/attention/backends/flash_attn.py:741-830).  q rows of sequence s are tokens q_start[s]..q_start[s+1]-1
  * and sit at absolute positions ctx_lens[s]-q_len .. ctx_lens[s]-1.  head_size must be 128.
- * workspace: qspec_paged_attention_workspace_bytes(n_seqs*max_q_len, ...) bytes. */
+ * workspace: qspec_paged_attention_workspace_bytes(n_seqs*max_q_len, ...) bytes, ZERO-FILLED once before its
+ * first use (it starts with the split-merge ticket counters, which every call leaves at zero again). */
 size_t qspec_paged_attention_workspace_bytes(int max_tokens, int num_heads, int head_size, int n_splits);
 int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_half* key_cache,
                           const qspec_half* value_cache, const int32_t* block_tables, int max_blocks_per_seq,

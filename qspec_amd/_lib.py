@@ -31,6 +31,11 @@ SIGNATURES = {
     "qspec_heads_hadamard": (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
     "qspec_silu_mul": (_i, [_vp, _vp, _i, _i, _vp]),
     "qspec_silu_mul_hadamard": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
+    "qspec_mlp_hadamard": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
+    "qspec_qkv_rope_linear_s4s4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "qspec_qkv_rope_linear_w4a16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "qspec_gate_up_silu_linear_s4s4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "qspec_gate_up_silu_linear_w4a16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_rowwise_scaled_linear_s4s4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_w4a16_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_linear_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

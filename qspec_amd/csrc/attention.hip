@@ -130,170 +130,326 @@ int rope_kv_write(const int64_t* positions, f16* qkv, const f16* cos_sin_cache, 
 }
 
 // ---------------------------------------------------------------- attention
-// Split-context ("flash-decoding") paged attention.
-//   grid (n_seqs, n_kv_heads, n_splits); each workgroup takes the keys
-//   [split*chunk, (split+1)*chunk) of one sequence and one kv head, and all
-//   R = q_len * group query rows that share that kv head (R <= 16 for
-//   k+1 = 4 tokens x GQA group 4).  16 lanes cover one key row (16 B each),
-//   so a wave reads 4 whole 256-byte key rows per trip.
-//   Pass 1: scores -> LDS; pass 2: max/exp/sum; pass 3: P.V; partial
-//   (o, m, l) per split in fp32, merged by attn_combine_kernel.
-// d = 128 only (16 lanes x 8 dims).
+// Split-context ("flash-decoding") paged attention, one launch, both products on the matrix cores.
+//   grid (n_seqs, n_kv_heads * n_rb, n_splits), 256 threads = 4 waves.  A workgroup takes the keys
+//   [split*128, split*128+128) of one sequence and one kv head, and up to 16 query rows (row = query token x
+//   GQA head of that kv head: 4 rows for the draft pass, 16 for verify k=3; longer queries use n_rb row blocks).
+//
+//   At these sizes a wave's INSTRUCTION COUNT is the cost (one wave per SIMD issues ~1 instruction / 4 cycles),
+//   so the kernel is shaped to need few of them:
+//     * S = Q K^T: Q and K are both d-contiguous, so MFMA fragments are plain 16-byte global loads
+//       (wave w owns key tiles 2w, 2w+1); 8 v_mfma_f32_16x16x32_f16 per wave.
+//     * softmax: S (fp32) sits in LDS as [row][key]; 16 lanes share a row, reduce with 4 shuffles, P goes back
+//       as fp16 [row][key] = exactly the A fragment layout of the second product.
+//     * O = P V: V rows are staged once in LDS ([key][d], 288-byte row stride) and read back TRANSPOSED with
+//       ds_read_b64_tr_b16, so B fragments cost 2 LDS reads instead of 8 gathers; wave w owns output columns
+//       32w..32w+31 (no cross-wave reduction); 8 MFMAs per wave.
+//     * block_size and the GQA group are powers of two: no integer division anywhere.
+//   Every global load of the workgroup is issued before the first use (one dependent chain:
+//   block table -> K/V).  The partial (o, m, l) of a split goes to the workspace; the LAST workgroup to
+//   arrive for a (sequence, kv head, row block) merges the splits in split order (deterministic) and writes
+//   fp16 -- agent-scope release / acquire around a relaxed ticket counter (reset for the next call).
+// d = 128 only.
 #define QS_ATT_MAXR 16
 #define QS_ATT_CHUNK 128
+#define QS_ATT_CNT_SLOTS 4096  // ints reserved at the head of the workspace for the ticket counters
+#define QS_ATT_VSTRIDE 144     // halves per V row in LDS (288 B): 4 rows x 4 column quads hit 16 distinct bank pairs
+#define QS_ATT_MAXSPLIT 64
+
+__device__ __forceinline__ u32x2 lds_read_tr_b16(uint32_t lds_byte_addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_byte_addr) : "memory");
+    return r;
+}
 
 __global__ __launch_bounds__(256) void paged_attention_kernel(
     const f16* __restrict__ q, int64_t q_stride, const f16* __restrict__ key_cache, const f16* __restrict__ value_cache,
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
-    const int32_t* __restrict__ q_start, int nq, int nkv, int block_size, float sm_scale, int n_splits,
-    int n_rb, float* __restrict__ ws_o, float* __restrict__ ws_ml) {
+    const int32_t* __restrict__ q_start, int nq, int nkv, int bs_log2, int group_log2, float sm_scale, int n_splits,
+    int n_rb, int* cnt, float* ws_o, float* ws_ml, f16* __restrict__ out) {
     constexpr int D = 128;
-    __shared__ __attribute__((aligned(16))) float q_lds[QS_ATT_MAXR][D];
-    __shared__ float sc[QS_ATT_MAXR][QS_ATT_CHUNK];
-    __shared__ float row_m[QS_ATT_MAXR], row_l[QS_ATT_MAXR];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sc = reinterpret_cast<float*>(smem_raw);                          // [16 rows][128 keys] fp32 scores
+    f16* pl = reinterpret_cast<f16*>(sc + QS_ATT_MAXR * QS_ATT_CHUNK);       // [16 rows][128 keys] fp16 probabilities
+    f16* pl2 = pl + QS_ATT_MAXR * QS_ATT_CHUNK;                              // low half of the fp32 probability (p - fp16(p))
+    f16* vl = pl2 + QS_ATT_MAXR * QS_ATT_CHUNK;                              // [128 keys][QS_ATT_VSTRIDE]
+    float* row_m = reinterpret_cast<float*>(vl + QS_ATT_CHUNK * QS_ATT_VSTRIDE);  // [16]
+    float* row_l = row_m + QS_ATT_MAXR;                                      // [16]
+    float* wgt = row_l + QS_ATT_MAXR;                                        // [16][QS_ATT_MAXSPLIT] merge weights
+    int* flag = reinterpret_cast<int*>(wgt + QS_ATT_MAXR * QS_ATT_MAXSPLIT); // [1]
     const int seq = blockIdx.x, kvh = blockIdx.y / n_rb, rb = blockIdx.y % n_rb, split = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int group = nq / nkv;
-    const int qs = q_start[seq], qlen = q_start[seq + 1] - qs;
-    const int r0 = rb * QS_ATT_MAXR;                       // first query row of this row-block
-    const int R = min(QS_ATT_MAXR, qlen * group - r0);     // rows handled here
-    if (R <= 0) return;                                     // uniform for the whole workgroup
-    const int ctx = ctx_lens[seq];
+    const int gmask = (1 << group_log2) - 1, bmask = (1 << bs_log2) - 1;
+    // per-sequence metadata through the VECTOR memory path: a uniform address would become an s_load, and a scalar
+    // cache miss on data the previous kernel has just written costs microseconds, not hundreds of cycles
+    int meta = 0;
+    if (lane < 3) meta = lane < 2 ? q_start[seq + lane] : ctx_lens[seq];
+    const int qs = __shfl(meta, 0, 64), qlen = __shfl(meta, 1, 64) - qs;
+    const int ctx = __shfl(meta, 2, 64);
+    const int r0 = rb * QS_ATT_MAXR;
+    const int R = min(QS_ATT_MAXR, (qlen << group_log2) - r0);
+    if (R <= 0) return;  // uniform for the whole workgroup
     const int k_begin = split * QS_ATT_CHUNK;
-    const int k_end = min(ctx, k_begin + QS_ATT_CHUNK);
-    const int nkeys = max(0, k_end - k_begin);
-    // row r <-> (token i = (r0+r) / group, head = kvh*group + (r0+r) % group)
-    for (int i = tid; i < R * D; i += 256) {
-        int r = i / D, e = i % D;
-        int tok = qs + (r0 + r) / group, head = kvh * group + (r0 + r) % group;
-        q_lds[r][e] = h2f(q[(size_t)tok * q_stride + (size_t)head * D + e]);
-    }
-    __syncthreads();
-    const int sub = lane >> 4, dl = lane & 15;  // 4 keys per wave trip, 8 dims per lane
+    const int nkeys = max(0, min(ctx, k_begin + QS_ATT_CHUNK) - k_begin);
+    const int c16 = lane & 15, g4 = lane >> 4;
     const int32_t* bt = block_tables + (size_t)seq * max_blocks;
-    // pass 1: scores
-    for (int kk = wave * 4 + sub; kk < nkeys; kk += 16) {
-        int p = k_begin + kk;
-        int64_t slot = (int64_t)bt[p / block_size] * block_size + p % block_size;
-        f16x8 kv = *reinterpret_cast<const f16x8*>(key_cache + (slot * nkv + kvh) * D + dl * 8);
-        float kf[8];
+#ifdef QS_ATT_STAMPS
+    long long stamp[10];
+#define QS_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i])::"memory")
+#else
+#define QS_STAMP(i)
+#endif
+    QS_STAMP(0);
+
+    // ---- every global load up front, in two waves of requests: vmcnt retires in order, so a block-table read
+    // placed between data loads would make its dependent address wait for ALL earlier data loads.
+    // (1) all block-table entries (index clamped, so they do not wait for ctx_lens)
+    int64_t ksl[2], vsl[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) kf[e] = h2f(kv[e]);
-        for (int r = 0; r < R; r++) {
-            float acc = 0.0f;
+    for (int t2 = 0; t2 < 2; t2++) {
+        const int p = k_begin + (wave * 2 + t2) * 16 + c16;
+        ksl[t2] = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
+    }
 #pragma unroll
-            for (int e = 0; e < 8; e++) acc = __builtin_fmaf(q_lds[r][dl * 8 + e], kf[e], acc);
+    for (int i = 0; i < 8; i++) {
+        const int p = k_begin + wave * 4 + g4 + 16 * i;
+        vsl[i] = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
+    }
+    // (2) Q fragments (independent of the table), then K fragments and V rows
+    u32x4 kfrag[2][4], qfrag[4], vraw[8];
+    {  // lane (row c16, d slice 8*g4 + 32j); rows >= R are zero
+        const int r = r0 + (c16 < R ? c16 : 0);
+        const int tok = qs + (r >> group_log2), head = (kvh << group_log2) + (r & gmask);
+        const f16* qp = q + (size_t)tok * q_stride + (size_t)head * D + g4 * 8;
 #pragma unroll
-            for (int m = 8; m > 0; m >>= 1) acc += shfl_xor_f(acc, m);
-            if (dl == 0) {
-                int pos = ctx - qlen + (r0 + r) / group;  // absolute position of this query token
-                sc[r][kk] = p <= pos ? acc * sm_scale : -__builtin_inff();
-            }
+        for (int j = 0; j < 4; j++) {
+            qfrag[j] = u32x4{0, 0, 0, 0};
+            if (c16 < R) qfrag[j] = *reinterpret_cast<const u32x4*>(qp + 32 * j);
         }
     }
+#pragma unroll
+    for (int t2 = 0; t2 < 2; t2++) {  // lane (key c16 of tile 2w+t2, d slice 8*g4 + 32j)
+        const int kk = (wave * 2 + t2) * 16 + c16;
+        const f16* kp = key_cache + (ksl[t2] * nkv + kvh) * D + g4 * 8;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            kfrag[t2][j] = u32x4{0, 0, 0, 0};
+            if (kk < nkeys) kfrag[t2][j] = *reinterpret_cast<const u32x4*>(kp + 32 * j);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {  // 16 lanes cover one 256-byte V row; wave w, group g4 -> keys 4w+g4 + 16i
+        const int kk = wave * 4 + g4 + 16 * i;
+        vraw[i] = u32x4{0, 0, 0, 0};
+        if (kk < nkeys) vraw[i] = *reinterpret_cast<const u32x4*>(value_cache + (vsl[i] * nkv + kvh) * D + c16 * 8);
+    }
+
+    QS_STAMP(1);
+    // ---- S = Q K^T (fp32 accumulate) -> sc[row][key], masked and scaled
+#pragma unroll
+    for (int t2 = 0; t2 < 2; t2++) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, qfrag[j]),
+                                                         __builtin_bit_cast(f16x8, kfrag[t2][j]), acc, 0, 0, 0);
+        const int kk = (wave * 2 + t2) * 16 + c16;  // lane holds rows 4*g4 + reg of key column kk
+        const int p = k_begin + kk;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int r = 4 * g4 + reg;
+            const int pos = ctx - qlen + ((r0 + r) >> group_log2);  // absolute position of this query token
+            sc[r * QS_ATT_CHUNK + kk] = (kk < nkeys && p <= pos) ? acc[reg] * sm_scale : -__builtin_inff();
+        }
+    }
+    // V rows -> LDS (zeros beyond nkeys keep the MFMA clean)
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        *reinterpret_cast<u32x4*>(vl + (wave * 4 + g4 + 16 * i) * QS_ATT_VSTRIDE + c16 * 8) = vraw[i];
     __syncthreads();
-    // pass 2: per-row max / exp / sum (one wave per rows r = wave, wave+4, ...)
-    for (int r = wave; r < R; r += 4) {
-        float mx = -__builtin_inff();
-        for (int kk = lane; kk < nkeys; kk += 64) mx = fmaxf(mx, sc[r][kk]);
-        mx = wave_max_f(mx);
+
+    QS_STAMP(2);
+    // ---- softmax over the 128 keys of a row: thread (row = tid>>4, 8 keys = tid&15)
+    {
+        const int r = tid >> 4, ks = tid & 15;
+        const float4 a = *reinterpret_cast<const float4*>(sc + r * QS_ATT_CHUNK + ks * 8);
+        const float4 b = *reinterpret_cast<const float4*>(sc + r * QS_ATT_CHUNK + ks * 8 + 4);
+        float s8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float mx = s8[0];
+#pragma unroll
+        for (int i = 1; i < 8; i++) mx = fmaxf(mx, s8[i]);
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) mx = fmaxf(mx, shfl_xor_f(mx, m));
         float sum = 0.0f;
-        for (int kk = lane; kk < nkeys; kk += 64) {
-            float pv = mx == -__builtin_inff() ? 0.0f : qexpf(sc[r][kk] - mx);
-            sc[r][kk] = pv;
+        f16x8 p8, p8lo;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float pv = mx == -__builtin_inff() ? 0.0f : qexpf(s8[i] - mx);
+            // the matrix core takes fp16 operands: carry the fp32 probability as hi + lo so that P.V keeps
+            // fp32-class accuracy (22 bits) for two MFMAs instead of one
+            const f16 ph = f2h(pv);
+            p8[i] = ph;
+            p8lo[i] = f2h(pv - h2f(ph));
             sum += pv;
         }
 #pragma unroll
-        for (int m = 32; m > 0; m >>= 1) sum += shfl_xor_f(sum, m);
-        if (lane == 0) {
+        for (int m = 8; m > 0; m >>= 1) sum += shfl_xor_f(sum, m);
+        *reinterpret_cast<f16x8*>(pl + r * QS_ATT_CHUNK + ks * 8) = p8;
+        *reinterpret_cast<f16x8*>(pl2 + r * QS_ATT_CHUNK + ks * 8) = p8lo;
+        if (ks == 0) {
             row_m[r] = mx;
             row_l[r] = sum;
         }
     }
     __syncthreads();
-    // pass 3: o[r][:] = sum_kk p[r][kk] * v[kk][:]; each 16-lane group owns keys kk = g16, g16+16, ...
-    float oacc[QS_ATT_MAXR][8];
+
+    QS_STAMP(3);
+    // ---- O = P V: wave w owns d columns 32w..32w+31 (two 16-wide tiles), k over the 128 keys in 4 steps of 32
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    {
+        const uint32_t vl_base = (uint32_t)(uintptr_t)vl;  // LDS byte address (low 32 bits of the shared pointer)
+        const int qd = c16 >> 2, pq = c16 & 3;              // lane 4q+p of its 16-lane group
 #pragma unroll
-    for (int r = 0; r < QS_ATT_MAXR; r++)
+        for (int st = 0; st < 4; st++) {
+            const f16x8 pa = *reinterpret_cast<const f16x8*>(pl + c16 * QS_ATT_CHUNK + st * 32 + g4 * 8);
+            const f16x8 pb = *reinterpret_cast<const f16x8*>(pl2 + c16 * QS_ATT_CHUNK + st * 32 + g4 * 8);
+            // B fragment of lane (col c16, group g4) = V[key st*32 + 8*g4 + j][d0 + c16], j = 0..7
+            const int krow = st * 32 + g4 * 8 + qd;
 #pragma unroll
-        for (int e = 0; e < 8; e++) oacc[r][e] = 0.0f;
-    for (int kk = wave * 4 + sub; kk < nkeys; kk += 16) {
-        int p = k_begin + kk;
-        int64_t slot = (int64_t)bt[p / block_size] * block_size + p % block_size;
-        f16x8 vv = *reinterpret_cast<const f16x8*>(value_cache + (slot * nkv + kvh) * D + dl * 8);
-        float vf[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) vf[e] = h2f(vv[e]);
-#pragma unroll
-        for (int r = 0; r < QS_ATT_MAXR; r++) {
-            if (r < R) {
-                float pv = sc[r][kk];
-#pragma unroll
-                for (int e = 0; e < 8; e++) oacc[r][e] = __builtin_fmaf(pv, vf[e], oacc[r][e]);
+            for (int dt = 0; dt < 2; dt++) {
+                const int d0 = wave * 32 + dt * 16;
+                const uint32_t a0 = vl_base + (uint32_t)((krow * QS_ATT_VSTRIDE + d0 + 4 * pq) * 2);
+                const u32x2 lo = lds_read_tr_b16(a0);
+                const u32x2 hi = lds_read_tr_b16(a0 + 4 * QS_ATT_VSTRIDE * 2);
+                const u32x4 bw = {lo[0], lo[1], hi[0], hi[1]};
+                if (dt == 0) {
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o0, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o0, 0, 0, 0);
+                } else {
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o1, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o1, 0, 0, 0);
+                }
             }
         }
     }
-    // reduce the 16 key-groups (4 per wave x 4 waves): lanes with equal dl across sub via shuffles, waves via LDS
-    __syncthreads();  // sc no longer needed; reuse q_lds as the cross-wave buffer [wave][r][D]... needs 4*16*128 floats
-    float* xw = &q_lds[0][0];  // 16*128 floats = one wave's worth; accumulate wave by wave
+    QS_STAMP(4);
+    // ---- partial of this split -> workspace: ws_o [T, nq, n_splits, D], ws_ml [T, nq, n_splits, 2]
+    // lane holds rows 4*g4 + reg, columns wave*32 + {0,16} + c16
 #pragma unroll
-    for (int r = 0; r < QS_ATT_MAXR; r++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            float v = oacc[r][e];
-            v += shfl_xor_f(v, 16);
-            v += shfl_xor_f(v, 32);
-            oacc[r][e] = v;
+    for (int reg = 0; reg < 4; reg++) {
+        const int r = 4 * g4 + reg;
+        if (r < R) {
+            const int rr = r0 + r;
+            const int tok = qs + (rr >> group_log2), head = (kvh << group_log2) + (rr & gmask);
+            float* dst = ws_o + (((size_t)tok * nq + head) * n_splits + split) * D + wave * 32 + c16;
+            dst[0] = o0[reg];
+            dst[16] = o1[reg];
         }
-    for (int w = 0; w < 4; w++) {
-        if (wave == w && sub == 0) {
+    }
+    if (tid < R) {
+        const int rr = r0 + tid;
+        const int tok = qs + (rr >> group_log2), head = (kvh << group_log2) + (rr & gmask);
+        const size_t o = (((size_t)tok * nq + head) * n_splits + split) * 2;
+        ws_ml[o] = row_m[tid];
+        ws_ml[o + 1] = row_l[tid];
+    }
+    QS_STAMP(5);
+    // ---- hand-off: every storing wave drains, one lane releases and takes a ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* my_cnt = cnt + (seq * nkv + kvh) * n_rb + rb;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(my_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = ticket == n_splits - 1;
+    }
+    __syncthreads();
+    QS_STAMP(6);
+    if (!*flag) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(my_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+    }
+    __syncthreads();
+    QS_STAMP(7);
+    // ---- merge: out = sum_s w_s o_s / sum_s w_s l_s, w_s = e^(m_s - M), splits in order.
+    // Thread i owns 4 output columns of one row; its o loads (up to 8 splits at a time) go out first, the
+    // per-row weights are computed meanwhile by 16 threads and passed through LDS.
+    const int NV = R * (D / 4);
+    for (int i0 = 0; i0 < NV; i0 += 256) {
+        const int i = i0 + tid;
+        const bool act = i < NV;
+        const int r = act ? i / (D / 4) : 0, e4 = act ? (i % (D / 4)) * 4 : 0;
+        const int rr = r0 + r;
+        const size_t th = (size_t)(qs + (rr >> group_log2)) * nq + (kvh << group_log2) + (rr & gmask);
+        float4 o8[8];
 #pragma unroll
-            for (int r = 0; r < QS_ATT_MAXR; r++)
-                if (r < R)
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        float prev = w == 0 ? 0.0f : xw[r * D + dl * 8 + e];
-                        xw[r * D + dl * 8 + e] = prev + oacc[r][e];
-                    }
+        for (int s2 = 0; s2 < 8; s2++) {
+            o8[s2] = float4{0.f, 0.f, 0.f, 0.f};
+            if (act && s2 < n_splits) o8[s2] = *reinterpret_cast<const float4*>(ws_o + (th * n_splits + s2) * D + e4);
         }
-        __syncthreads();
+        if (i0 == 0) {
+            if (tid < R) {
+                const int r2 = r0 + tid;
+                const size_t t2 = (size_t)(qs + (r2 >> group_log2)) * nq + (kvh << group_log2) + (r2 & gmask);
+                float M = -__builtin_inff();
+                for (int s2 = 0; s2 < n_splits; s2++) M = fmaxf(M, ws_ml[(t2 * n_splits + s2) * 2]);
+                float den = 0.0f;
+                for (int s2 = 0; s2 < n_splits; s2++) {
+                    const float m = ws_ml[(t2 * n_splits + s2) * 2];
+                    const float w = m == -__builtin_inff() ? 0.0f : qexpf(m - M);
+                    wgt[tid * QS_ATT_MAXSPLIT + s2] = w;
+                    den = __builtin_fmaf(w, ws_ml[(t2 * n_splits + s2) * 2 + 1], den);
+                }
+                row_l[tid] = den;
+            }
+            __syncthreads();
+        }
+        if (act) {
+            float4 num = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 8; s2++) {
+                if (s2 < n_splits) {
+                    const float w = wgt[r * QS_ATT_MAXSPLIT + s2];
+                    num.x = __builtin_fmaf(w, o8[s2].x, num.x);
+                    num.y = __builtin_fmaf(w, o8[s2].y, num.y);
+                    num.z = __builtin_fmaf(w, o8[s2].z, num.z);
+                    num.w = __builtin_fmaf(w, o8[s2].w, num.w);
+                }
+            }
+            for (int s2 = 8; s2 < n_splits; s2++) {
+                const float w = wgt[r * QS_ATT_MAXSPLIT + s2];
+                const float4 o4 = *reinterpret_cast<const float4*>(ws_o + (th * n_splits + s2) * D + e4);
+                num.x = __builtin_fmaf(w, o4.x, num.x);
+                num.y = __builtin_fmaf(w, o4.y, num.y);
+                num.z = __builtin_fmaf(w, o4.z, num.z);
+                num.w = __builtin_fmaf(w, o4.w, num.w);
+            }
+            const float den = row_l[r];
+            f16x4 o = {f2h(num.x / den), f2h(num.y / den), f2h(num.z / den), f2h(num.w / den)};
+            *reinterpret_cast<f16x4*>(out + th * D + e4) = o;
+        }
     }
-    // write partials: ws_o [T, nq, n_splits, D], ws_ml [T, nq, n_splits, 2]
-    for (int i = tid; i < R * D; i += 256) {
-        int r = i / D, e = i % D;
-        int tok = qs + (r0 + r) / group, head = kvh * group + (r0 + r) % group;
-        ws_o[(((size_t)tok * nq + head) * n_splits + split) * D + e] = xw[i];
+#ifdef QS_ATT_STAMPS
+    QS_STAMP(8);
+    if (tid == 0 && seq == 0 && kvh == 0 && rb == 0) {
+        long long* sb = reinterpret_cast<long long*>(cnt + 2048);
+        for (int i = 0; i < 9; i++) sb[i] = stamp[i];
     }
-    for (int r = tid; r < R; r += 256) {
-        int tok = qs + (r0 + r) / group, head = kvh * group + (r0 + r) % group;
-        size_t o = (((size_t)tok * nq + head) * n_splits + split) * 2;
-        ws_ml[o] = row_m[r];
-        ws_ml[o + 1] = row_l[r];
-    }
-}
-
-// out[t, h, :] = sum_s e^(m_s - M) o_s / sum_s e^(m_s - M) l_s
-__global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ ws_o,
-                                                           const float* __restrict__ ws_ml, f16* __restrict__ out,
-                                                           int n_splits) {
-    constexpr int D = 128;
-    const size_t th = blockIdx.x;  // token * nq + head
-    const int e = threadIdx.x;
-    float M = -__builtin_inff();
-    for (int s = 0; s < n_splits; s++) M = fmaxf(M, ws_ml[(th * n_splits + s) * 2]);
-    float num = 0.0f, den = 0.0f;
-    for (int s = 0; s < n_splits; s++) {
-        float m = ws_ml[(th * n_splits + s) * 2], l = ws_ml[(th * n_splits + s) * 2 + 1];
-        if (m == -__builtin_inff()) continue;
-        float w = qexpf(m - M);
-        num = __builtin_fmaf(w, ws_o[(th * n_splits + s) * D + e], num);
-        den = __builtin_fmaf(w, l, den);
-    }
-    out[th * D + e] = f2h(num / den);
+#endif
 }
 
 size_t paged_attention_ws_bytes(int T, int nq, int d, int n_splits) {
-    return (size_t)T * nq * n_splits * (d + 2) * sizeof(float);
+    return QS_ATT_CNT_SLOTS * sizeof(int) + (size_t)T * nq * n_splits * (d + 2) * sizeof(float);
+}
+
+static int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) l++;
+    return l;
 }
 
 int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const f16* value_cache,
@@ -302,24 +458,22 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
                     float* ws, f16* out, hipStream_t st) {
     if (n_seqs == 0) return 0;
     if (d != 128 || nq % nkv) return -1;
-    if (n_splits < 1) return -3;
-    const int n_rb = (max_q_len * (nq / nkv) + QS_ATT_MAXR - 1) / QS_ATT_MAXR;
-    // T is not known here; the host sizes ws with paged_attention_ws_bytes(T,...) and lays it out as [o | ml]
-    // with o first: the split between them is passed through max tokens = n_seqs * max_q_len.
+    if (n_splits < 1 || n_splits > QS_ATT_MAXSPLIT) return -3;
+    const int bs_log2 = ilog2_exact(block_size), group_log2 = ilog2_exact(nq / nkv);
+    if (bs_log2 < 0 || group_log2 < 0) return -5;  // block size and GQA group must be powers of two
+    const int n_rb = ((max_q_len << group_log2) + QS_ATT_MAXR - 1) / QS_ATT_MAXR;
+    if ((size_t)n_seqs * nkv * n_rb > QS_ATT_CNT_SLOTS) return -4;
+    // workspace: [ticket counters | o partials | (m,l) partials]; sized by the host for n_seqs*max_q_len tokens.
+    // It must be zero-filled once before its first use; every call leaves the counters zero again.
     const size_t Tmax = (size_t)n_seqs * max_q_len;
-    float* ws_o = ws;
-    float* ws_ml = ws + Tmax * nq * n_splits * d;
-    hipLaunchKernelGGL(paged_attention_kernel, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), 0, st, q, q_stride,
-                       key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv, block_size,
-                       sm_scale, n_splits, n_rb, ws_o, ws_ml);
-    return 0;
-}
-
-int paged_attention_combine(const float* ws, int T, int Tmax, int nq, int d, int n_splits, f16* out, hipStream_t st) {
-    if (T == 0) return 0;
-    const float* ws_o = ws;
-    const float* ws_ml = ws + (size_t)Tmax * nq * n_splits * d;
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(T * nq), dim3(d), 0, st, ws_o, ws_ml, out, n_splits);
+    int* cnt = reinterpret_cast<int*>(ws);
+    float* ws_o = ws + QS_ATT_CNT_SLOTS;
+    float* ws_ml = ws_o + Tmax * nq * n_splits * d;
+    const size_t lds = QS_ATT_MAXR * QS_ATT_CHUNK * 4 + 2 * QS_ATT_MAXR * QS_ATT_CHUNK * 2 +
+                       QS_ATT_CHUNK * QS_ATT_VSTRIDE * 2 + (2 * QS_ATT_MAXR + QS_ATT_MAXR * QS_ATT_MAXSPLIT + 4) * 4;
+    hipLaunchKernelGGL(paged_attention_kernel, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), lds, st, q, q_stride,
+                       key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv, bs_log2,
+                       group_log2, sm_scale, n_splits, n_rb, cnt, ws_o, ws_ml, out);
     return 0;
 }
 

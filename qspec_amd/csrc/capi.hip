@@ -125,7 +125,7 @@ int qspec_silu_mul_hadamard(const qspec_half* gate_up, const qspec_half* hadK, q
     if (K > 1) NONNULL(op, hadK);
     if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
     if (intermediate % 8) return fail("%s: intermediate %% 8 != 0", op);
-    return finish(op, qspec::silu_mul_hadamard(CH(gate_up), CH(hadK), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, intermediate, K, ST));
+    return finish(op, qspec::silu_mul_hadamard(CH(gate_up), CH(hadK), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, intermediate, K, 0, ST));
 }
 int qspec_rowwise_scaled_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
                                      const qspec_half* bias, qspec_half* out, int M, int N, int K, void* stream) {
@@ -198,8 +198,7 @@ int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_hal
     if (head_size != 128) return fail("%s: head_size=%d (only 128 is built)", op, head_size);
     if (tokens > n_seqs * max_q_len) return fail("%s: tokens=%d > n_seqs*max_q_len=%d", op, tokens, n_seqs * max_q_len);
     int rc = qspec::paged_attention(CH(q), q_stride, CH(key_cache), CH(value_cache), block_tables, max_blocks_per_seq, ctx_lens, q_start, n_seqs, max_q_len, num_heads, num_kv_heads, head_size, block_size, sm_scale, n_splits, (float*)workspace, H(out), ST);
-    if (rc) return finish(op, rc);
-    return finish(op, qspec::paged_attention_combine((const float*)workspace, tokens, n_seqs * max_q_len, num_heads, head_size, n_splits, H(out), ST));
+    return finish(op, rc);
 }
 int qspec_embedding(const int64_t* ids, const qspec_half* table, qspec_half* out, int tokens, int hidden, int vocab,
                     void* stream) {
@@ -266,6 +265,55 @@ int qspec_spec_commit(int batch, int k, const int64_t* out_tokens, int32_t* seq_
     NONNULL(op, out_tokens); NONNULL(op, seq_lens); NONNULL(op, last_token);
     if (gen_tokens) NONNULL(op, gen_lens);
     return finish(op, qspec::spec_commit(batch, k, out_tokens, seq_lens, last_token, gen_tokens, gen_lens, gen_capacity, ST));
+}
+
+int qspec_mlp_hadamard(const qspec_half* act, const qspec_half* hadK, qspec_half* out_f16, int8_t* q, qspec_half* scale,
+                       float had_scale, float clip_ratio, int tokens, int intermediate, int K, void* stream) {
+    const char* op = "qspec_mlp_hadamard";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, act);
+    if (K > 1) NONNULL(op, hadK);
+    if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
+    if (intermediate % 8) return fail("%s: intermediate %% 8 != 0", op);
+    return finish(op, qspec::silu_mul_hadamard(CH(act), CH(hadK), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, intermediate, K, 1, ST));
+}
+int qspec_qkv_rope_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
+                               qspec_half* qkv, int M, int N, int K, const int64_t* positions,
+                               const qspec_half* cos_sin_cache, qspec_half* key_cache, qspec_half* value_cache,
+                               const int64_t* slot_mapping, int num_heads, int num_kv_heads, int head_size,
+                               int rot_dim, void* stream) {
+    const char* op = "qspec_qkv_rope_linear_s4s4";
+    if (M == 0) return 0;
+    NONNULL(op, xq); NONNULL(op, xs); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, qkv); NONNULL(op, positions);
+    NONNULL(op, cos_sin_cache); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
+    if (head_size != 128 || rot_dim != 128) return fail("%s: head_size and rot_dim must be 128", op);
+    return finish(op, qspec::gemm_w4a4_qkv_rope(xq, CH(xs), wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST));
+}
+int qspec_qkv_rope_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M,
+                                int N, int K, const int64_t* positions, const qspec_half* cos_sin_cache,
+                                qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
+                                int num_heads, int num_kv_heads, int head_size, int rot_dim, void* stream) {
+    const char* op = "qspec_qkv_rope_linear_w4a16";
+    if (M == 0) return 0;
+    NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, qkv); NONNULL(op, positions);
+    NONNULL(op, cos_sin_cache); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
+    if (head_size != 128 || rot_dim != 128) return fail("%s: head_size and rot_dim must be 128", op);
+    return finish(op, qspec::gemm_w4a16_qkv_rope(CH(x), wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST));
+}
+int qspec_gate_up_silu_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
+                                   qspec_half* act, int M, int intermediate, int K, void* stream) {
+    const char* op = "qspec_gate_up_silu_linear_s4s4";
+    if (M == 0) return 0;
+    NONNULL(op, xq); NONNULL(op, xs); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
+    return finish(op, qspec::gemm_w4a4_gate_up_silu(xq, CH(xs), wq, CH(ws), H(act), M, intermediate, K, ST));
+}
+int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
+                                    int intermediate, int K, void* stream) {
+    const char* op = "qspec_gate_up_silu_linear_w4a16";
+    if (M == 0) return 0;
+    NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
+    return finish(op, qspec::gemm_w4a16_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, ST));
 }
 
 }  // extern "C"

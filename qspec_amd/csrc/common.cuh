@@ -33,11 +33,11 @@ __device__ __forceinline__ uint16_t h2u(f16 h) { return __builtin_bit_cast(uint1
 // Deterministic expf -- bit-identical to oracle/qspec_oracle.c:qexpf (only
 // v_fma_f32 / v_rndne_f32 / v_ldexp_f32, all exactly specified).
 __device__ __forceinline__ float qexpf(float x) {
-    if (x != x) return x;
-    if (x > 88.0f) return __builtin_inff();
-    if (x < -86.0f) return 0.0f;
-    float n = __builtin_rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    // branch-free: the polynomial runs on a clamped argument and the special cases are selected afterwards
+    // (same results as the early-return form of the oracle for every input, NaN included)
+    const float xc = fminf(fmaxf(x, -86.0f), 88.0f);
+    float n = __builtin_rintf(xc * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693145751953125f, xc);
     r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
     float p = 1.9875691500e-4f;
     p = __builtin_fmaf(p, r, 1.3981999507e-3f);
@@ -47,7 +47,10 @@ __device__ __forceinline__ float qexpf(float x) {
     p = __builtin_fmaf(p, r, 5.0000001201e-1f);
     float z = r * r;
     float y = __builtin_fmaf(p, z, r) + 1.0f;
-    return __builtin_ldexpf(y, (int)n);
+    float e = __builtin_ldexpf(y, (int)n);
+    e = x > 88.0f ? __builtin_inff() : e;
+    e = x < -86.0f ? 0.0f : e;
+    return x != x ? x : e;
 }
 
 // round-to-nearest-even to integer with saturation, NaN -> 0

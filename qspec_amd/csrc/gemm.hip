@@ -42,20 +42,93 @@ __device__ __forceinline__ i32x4 widen_s4x16(u32 p0, u32 p1) {
                  (int)(p1 & 0xF0F0F0F0u)};
 }
 
+// ------------------------------------------------------------------ fused epilogues
+// The 16 weight rows of a workgroup need not be contiguous.  Choosing them as 8 rows + the 8 rows that pair with
+// them lets the GEMM finish what the reference does in separate kernels right after it:
+//   EPI_QKV    rows = channels {8j..8j+7} and {64+8j..} of one head: NeoX RoPE pairs (i, i+64) meet in one
+//              workgroup -> rotate q,k (csrc/pos_encoding_kernels.cu:10-35) and scatter k,v into the paged
+//              cache (csrc/cache_kernels.cu:207-247) from the epilogue; the rope + cache-write kernel disappears.
+//   EPI_GATEUP rows = 8 `up` channels and their 8 `gate` channels of the fused gate_up weight:
+//              out[m, c] = h(h(silu(gate)) * up)   (quarot_llama.py:279-284), half the output bytes.
+// Rounding points are unchanged: the GEMM result is rounded to fp16 exactly where the reference's op returns
+// fp16, and only then rotated / activated.
+enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_GATEUP = 2 };
+
+struct EpiArgs {
+    const int64_t* positions;   // [M]
+    const f16* cos_sin_cache;   // [max_pos, 128]
+    f16* key_cache;             // [slots, nkv, 128]
+    f16* value_cache;
+    const int64_t* slot_mapping;  // [M]
+    int nq, nkv;
+    int I;                      // intermediate size (EPI_GATEUP)
+};
+
+template <int EPI>
+__device__ __forceinline__ int tile_row(int tb, int r, const EpiArgs& ea) {
+    if (EPI == EPI_QKV) return (tb >> 3) * 128 + (r >> 3) * 64 + (tb & 7) * 8 + (r & 7);
+    if (EPI == EPI_GATEUP) return (r >> 3) * ea.I + tb * 8 + (r & 7);
+    return tb * 16 + r;
+}
+
+// hv = the fp16 GEMM result of element (m, tile column c); ex = 256 halves of LDS per m-tile for the pair exchange.
+template <int EPI>
+__device__ __forceinline__ void epilogue_store(f16 hv, bool valid, int m, int c, int tb, int N, f16* __restrict__ out,
+                                               f16* ex, int ex_idx, const EpiArgs& ea) {
+    if (EPI == EPI_PLAIN) {
+        if (valid) out[(size_t)m * N + tb * 16 + c] = hv;
+        return;
+    }
+    ex[ex_idx] = hv;
+    __syncthreads();
+    const f16 partner = ex[ex_idx ^ 8];
+    __syncthreads();
+    if (!valid) return;
+    if (EPI == EPI_GATEUP) {
+        if (c < 8) {  // hv = up, partner = gate
+            const float g = h2f(partner);
+            const float a = h2f(f2h(g / (1.0f + qexpf(-g))));
+            out[(size_t)m * ea.I + tb * 8 + c] = f2h(a * h2f(hv));
+        }
+        return;
+    }
+    // EPI_QKV
+    const int head = tb >> 3, o = (tb & 7) * 8 + (c & 7);  // o = index inside the first half of the head
+    const int n = head * 128 + (c >> 3) * 64 + o;
+    f16 res = hv;
+    if (head < ea.nq + ea.nkv) {
+        const f16* cs = ea.cos_sin_cache + ea.positions[m] * 128;
+        const float cf = h2f(cs[o]), sf = h2f(cs[64 + o]);
+        const float xf = h2f(c < 8 ? hv : partner), yf = h2f(c < 8 ? partner : hv);
+        res = c < 8 ? f2h(h2f(f2h(xf * cf)) - h2f(f2h(yf * sf))) : f2h(h2f(f2h(yf * cf)) + h2f(f2h(xf * sf)));
+    }
+    out[(size_t)m * N + n] = res;
+    if (head >= ea.nq) {
+        const int64_t slot = ea.slot_mapping[m];
+        if (slot >= 0) {
+            const bool is_k = head < ea.nq + ea.nkv;
+            const int kvh = is_k ? head - ea.nq : head - ea.nq - ea.nkv;
+            f16* cache = is_k ? ea.key_cache : ea.value_cache;
+            cache[(slot * ea.nkv + kvh) * 128 + (c >> 3) * 64 + o] = res;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ W4A4
 // out[m,n] = h( (f(acc[m,n]) * f(sa[m])) * f(sw[n]) (+ f(bias[n])) ),  acc = sum_k a[m,k] w[n,k]  (int32, exact)
-template <int MT>
+template <int MT, int EPI>
 __global__ __launch_bounds__(256) void gemm_w4a4_kernel(const int8_t* __restrict__ xq, const f16* __restrict__ xs,
                                                          const int8_t* __restrict__ wq, const f16* __restrict__ ws,
                                                          const f16* __restrict__ bias, f16* __restrict__ out, int M,
-                                                         int N, int K, int m_base) {
+                                                         int N, int K, int m_base, EpiArgs ea) {
     __shared__ int red[4][MT][256];
+    __shared__ f16 ex[MT][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int tb = blockIdx.x;
     const int Kb = K >> 1;
     const int nsteps = Kb >> 6;  // 64 bytes of every row per step
-    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)(n0 + r) * Kb + g * 16;
+    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)tile_row<EPI>(tb, r, ea) * Kb + g * 16;
     const uint8_t* arow[MT];
     bool aval[MT];
 #pragma unroll
@@ -111,35 +184,69 @@ __global__ __launch_bounds__(256) void gemm_w4a4_kernel(const int8_t* __restrict
     __syncthreads();
     // thread t owns accumulator element (reg = t>>6, lane = t&63): row = 4*(lane>>4)+reg, col = lane&15
     const int t = threadIdx.x, el = t & 63, reg = t >> 6;
-    const int n = n0 + (el & 15);
+    const int c = el & 15;
+    const int n = tile_row<EPI>(tb, c, ea);
     const float swn = h2f(ws[n]);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
-        int m = m_base + mt * 16 + 4 * (el >> 4) + reg;
-        if (m < M) {
+        const int row16 = 4 * (el >> 4) + reg;
+        const int m = m_base + mt * 16 + row16;
+        const bool valid = m < M;
+        f16 hv = (f16)0.0f;
+        if (valid) {
             int sum = red[0][mt][t] + red[1][mt][t] + red[2][mt][t] + red[3][mt][t];
             float v = ((float)(sum >> 8) * h2f(xs[m])) * swn;  // both operands carried a factor 16
             if (bias) v = v + h2f(bias[n]);
-            out[(size_t)m * N + n] = f2h(v);
+            hv = f2h(v);
         }
+        epilogue_store<EPI>(hv, valid, m, c, tb, N, out, &ex[mt][0], row16 * 16 + c, ea);
     }
+}
+
+template <int EPI>
+static int launch_w4a4(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, const f16* bias, f16* out,
+                       int M, int N, int K, const EpiArgs& ea, hipStream_t st) {
+    // up to 64 rows per pass over the weights; larger M re-streams W (prefill-sized M is not this kernel's job)
+    for (int mb = 0; mb < M; mb += 64) {
+        int rows = M - mb;
+        if (rows <= 16)
+            hipLaunchKernelGGL((gemm_w4a4_kernel<1, EPI>), dim3(N / 16), dim3(256), 0, st, xq, xs, wq, ws, bias, out, M, N, K, mb, ea);
+        else if (rows <= 32)
+            hipLaunchKernelGGL((gemm_w4a4_kernel<2, EPI>), dim3(N / 16), dim3(256), 0, st, xq, xs, wq, ws, bias, out, M, N, K, mb, ea);
+        else
+            hipLaunchKernelGGL((gemm_w4a4_kernel<4, EPI>), dim3(N / 16), dim3(256), 0, st, xq, xs, wq, ws, bias, out, M, N, K, mb, ea);
+    }
+    return 0;
 }
 
 int gemm_w4a4(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M,
               int N, int K, hipStream_t st) {
     if (M == 0 || N == 0) return 0;
     if (N % 16 || K % 128 || K > (1 << 19)) return -1;
-    // up to 64 rows per pass over the weights; larger M re-streams W (prefill-sized M is not this kernel's job)
-    for (int mb = 0; mb < M; mb += 64) {
-        int rows = M - mb;
-        if (rows <= 16)
-            hipLaunchKernelGGL((gemm_w4a4_kernel<1>), dim3(N / 16), dim3(256), 0, st, xq, xs, wq, ws, bias, out, M, N, K, mb);
-        else if (rows <= 32)
-            hipLaunchKernelGGL((gemm_w4a4_kernel<2>), dim3(N / 16), dim3(256), 0, st, xq, xs, wq, ws, bias, out, M, N, K, mb);
-        else
-            hipLaunchKernelGGL((gemm_w4a4_kernel<4>), dim3(N / 16), dim3(256), 0, st, xq, xs, wq, ws, bias, out, M, N, K, mb);
-    }
+    return launch_w4a4<EPI_PLAIN>(xq, xs, wq, ws, bias, out, M, N, K, EpiArgs{}, st);
+}
+
+static int check_qkv(int N, int K, int nq, int nkv, int d, int rot_dim) {
+    if (d != 128 || rot_dim != 128 || N != (nq + 2 * nkv) * 128 || K % 128) return -1;
     return 0;
+}
+
+int gemm_w4a4_qkv_rope(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
+                       const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
+                       const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st) {
+    if (M == 0) return 0;
+    if (check_qkv(N, K, nq, nkv, d, rot_dim)) return -1;
+    EpiArgs ea{positions, cos_sin_cache, key_cache, value_cache, slot_mapping, nq, nkv, 0};
+    return launch_w4a4<EPI_QKV>(xq, xs, wq, ws, nullptr, qkv, M, N, K, ea, st);
+}
+
+int gemm_w4a4_gate_up_silu(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, f16* act, int M, int I,
+                           int K, hipStream_t st) {
+    if (M == 0) return 0;
+    if (I % 8 || K % 128) return -1;
+    EpiArgs ea{};
+    ea.I = I;
+    return launch_w4a4<EPI_GATEUP>(xq, xs, wq, ws, nullptr, act, M, 2 * I, K, ea, st);
 }
 
 // ------------------------------------------------------------------ W4A16
@@ -176,17 +283,19 @@ __device__ __forceinline__ f16x8 shuffle_act8(u32x4 a) {
 }
 
 // out[m,n] = h( (sum_k f(x[m,k]) * w[n,k]) * f(sw[n]) (+ f(bias[n])) ), fp32 accumulate
-template <int MT>
+template <int MT, int EPI>
 __global__ __launch_bounds__(256) void gemm_w4a16_kernel(const f16* __restrict__ x, const int8_t* __restrict__ wq,
                                                           const f16* __restrict__ ws, const f16* __restrict__ bias,
-                                                          f16* __restrict__ out, int M, int N, int K, int m_base) {
+                                                          f16* __restrict__ out, int M, int N, int K, int m_base,
+                                                          EpiArgs ea) {
     __shared__ float red[4][MT][256];
+    __shared__ f16 ex[MT][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int tb = blockIdx.x;
     const int Kb = K >> 1;
     const int nsteps = Kb >> 6;
-    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)(n0 + r) * Kb + g * 16;
+    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)tile_row<EPI>(tb, r, ea) * Kb + g * 16;
     const f16* arow[MT];
     bool aval[MT];
 #pragma unroll
@@ -223,32 +332,61 @@ __global__ __launch_bounds__(256) void gemm_w4a16_kernel(const f16* __restrict__
         for (int i = 0; i < 4; i++) red[wave][mt][i * 64 + lane] = acc[mt][i];
     __syncthreads();
     const int t = threadIdx.x, el = t & 63, reg = t >> 6;
-    const int n = n0 + (el & 15);
+    const int c = el & 15;
+    const int n = tile_row<EPI>(tb, c, ea);
     const float swn = h2f(ws[n]);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
-        int m = m_base + mt * 16 + 4 * (el >> 4) + reg;
-        if (m < M) {
+        const int row16 = 4 * (el >> 4) + reg;
+        const int m = m_base + mt * 16 + row16;
+        const bool valid = m < M;
+        f16 hv = (f16)0.0f;
+        if (valid) {
             float sum = ((red[0][mt][t] + red[1][mt][t]) + red[2][mt][t]) + red[3][mt][t];
             float v = sum * swn;
             if (bias) v = v + h2f(bias[n]);
-            out[(size_t)m * N + n] = f2h(v);
+            hv = f2h(v);
         }
+        epilogue_store<EPI>(hv, valid, m, c, tb, N, out, &ex[mt][0], row16 * 16 + c, ea);
     }
+}
+
+template <int EPI>
+static int launch_w4a16(const f16* x, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M, int N, int K,
+                        const EpiArgs& ea, hipStream_t st) {
+    for (int mb = 0; mb < M; mb += 32) {
+        int rows = M - mb;
+        if (rows <= 16)
+            hipLaunchKernelGGL((gemm_w4a16_kernel<1, EPI>), dim3(N / 16), dim3(256), 0, st, x, wq, ws, bias, out, M, N, K, mb, ea);
+        else
+            hipLaunchKernelGGL((gemm_w4a16_kernel<2, EPI>), dim3(N / 16), dim3(256), 0, st, x, wq, ws, bias, out, M, N, K, mb, ea);
+    }
+    return 0;
 }
 
 int gemm_w4a16(const f16* x, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M, int N, int K,
                hipStream_t st) {
     if (M == 0 || N == 0) return 0;
     if (N % 16 || K % 128) return -1;
-    for (int mb = 0; mb < M; mb += 32) {
-        int rows = M - mb;
-        if (rows <= 16)
-            hipLaunchKernelGGL((gemm_w4a16_kernel<1>), dim3(N / 16), dim3(256), 0, st, x, wq, ws, bias, out, M, N, K, mb);
-        else
-            hipLaunchKernelGGL((gemm_w4a16_kernel<2>), dim3(N / 16), dim3(256), 0, st, x, wq, ws, bias, out, M, N, K, mb);
-    }
-    return 0;
+    return launch_w4a16<EPI_PLAIN>(x, wq, ws, bias, out, M, N, K, EpiArgs{}, st);
+}
+
+int gemm_w4a16_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
+                        const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
+                        const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st) {
+    if (M == 0) return 0;
+    if (check_qkv(N, K, nq, nkv, d, rot_dim)) return -1;
+    EpiArgs ea{positions, cos_sin_cache, key_cache, value_cache, slot_mapping, nq, nkv, 0};
+    return launch_w4a16<EPI_QKV>(x, wq, ws, nullptr, qkv, M, N, K, ea, st);
+}
+
+int gemm_w4a16_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K,
+                            hipStream_t st) {
+    if (M == 0) return 0;
+    if (I % 8 || K % 128) return -1;
+    EpiArgs ea{};
+    ea.I = I;
+    return launch_w4a16<EPI_GATEUP>(x, wq, ws, nullptr, act, M, 2 * I, K, ea, st);
 }
 
 // ------------------------------------------------------------------ fp16 x fp16^T (lm_head)

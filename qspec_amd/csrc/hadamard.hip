@@ -191,30 +191,48 @@ int silu_mul(const f16* gate_up, f16* out, int T, int I, hipStream_t st) {
 //   z[i,j]  = h( sum_k hadK[i,k] y[k,j] )            (K == 1: z = y)
 //   draft: row-absmax int4 of z (index i*P + j); verify: fp16 z.
 // One 256-thread workgroup per token.  LDS: y fp16 [K][P], z fp16 [K][P], hadK fp32 [K][K].
-template <int EPL>  // elements per lane in the FWHT phase = P / 64
-__global__ __launch_bounds__(256) void silu_mul_hadamard_kernel(const f16* __restrict__ gate_up,
-                                                                const f16* __restrict__ hadK,
-                                                                f16* __restrict__ out16, int8_t* __restrict__ q,
-                                                                f16* __restrict__ scale, float had_scale, float clip,
-                                                                int I, int K) {
+#define QS_SMH_THREADS 1024
+template <int EPL, int KH>  // EPL = elements per lane in the FWHT phase = P / 64; KH = K if specialised, else 0
+__global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const f16* __restrict__ gate_up,
+                                                                            const f16* __restrict__ hadK,
+                                                                            f16* __restrict__ out16,
+                                                                            int8_t* __restrict__ q,
+                                                                            f16* __restrict__ scale, float had_scale,
+                                                                            float clip, int I, int K,
+                                                                            int pre_activated) {
     constexpr int P = EPL * 64;
+    constexpr int NT = QS_SMH_THREADS, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // all LDS in the one dynamic region so every carve stays 16-byte aligned
-    float* red = reinterpret_cast<float*>(smem_raw);
+    float* red = reinterpret_cast<float*>(smem_raw);  // [16]
     f16* ylds = reinterpret_cast<f16*>(smem_raw + 64);
     f16* zlds = ylds + (size_t)K * P;
     float* had = reinterpret_cast<float*>(zlds + (K > 1 ? (size_t)K * P : 0));
     const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const f16* up = gate_up + (size_t)t * 2 * I;
+    // pre_activated: the input is already g = silu(gate)*up, [T, I] (fused into the gate_up GEMM epilogue)
+    const f16* up = gate_up + (size_t)t * (pre_activated ? I : 2 * I);
     const f16* gate = up + I;
     if (K > 1)
-        for (int i = tid; i < K * K; i += 256) had[i] = h2f(hadK[i]);
+        for (int i = tid; i < K * K; i += NT) had[i] = h2f(hadK[i]);
 
-    // phase A: one chunk of P elements per wave trip
-    for (int c = wave; c < K; c += 4) {
+    // phase A: one chunk of P elements per wave trip (a token's 14336 elements keep 16 waves = 4 per SIMD busy:
+    // this kernel is VALU bound -- correctly rounded fp32 divisions in SiLU and in the quantiser)
+    for (int c = wave; c < K; c += NW) {
         float v[EPL];
         const int e0 = c * P + lane * EPL;
-        if (EPL >= 8) {
+        if (pre_activated) {
+            if (EPL >= 8) {
+#pragma unroll
+                for (int b = 0; b < EPL / 8; b++) {
+                    f16x8 u8 = *reinterpret_cast<const f16x8*>(up + e0 + 8 * b);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[8 * b + i] = h2f(u8[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < EPL; i++) v[i] = h2f(up[e0 + i]);
+            }
+        } else if (EPL >= 8) {
 #pragma unroll
             for (int b = 0; b < EPL / 8; b++) {
                 f16x8 g8 = *reinterpret_cast<const f16x8*>(gate + e0 + 8 * b);
@@ -258,21 +276,56 @@ __global__ __launch_bounds__(256) void silu_mul_hadamard_kernel(const f16* __res
     }
     __syncthreads();
 
-    // phase B: hadK mix, two adjacent columns per trip
+    // phase B: hadK mix.  KH > 0: a thread owns a column pair and KH/IQ output rows; the column pair lives in
+    // registers and the k loop is fully unrolled with 16-byte broadcast reads of hadK (a naive loop is LDS
+    // latency bound: 2*K*K dependent ds_reads per lane).  KH == 0: generic K.
     const f16* zsrc = ylds;
     if (K > 1) {
         zsrc = zlds;
-        for (int j2 = tid; j2 < P / 2; j2 += 256) {
-            for (int i = 0; i < K; i++) {
-                float a0 = 0.0f, a1 = 0.0f;
-                for (int k = 0; k < K; k++) {
-                    float h = had[i * K + k];
+        if constexpr (KH > 0) {
+            constexpr int IQ = (NT / (P / 2)) >= 4 ? 4 : ((NT / (P / 2)) >= 2 ? 2 : 1);
+            static_assert(KH % IQ == 0 && KH % 4 == 0, "row split");
+            constexpr int ROWS = KH / IQ;
+            const int j2 = tid % (P / 2), iq = tid / (P / 2);
+            if (iq < IQ) {
+                float y0[KH], y1[KH];
+#pragma unroll
+                for (int k = 0; k < KH; k++) {
                     f16x2 yy = *reinterpret_cast<const f16x2*>(ylds + (size_t)k * P + 2 * j2);
-                    a0 = __builtin_fmaf(h, h2f(yy[0]), a0);
-                    a1 = __builtin_fmaf(h, h2f(yy[1]), a1);
+                    y0[k] = h2f(yy[0]);
+                    y1[k] = h2f(yy[1]);
                 }
-                f16x2 zz = {f2h(a0), f2h(a1)};
-                *reinterpret_cast<f16x2*>(zlds + (size_t)i * P + 2 * j2) = zz;
+                for (int i = iq * ROWS; i < (iq + 1) * ROWS; i++) {
+                    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                    for (int kq = 0; kq < KH / 4; kq++) {
+                        const float4 h = *reinterpret_cast<const float4*>(had + i * KH + 4 * kq);
+                        a0 = __builtin_fmaf(h.x, y0[4 * kq + 0], a0);
+                        a1 = __builtin_fmaf(h.x, y1[4 * kq + 0], a1);
+                        a0 = __builtin_fmaf(h.y, y0[4 * kq + 1], a0);
+                        a1 = __builtin_fmaf(h.y, y1[4 * kq + 1], a1);
+                        a0 = __builtin_fmaf(h.z, y0[4 * kq + 2], a0);
+                        a1 = __builtin_fmaf(h.z, y1[4 * kq + 2], a1);
+                        a0 = __builtin_fmaf(h.w, y0[4 * kq + 3], a0);
+                        a1 = __builtin_fmaf(h.w, y1[4 * kq + 3], a1);
+                    }
+                    f16x2 zz = {f2h(a0), f2h(a1)};
+                    *reinterpret_cast<f16x2*>(zlds + (size_t)i * P + 2 * j2) = zz;
+                }
+            }
+        } else {
+            for (int j2 = tid; j2 < P / 2; j2 += NT) {
+                for (int i = 0; i < K; i++) {
+                    float a0 = 0.0f, a1 = 0.0f;
+                    for (int k = 0; k < K; k++) {
+                        float h = had[i * K + k];
+                        f16x2 yy = *reinterpret_cast<const f16x2*>(ylds + (size_t)k * P + 2 * j2);
+                        a0 = __builtin_fmaf(h, h2f(yy[0]), a0);
+                        a1 = __builtin_fmaf(h, h2f(yy[1]), a1);
+                    }
+                    f16x2 zz = {f2h(a0), f2h(a1)};
+                    *reinterpret_cast<f16x2*>(zlds + (size_t)i * P + 2 * j2) = zz;
+                }
             }
         }
         __syncthreads();
@@ -281,12 +334,12 @@ __global__ __launch_bounds__(256) void silu_mul_hadamard_kernel(const f16* __res
     // phase C: fp16 out, or abs-max + int4
     const int nvec = I / 8;
     if (q == nullptr) {
-        for (int i = tid; i < nvec; i += 256)
+        for (int i = tid; i < nvec; i += NT)
             *reinterpret_cast<f16x8*>(out16 + (size_t)t * I + 8 * i) = *reinterpret_cast<const f16x8*>(zsrc + 8 * i);
         return;
     }
     float amax = 0.0f;
-    for (int i = tid; i < nvec; i += 256) {
+    for (int i = tid; i < nvec; i += NT) {
         f16x8 a = *reinterpret_cast<const f16x8*>(zsrc + 8 * i);
 #pragma unroll
         for (int c = 0; c < 8; c++) {
@@ -297,11 +350,13 @@ __global__ __launch_bounds__(256) void silu_mul_hadamard_kernel(const f16* __res
     amax = wave_max_f(amax);
     if (lane == 0) red[wave] = amax;
     __syncthreads();
-    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    amax = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) amax = fmaxf(amax, red[w]);
     const f16 sc = f2h(h2f(f2h(amax / 7.0f)) * h2f(f2h(clip)));
     const float scf = h2f(sc);
     if (tid == 0) scale[t] = sc;
-    for (int i = tid; i < nvec; i += 256) {
+    for (int i = tid; i < nvec; i += NT) {
         f16x8 a = *reinterpret_cast<const f16x8*>(zsrc + 8 * i);
         uint32_t w = 0;
 #pragma unroll
@@ -314,24 +369,32 @@ __global__ __launch_bounds__(256) void silu_mul_hadamard_kernel(const f16* __res
 }
 
 int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,
-                      float clip, int T, int I, int K, hipStream_t st) {
+                      float clip, int T, int I, int K, int pre_activated, hipStream_t st) {
     if (T == 0) return 0;
     if (K < 1 || K > 172 || I % K) return -1;
     const int P = I / K;
     if (P & (P - 1)) return -1;
     size_t lds = 64 + (size_t)I * 2 * (K > 1 ? 2 : 1) + (K > 1 ? (size_t)K * K * 4 : 0);
     if (lds > 160 * 1024 - 64) return -2;
+#define QS_SMH2(EPLV, KHV)                                                                                      \
+    {                                                                                                            \
+        if (lds > 64 * 1024)                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&silu_mul_hadamard_kernel<EPLV, KHV>),       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+        hipLaunchKernelGGL((silu_mul_hadamard_kernel<EPLV, KHV>), dim3(T), dim3(QS_SMH_THREADS), lds, st, gate_up, hadK, \
+                           out_f16, q, scale, had_scale, clip, I, K, pre_activated);                             \
+        return 0;                                                                                                \
+    }
 #define QS_SMH(EPLV)                                                                                            \
     if (P == EPLV * 64) {                                                                                        \
-        if (lds > 64 * 1024)                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&silu_mul_hadamard_kernel<EPLV>),            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-        hipLaunchKernelGGL((silu_mul_hadamard_kernel<EPLV>), dim3(T), dim3(256), lds, st, gate_up, hadK, out_f16, \
-                           q, scale, had_scale, clip, I, K);                                                     \
-        return 0;                                                                                                \
+        if (K == 28) QS_SMH2(EPLV, 28)                                                                           \
+        if (K == 44) QS_SMH2(EPLV, 44)                                                                           \
+        if (K == 12) QS_SMH2(EPLV, 12)                                                                           \
+        QS_SMH2(EPLV, 0)                                                                                         \
     }
     QS_SMH(2) QS_SMH(4) QS_SMH(8) QS_SMH(16) QS_SMH(32)
 #undef QS_SMH
+#undef QS_SMH2
     return -1;
 }
 

@@ -21,13 +21,23 @@ int heads_hadamard(const f16* attn, f16* out_f16, int8_t* q, f16* scale, float h
                    int heads, int d, hipStream_t st);
 int silu_mul(const f16* gate_up, f16* out, int T, int I, hipStream_t st);
 int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,
-                      float clip, int T, int I, int K, hipStream_t st);
+                      float clip, int T, int I, int K, int pre_activated, hipStream_t st);
 
 // gemm.hip
 int gemm_w4a4(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M,
               int N, int K, hipStream_t st);
 int gemm_w4a16(const f16* x, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M, int N, int K,
                hipStream_t st);
+int gemm_w4a4_qkv_rope(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
+                       const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
+                       const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st);
+int gemm_w4a16_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
+                        const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
+                        const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st);
+int gemm_w4a4_gate_up_silu(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, f16* act, int M, int I,
+                           int K, hipStream_t st);
+int gemm_w4a16_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K,
+                            hipStream_t st);
 int gemm_f16(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st);
 int dequant_w4(const int8_t* wq, const f16* ws, f16* out, int N, int K, hipStream_t st);
 
@@ -43,7 +53,6 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
                     const int32_t* block_tables, int max_blocks, const int32_t* ctx_lens, const int32_t* q_start,
                     int n_seqs, int max_q_len, int nq, int nkv, int d, int block_size, float sm_scale, int n_splits,
                     float* ws, f16* out, hipStream_t st);
-int paged_attention_combine(const float* ws, int T, int Tmax, int nq, int d, int n_splits, f16* out, hipStream_t st);
 size_t paged_attention_ws_bytes(int T, int nq, int d, int n_splits);
 
 // sampler.hip

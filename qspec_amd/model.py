@@ -99,7 +99,7 @@ class Scratch:
         self.act_buffer_had_mlp = e(T, I)
         self.logits = e(T if logits_rows is None else logits_rows, cfg.vocab_size)
         ws = ops.paged_attention_workspace_bytes(n_seqs * max_q_len, cfg.num_attention_heads, cfg.head_dim, n_splits)
-        self.attn_ws = torch.empty(ws, dtype=torch.uint8, device=device)
+        self.attn_ws = torch.zeros(ws, dtype=torch.uint8, device=device)   # ticket counters start at zero
 
 
 class DecoderLayerWeights:
@@ -182,35 +182,62 @@ class QuarotLlamaForCausalLM:
         q1, q3, sc = s.quantized_buffer_qkv[:T], s.quantized_buffer_mlp[:T], s.scale_buffer[:T]
         normed, had, had_mlp = s.normed[:T], s.act_buffer_had[:T], s.act_buffer_had_mlp[:T]
         row = cfg.q_size + 2 * cfg.kv_size
+        fuse = cfg.head_dim == 128 and (w4a4 or T <= self.BIG_M)   # fused GEMM epilogues (decode-sized M)
+        act = s.act_buffer_had_mlp[:T]                            # silu(gate)*up, [T, I]
+        nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         for li, layer in enumerate(self.layers):
             kc, vc = kv_caches[li]
-            # input_layernorm (+ residual add of the previous MLP)            quarot_llama.py:373-374,390
+            qkv_w, qkv_s = layer.qkv_proj.weight, layer.qkv_proj._scales()
+            gu_w, gu_s = layer.gate_up.weight, layer.gate_up._scales()
+            # input_layernorm (+ residual add of the previous MLP) -> qkv_proj -> rope -> kv write    :373-374,183-226
             if w4a4:
                 ops.add_rms_norm_i4(q1, sc, hidden, hidden, delta, eps)
-                ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, layer.qkv_proj.weight, layer.qkv_proj._scales(), None, qkv)
+                x, xs = q1, sc
             else:
                 ops.add_rms_norm_fp16(normed, hidden, hidden, delta, eps)
-                self._w4a16(normed, layer.qkv_proj, qkv)
-            # rope + kv write + attention                                     :207-226
-            ops.rope_kv_write(positions, qkv, self.cos_sin_cache, kc, vc, md.slot_mapping, cfg.num_attention_heads,
-                              cfg.num_key_value_heads, cfg.head_dim)
-            ops.paged_attention(qkv, row, kc, vc, md.block_tables, md.ctx_lens, md.q_start, T, md.max_q_len,
-                                cfg.num_attention_heads, self.sm_scale, md.n_splits, s.attn_ws, attn)
-            # heads hadamard (+ quant) + o_proj                               :231-243
-            if w4a4:
-                ops.heads_hadamard(attn, self.head_had_scale, q=q1, scale=sc, heads=cfg.num_attention_heads)
-                ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, layer.o_proj.weight, layer.o_proj._scales(), None, o)
-                ops.add_rms_norm_i4(q1, sc, hidden, hidden, o, eps)                        # :380,387
-                ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, layer.gate_up.weight, layer.gate_up._scales(), None, gu)
-                ops.silu_mul_hadamard(gu, self.had_rem_dim, self.had_K, self.mlp_had_scale, q=q3, scale=sc)   # :279-295
-                ops.rowwise_scaled_linear_cutlass_s4s4_unified(q3, sc, layer.down_proj.weight, layer.down_proj._scales(), None, o)
+                x, xs = normed, None
+            if fuse:
+                ops.qkv_rope_linear(x, xs, qkv_w, qkv_s, qkv, positions, self.cos_sin_cache, kc, vc, md.slot_mapping,
+                                    nh, nkv, hd)
             else:
-                ops.heads_hadamard(attn, self.head_had_scale, out_f16=had, heads=cfg.num_attention_heads)
+                if w4a4:
+                    ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, qkv_w, qkv_s, None, qkv)
+                else:
+                    self._w4a16(normed, layer.qkv_proj, qkv)
+                ops.rope_kv_write(positions, qkv, self.cos_sin_cache, kc, vc, md.slot_mapping, nh, nkv, hd)
+            ops.paged_attention(qkv, row, kc, vc, md.block_tables, md.ctx_lens, md.q_start, T, md.max_q_len, nh,
+                                self.sm_scale, md.n_splits, s.attn_ws, attn)
+            # heads hadamard (+ quant) -> o_proj -> residual + post_attention_layernorm                 :231-243,380-387
+            if w4a4:
+                ops.heads_hadamard(attn, self.head_had_scale, q=q1, scale=sc, heads=nh)
+                ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, layer.o_proj.weight, layer.o_proj._scales(), None, o)
+                ops.add_rms_norm_i4(q1, sc, hidden, hidden, o, eps)
+                x, xs = q1, sc
+            else:
+                ops.heads_hadamard(attn, self.head_had_scale, out_f16=had, heads=nh)
                 self._w4a16(had, layer.o_proj, o)
                 ops.add_rms_norm_fp16(normed, hidden, hidden, o, eps)
-                self._w4a16(normed, layer.gate_up, gu)
-                ops.silu_mul_hadamard(gu, self.had_rem_dim, self.had_K, self.mlp_had_scale, out_f16=had_mlp)
-                self._w4a16(had_mlp, layer.down_proj, o)
+                x, xs = normed, None
+            # gate_up -> silu*up -> online hadamard (+ quant) -> down_proj                              :266-299
+            if fuse:
+                ops.gate_up_silu_linear(x, xs, gu_w, gu_s, act)
+                if w4a4:
+                    ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, q=q3, scale=sc)
+                else:
+                    had_mlp_in = s.act_buffer_gate_up.view(-1)[:T * cfg.intermediate_size].view(T, cfg.intermediate_size)
+                    ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, out_f16=had_mlp_in)
+            else:
+                if w4a4:
+                    ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, gu_w, gu_s, None, gu)
+                    ops.silu_mul_hadamard(gu, self.had_rem_dim, self.had_K, self.mlp_had_scale, q=q3, scale=sc)
+                else:
+                    self._w4a16(normed, layer.gate_up, gu)
+                    ops.silu_mul_hadamard(gu, self.had_rem_dim, self.had_K, self.mlp_had_scale, out_f16=had_mlp)
+                    had_mlp_in = had_mlp
+            if w4a4:
+                ops.rowwise_scaled_linear_cutlass_s4s4_unified(q3, sc, layer.down_proj.weight, layer.down_proj._scales(), None, o)
+            else:
+                self._w4a16(had_mlp_in, layer.down_proj, o)
             delta = o
         # final norm is always fp16, in both passes (self.norm(hidden_states) without kwargs, :533)
         ops.add_rms_norm_fp16(normed, hidden, hidden, delta, eps)
@@ -234,7 +261,7 @@ class QuarotLlamaForCausalLM:
         mlp_had = quarot_nn.OnlineHadamard(cfg.intermediate_size, device=self.device)
         if self.had_rem_dim is not None:
             mlp_had.had_rem_dim = self.had_rem_dim
-        ws = torch.empty(ops.paged_attention_workspace_bytes(md.q_start.numel() * md.max_q_len, cfg.num_attention_heads,
+        ws = torch.zeros(ops.paged_attention_workspace_bytes(md.q_start.numel() * md.max_q_len, cfg.num_attention_heads,
                                                              cfg.head_dim, md.n_splits), dtype=torch.uint8, device=self.device)
         for li, layer in enumerate(self.layers):
             kc, vc = kv_caches[li]

@@ -136,7 +136,48 @@ def silu_mul_hadamard(gate_up, hadK, K: int, had_scale: float, out_f16=None, q=N
           float(clip_ratio), T, two_i // 2, K, _stream())
 
 
+def mlp_hadamard(act, hadK, K: int, had_scale: float, out_f16=None, q=None, scale=None, clip_ratio: float = 1.0):
+    """Hadamard (+ quantiser) tail of silu_mul_hadamard on act = silu(gate)*up, [T, I]."""
+    T, I = act.shape
+    _call("qspec_mlp_hadamard", _chk(act, "act", _F16), _opt(hadK, "hadK", _F16), _opt(out_f16, "out_f16", _F16),
+          _opt(q, "q", _I8), _opt(scale, "scale", _F16), float(had_scale), float(clip_ratio), T, I, K, _stream())
+
+
 # ------------------------------------------------------------------ linear
+
+def qkv_rope_linear(x, x_scale, wq, w_scale, qkv, positions, cos_sin_cache, key_cache, value_cache, slot_mapping,
+                    num_heads, num_kv_heads, head_size):
+    """qkv GEMM + rotary_embedding + reshape_and_cache_flash in one launch (quarot_llama.py:183-226).
+    x_scale is None -> W4A16 (x fp16 [M,K]); else W4A4 (x packed int4 [M,K/2])."""
+    N = wq.shape[0]
+    K = wq.shape[1] * 2
+    M = x.shape[0]
+    common = (_chk(positions, "positions", _I64), _chk(cos_sin_cache, "cos_sin_cache", _F16),
+              _chk(key_cache, "key_cache", _F16), _chk(value_cache, "value_cache", _F16),
+              _chk(slot_mapping, "slot_mapping", _I64), num_heads, num_kv_heads, head_size, cos_sin_cache.shape[-1],
+              _stream())
+    if x_scale is not None:
+        _call("qspec_qkv_rope_linear_s4s4", _chk(x, "xq", (_I8, _U8)), _chk(x_scale, "x_scale", _F16),
+              _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16), _chk(qkv, "qkv", _F16), M, N, K, *common)
+    else:
+        _call("qspec_qkv_rope_linear_w4a16", _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)),
+              _chk(w_scale, "w_scale", _F16), _chk(qkv, "qkv", _F16), M, N, K, *common)
+    return qkv
+
+
+def gate_up_silu_linear(x, x_scale, wq, w_scale, act):
+    """gate_up GEMM + silu(gate)*up in one launch (quarot_llama.py:276-284); act [M, I]."""
+    M = x.shape[0]
+    I = wq.shape[0] // 2
+    K = wq.shape[1] * 2
+    if x_scale is not None:
+        _call("qspec_gate_up_silu_linear_s4s4", _chk(x, "xq", (_I8, _U8)), _chk(x_scale, "x_scale", _F16),
+              _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16), _chk(act, "act", _F16), M, I, K, _stream())
+    else:
+        _call("qspec_gate_up_silu_linear_w4a16", _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)),
+              _chk(w_scale, "w_scale", _F16), _chk(act, "act", _F16), M, I, K, _stream())
+    return act
+
 
 def rowwise_scaled_linear_cutlass_s4s4_unified(xq, x_scale, wq, w_scale, bias, out):
     """torch.ops.torchao.rowwise_scaled_linear_cutlass_s4s4_unified (third-party/ao/torchao/ops.py:600-636)."""

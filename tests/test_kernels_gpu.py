@@ -265,6 +265,72 @@ def test_both_views_read_the_same_buffer(ops, oracle):
     assert torch.equal(w, before)
 
 
+@pytest.mark.parametrize("M,w4a4", [(4, True), (16, True), (33, True), (16, False), (24, False)])
+def test_qkv_rope_linear_equals_gemm_then_rope_then_cache(ops, oracle, M, w4a4):
+    """Fused epilogue == the three reference ops one after the other, bit for bit (same kernels' arithmetic)."""
+    rng = np.random.default_rng(M)
+    nq, nkv, d, K, bs = 8, 2, 128, 1024, 16
+    N = (nq + 2 * nkv) * d
+    wq = dev(oracle.pack_i4(rand_w4(rng, N, K)))
+    ws = dev((rng.random(N) * 0.01 + 0.001).astype(np.float16))
+    cs = dev(oracle.make_cos_sin_cache(d, 2048, 10000.0))
+    pos = dev(rng.integers(0, 2048, M).astype(np.int64))
+    slots_np = rng.permutation(64 * bs)[:M].astype(np.int64)
+    slots_np[0] = -1
+    slots = dev(slots_np)
+    if w4a4:
+        x, xs = dev(oracle.pack_i4(rand_w4(rng, M, K))), dev((rng.random(M) * 0.1 + 0.01).astype(np.float16))
+    else:
+        x, xs = dev(rand_hidden(rng, M, K)), None
+    ref = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    if w4a4:
+        ops.rowwise_scaled_linear_cutlass_s4s4_unified(x, xs, wq, ws, None, ref)
+    else:
+        ops.w4a16_linear(x, wq, ws, ref)
+    kc0 = torch.zeros(64, bs, nkv, d, dtype=torch.float16, device=DEV); vc0 = torch.zeros_like(kc0)
+    ops.rope_kv_write(pos, ref, cs, kc0, vc0, slots, nq, nkv, d)
+    out = torch.empty_like(ref)
+    kc1 = torch.zeros_like(kc0); vc1 = torch.zeros_like(kc0)
+    ops.qkv_rope_linear(x, xs, wq, ws, out, pos, cs, kc1, vc1, slots, nq, nkv, d)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    assert torch.equal(kc1, kc0) and torch.equal(vc1, vc0)
+
+
+@pytest.mark.parametrize("M,w4a4", [(4, True), (16, True), (40, True), (16, False)])
+def test_gate_up_silu_linear_and_mlp_hadamard_equal_unfused(ops, oracle, golden_dir, M, w4a4):
+    rng = np.random.default_rng(M + 100)
+    I, K = 3584, 1024
+    g = np.load(os.path.join(golden_dir, "hadamard.npz"))
+    had = dev(g["had28"].astype(np.float16))
+    wq = dev(oracle.pack_i4(rand_w4(rng, 2 * I, K)))
+    ws = dev((rng.random(2 * I) * 0.01 + 0.001).astype(np.float16))
+    if w4a4:
+        x, xs = dev(oracle.pack_i4(rand_w4(rng, M, K))), dev((rng.random(M) * 0.1 + 0.01).astype(np.float16))
+    else:
+        x, xs = dev(rand_hidden(rng, M, K)), None
+    gu = torch.empty(M, 2 * I, dtype=torch.float16, device=DEV)
+    if w4a4:
+        ops.rowwise_scaled_linear_cutlass_s4s4_unified(x, xs, wq, ws, None, gu)
+    else:
+        ops.w4a16_linear(x, wq, ws, gu)
+    ref_act = ops.silu_mul(gu, torch.empty(M, I, dtype=torch.float16, device=DEV))
+    act = ops.gate_up_silu_linear(x, xs, wq, ws, torch.empty(M, I, dtype=torch.float16, device=DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(act.view(torch.int16), ref_act.view(torch.int16))
+    sc = oracle.rsqrt_scale(I)
+    q0 = torch.empty(M, I // 2, dtype=torch.int8, device=DEV); s0 = torch.empty(M, dtype=torch.float16, device=DEV)
+    q1 = torch.empty_like(q0); s1 = torch.empty_like(s0)
+    ops.silu_mul_hadamard(gu, had, 28, sc, q=q0, scale=s0)
+    ops.mlp_hadamard(act, had, 28, sc, q=q1, scale=s1)
+    o0 = torch.empty(M, I, dtype=torch.float16, device=DEV); o1 = torch.empty_like(o0)
+    ops.silu_mul_hadamard(gu, had, 28, sc, out_f16=o0)
+    ops.mlp_hadamard(act, had, 28, sc, out_f16=o1)
+    torch.cuda.synchronize()
+    assert torch.equal(q0, q1) and torch.equal(s0.view(torch.int16), s1.view(torch.int16))
+    assert torch.equal(o0.view(torch.int16), o1.view(torch.int16))
+
+
 @pytest.mark.parametrize("M,N,K", [(4, 1000, 4096), (16, 128256, 256), (20, 2048, 2048)])
 def test_linear_f16_within_1e3(ops, oracle, M, N, K):
     rng = np.random.default_rng(N)
@@ -341,7 +407,7 @@ def test_paged_attention_within_1e3(ops, oracle, ctx_lens, q_len):
     scale = d ** -0.5
     ref = oracle.paged_attention(qkv[:, : nq * d], kc, vc, bt, ctx, q_start, scale)
     n_splits = (max(ctx_lens) + 127) // 128 + 1
-    ws = torch.empty(ops.paged_attention_workspace_bytes(T, nq, d, n_splits), dtype=torch.uint8, device=DEV)
+    ws = torch.zeros(ops.paged_attention_workspace_bytes(T, nq, d, n_splits), dtype=torch.uint8, device=DEV)
     out = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
     ops.paged_attention(dev(qkv), row, dev(kc), dev(vc), dev(bt), dev(ctx), dev(q_start), T, q_len, nq, scale,
                         n_splits, ws, out)
