@@ -177,7 +177,9 @@ int qspec_embedding(const int64_t* ids, const qspec_half* table, qspec_half* out
 
 /* Sampler.forward, greedy, modify_greedy_probs=False  (vllm/model_executor/layers/sampler.py:216-316):
  *   probs = softmax(float(logits)) [tokens, vocab] fp32, token = argmax. */
-int qspec_softmax_argmax(const qspec_half* logits, float* probs, int64_t* token, int tokens, int vocab, void* stream);
+size_t qspec_sampler_workspace_bytes(int rows);   /* rows = tokens (softmax) or batch*k (rejection sampler) */
+int qspec_softmax_argmax(const qspec_half* logits, float* probs, int64_t* token, int tokens, int vocab,
+                         void* workspace, void* stream);
 
 /* RejectionSampler.forward(target_with_bonus_probs, bonus_token_ids, draft_probs, draft_token_ids)
  *   vllm/model_executor/layers/rejection_sampler.py:60-154 + spec_decode_base_sampler.py:69-131.
@@ -195,7 +197,7 @@ int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* 
                            int k, int vocab, int64_t dp_stride_b, int64_t dp_stride_k, int64_t ids_stride_b,
                            int64_t ids_stride_k, int64_t bonus_stride,
                            int64_t* out_tokens, uint8_t* accepted, int64_t* recovered, int64_t* counters,
-                           void* stream);
+                           void* workspace, void* stream);
 
 /* ops.advance_step_flashattn(num_seqs, num_queries, block_size, input_tokens, sampled_token_ids,
  *   input_positions, seq_lens, slot_mapping, block_tables)   csrc/prepare_inputs/advance_step.cu:14-64,192

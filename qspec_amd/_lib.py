@@ -47,9 +47,10 @@ SIGNATURES = {
     "qspec_paged_attention": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp,
                                    _vp, _vp]),
     "qspec_embedding": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
-    "qspec_softmax_argmax": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "qspec_sampler_workspace_bytes": (_sz, [_i]),
+    "qspec_softmax_argmax": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "qspec_rejection_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _i, _i64, _i64, _i64, _i64,
-                                    _i64, _vp, _vp, _vp, _vp, _vp]),
+                                    _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qspec_advance_step_flashattn": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qspec_spec_prepare_draft": (_i, [_i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "qspec_spec_prepare_verify": (_i, [_i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -207,11 +207,13 @@ int qspec_embedding(const int64_t* ids, const qspec_half* table, qspec_half* out
     NONNULL(op, ids); NONNULL(op, table); NONNULL(op, out);
     return finish(op, qspec::embedding(ids, CH(table), H(out), tokens, hidden, vocab, ST));
 }
-int qspec_softmax_argmax(const qspec_half* logits, float* probs, int64_t* token, int tokens, int vocab, void* stream) {
+size_t qspec_sampler_workspace_bytes(int rows) { return qspec::sampler_ws_bytes(rows); }
+int qspec_softmax_argmax(const qspec_half* logits, float* probs, int64_t* token, int tokens, int vocab,
+                         void* workspace, void* stream) {
     const char* op = "qspec_softmax_argmax";
     if (tokens == 0) return 0;
-    NONNULL(op, logits); NONNULL(op, probs); NONNULL(op, token);
-    return finish(op, qspec::softmax_argmax(CH(logits), probs, token, tokens, vocab, ST));
+    NONNULL(op, logits); NONNULL(op, probs); NONNULL(op, token); NONNULL(op, workspace);
+    return finish(op, qspec::softmax_argmax(CH(logits), probs, token, tokens, vocab, workspace, ST));
 }
 int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* bonus_token_ids,
                            const float* draft_probs, const int64_t* draft_token_ids, const float* uniform,
@@ -219,13 +221,15 @@ int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* 
                            int k, int vocab, int64_t dp_stride_b, int64_t dp_stride_k, int64_t ids_stride_b,
                            int64_t ids_stride_k, int64_t bonus_stride,
                            int64_t* out_tokens, uint8_t* accepted, int64_t* recovered, int64_t* counters,
-                           void* stream) {
+                           void* workspace, void* stream) {
     const char* op = "qspec_rejection_sample";
     if (batch == 0) return 0;
     NONNULL(op, target_with_bonus_probs); NONNULL(op, bonus_token_ids); NONNULL(op, draft_probs);
     NONNULL(op, draft_token_ids); NONNULL(op, out_tokens); NONNULL(op, accepted); NONNULL(op, recovered);
+    NONNULL(op, workspace);
+    if (batch * k > 4096) return fail("%s: batch*k=%d too large", op, batch * k);
     if (k < 1) return fail("%s: k=%d must be >= 1", op, k);
-    return finish(op, qspec::rejection_sample(target_with_bonus_probs, draft_probs, draft_token_ids, bonus_token_ids, uniform, exponential, seed, offset, rng_state, batch, k, vocab, dp_stride_b, dp_stride_k, ids_stride_b, ids_stride_k, bonus_stride, out_tokens, accepted, recovered, counters, ST));
+    return finish(op, qspec::rejection_sample(target_with_bonus_probs, draft_probs, draft_token_ids, bonus_token_ids, uniform, exponential, seed, offset, rng_state, batch, k, vocab, dp_stride_b, dp_stride_k, ids_stride_b, ids_stride_k, bonus_stride, out_tokens, accepted, recovered, counters, workspace, ST));
 }
 int qspec_advance_step_flashattn(int num_seqs, int block_size, int64_t* input_tokens,
                                  const int64_t* sampled_token_ids, int64_t* input_positions, int32_t* seq_lens,

@@ -271,10 +271,28 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
                 v[i] = hi ? (o - v[i]) : (v[i] + o);
             }
         }
+        if (EPL >= 8) {  // one 16-byte LDS store per 8 values (2-byte stores at a 16-byte lane stride are 8-way conflicted)
 #pragma unroll
-        for (int i = 0; i < EPL; i++) ylds[(size_t)c * P + lane * EPL + i] = f2h(v[i] * had_scale);
+            for (int b = 0; b < EPL / 8; b++) {
+                f16x8 o8;
+#pragma unroll
+                for (int i = 0; i < 8; i++) o8[i] = f2h(v[8 * b + i] * had_scale);
+                *reinterpret_cast<f16x8*>(ylds + (size_t)c * P + lane * EPL + 8 * b) = o8;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPL; i++) ylds[(size_t)c * P + lane * EPL + i] = f2h(v[i] * had_scale);
+        }
     }
+#ifdef QS_SMH_STAMPS
+    long long stp[6];
+#define QS_ST2(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stp[i])::"memory")
+#else
+#define QS_ST2(i)
+#endif
+    QS_ST2(1);
     __syncthreads();
+    QS_ST2(2);
 
     // phase B: hadK mix.  KH > 0: a thread owns a column pair and KH/IQ output rows; the column pair lives in
     // registers and the k loop is fully unrolled with 16-byte broadcast reads of hadK (a naive loop is LDS
@@ -331,6 +349,7 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
         __syncthreads();
     }
 
+    QS_ST2(3);
     // phase C: fp16 out, or abs-max + int4
     const int nvec = I / 8;
     if (q == nullptr) {
@@ -366,6 +385,13 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
         }
         *reinterpret_cast<uint32_t*>(q + (size_t)t * (I / 2) + 4 * i) = w;
     }
+#ifdef QS_SMH_STAMPS
+    QS_ST2(4);
+    if (tid == 0 && t == 0) {  // debug: stamps land in the first bytes of the NEXT token's int4 row region is unsafe; use scale[64..]
+        long long* sb = reinterpret_cast<long long*>(scale + 64);
+        sb[0] = stp[2] - stp[1]; sb[1] = stp[3] - stp[2]; sb[2] = stp[4] - stp[3]; sb[3] = stp[1];  sb[4] = stp[4];
+    }
+#endif
 }
 
 int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,

@@ -57,12 +57,13 @@ size_t paged_attention_ws_bytes(int T, int nq, int d, int n_splits);
 
 // sampler.hip
 int embedding(const int64_t* ids, const f16* table, f16* out, int T, int H, int V, hipStream_t st);
-int softmax_argmax(const f16* logits, float* probs, int64_t* token, int T, int V, hipStream_t st);
+size_t sampler_ws_bytes(int rows);
+int softmax_argmax(const f16* logits, float* probs, int64_t* token, int T, int V, void* ws, hipStream_t st);
 int rejection_sample(const float* target_probs, const float* draft_probs, const int64_t* draft_ids,
                      const int64_t* bonus_ids, const float* uniform, const float* exponential, uint64_t seed,
                      uint64_t offset, uint64_t* rng_state, int B, int k, int V, int64_t dp_sb, int64_t dp_sk,
                      int64_t di_sb, int64_t di_sk, int64_t bonus_stride, int64_t* out_tokens, uint8_t* accepted,
-                     int64_t* recovered, int64_t* counters, hipStream_t st);
+                     int64_t* recovered, int64_t* counters, void* ws, hipStream_t st);
 int advance_step(int n, int block_size, int64_t* input_tokens, const int64_t* sampled, int64_t* positions,
                  int32_t* seq_lens, int64_t* slot_mapping, const int32_t* block_tables, int64_t bt_stride,
                  hipStream_t st);

@@ -68,16 +68,32 @@ __device__ __forceinline__ double block_sum_f64(double v, double* red) {
 }
 
 // probs = softmax_fp32(float(logits)); token = argmax (first index on ties).
-// exp via qexpf, denominator accumulated in fp64 and rounded once (the oracle does the same), so
-// the fp32 probabilities are the oracle's bit for bit up to a ~2^-29 chance per row.
-__global__ __launch_bounds__(1024) void softmax_argmax_kernel(const f16* __restrict__ logits, float* __restrict__ probs,
-                                                              int64_t* __restrict__ token, int V) {
-    __shared__ ArgMax red_a[16];
-    __shared__ double red_d[16];
-    const int t = blockIdx.x;
+// exp via qexpf, denominator accumulated in fp64 and rounded once (the oracle does the same), so the fp32
+// probabilities are the oracle's bit for bit up to a ~2^-29 chance per row.
+// A row of 128256 logits is ~1.8 MB of traffic; one workgroup per row would sit on one CU's ~25 GB/s share
+// (150 us).  The row is cut into QS_SM_CHUNKS chunks, three small launches:
+//   1. per chunk max / argmax            -> part_a[row][chunk]
+//   2. row max from the partials, e = qexpf(l - M) -> probs, per chunk sum (fp64) -> part_s[row][chunk]
+//   3. total in chunk order (deterministic), p = e / float(total); chunk 0 writes the token
+#define QS_SM_CHUNKS 64
+struct SmPartA {
+    float v;
+    int i;
+};
+__device__ __forceinline__ void sm_chunk_range(int V, int c, int& lo, int& hi) {
+    const int len = (((V + QS_SM_CHUNKS - 1) / QS_SM_CHUNKS) + 7) & ~7;
+    lo = min(V, c * len);
+    hi = min(V, lo + len);
+}
+__global__ __launch_bounds__(256) void softmax_max_kernel(const f16* __restrict__ logits, SmPartA* __restrict__ part_a,
+                                                          int V) {
+    __shared__ ArgMax red_a[4];
+    const int c = blockIdx.x, t = blockIdx.y;
+    int lo, hi;
+    sm_chunk_range(V, c, lo, hi);
     const f16* l = logits + (size_t)t * V;
     ArgMax am{-__builtin_inff(), 0x7fffffff};
-    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    for (int v = lo + threadIdx.x; v < hi; v += 256) {
         float f = h2f(l[v]);
         if (f > am.v) {
             am.v = f;
@@ -85,23 +101,60 @@ __global__ __launch_bounds__(1024) void softmax_argmax_kernel(const f16* __restr
         }
     }
     am = block_argmax(am, red_a);
-    if (am.i == 0x7fffffff) am.i = 0;  // all -inf / NaN row
-    const float mx = am.v;
-    double den = 0.0;
+    if (threadIdx.x == 0) part_a[t * QS_SM_CHUNKS + c] = SmPartA{am.v, am.i};
+}
+__device__ __forceinline__ ArgMax sm_row_max(const SmPartA* part_a, int t) {
+    ArgMax am{-__builtin_inff(), 0x7fffffff};
+    for (int c = 0; c < QS_SM_CHUNKS; c++) {
+        SmPartA pa = part_a[t * QS_SM_CHUNKS + c];
+        am = argmax_combine(am, ArgMax{pa.v, pa.i});
+    }
+    return am;
+}
+__global__ __launch_bounds__(256) void softmax_exp_kernel(const f16* __restrict__ logits, const SmPartA* part_a,
+                                                          float* __restrict__ probs, double* __restrict__ part_s,
+                                                          int V) {
+    __shared__ double red_d[4];
+    const int c = blockIdx.x, t = blockIdx.y;
+    int lo, hi;
+    sm_chunk_range(V, c, lo, hi);
+    const float mx = sm_row_max(part_a, t).v;
+    const f16* l = logits + (size_t)t * V;
     float* p = probs + (size_t)t * V;
-    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    double den = 0.0;
+    for (int v = lo + threadIdx.x; v < hi; v += 256) {
         float e = qexpf(h2f(l[v]) - mx);
         p[v] = e;
         den += (double)e;
     }
     den = block_sum_f64(den, red_d);
-    const float inv = (float)den;
-    for (int v = threadIdx.x; v < V; v += blockDim.x) p[v] = p[v] / inv;
-    if (threadIdx.x == 0) token[t] = am.i;
+    if (threadIdx.x == 0) part_s[t * QS_SM_CHUNKS + c] = den;
 }
-int softmax_argmax(const f16* logits, float* probs, int64_t* token, int T, int V, hipStream_t st) {
+__global__ __launch_bounds__(256) void softmax_norm_kernel(const SmPartA* part_a, const double* part_s,
+                                                           float* __restrict__ probs, int64_t* __restrict__ token,
+                                                           int64_t token_stride, int V) {
+    const int c = blockIdx.x, t = blockIdx.y;
+    int lo, hi;
+    sm_chunk_range(V, c, lo, hi);
+    double den = 0.0;
+    for (int cc = 0; cc < QS_SM_CHUNKS; cc++) den += part_s[t * QS_SM_CHUNKS + cc];
+    const float inv = (float)den;
+    float* p = probs + (size_t)t * V;
+    for (int v = lo + threadIdx.x; v < hi; v += 256) p[v] = p[v] / inv;
+    if (c == 0 && threadIdx.x == 0) {
+        ArgMax am = sm_row_max(part_a, t);
+        token[t * token_stride] = am.i == 0x7fffffff ? 0 : am.i;
+    }
+}
+size_t sampler_ws_bytes(int rows) { return (size_t)rows * QS_SM_CHUNKS * 16; }
+int softmax_argmax(const f16* logits, float* probs, int64_t* token, int T, int V, void* ws, hipStream_t st) {
     if (T == 0) return 0;
-    hipLaunchKernelGGL(softmax_argmax_kernel, dim3(T), dim3(1024), 0, st, logits, probs, token, V);
+    SmPartA* part_a = reinterpret_cast<SmPartA*>(ws);
+    double* part_s = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + (size_t)T * QS_SM_CHUNKS * 8);
+    hipLaunchKernelGGL(softmax_max_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, logits, part_a, V);
+    hipLaunchKernelGGL(softmax_exp_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, logits, part_a, probs, part_s, V);
+    hipLaunchKernelGGL(softmax_norm_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, part_a, part_s, probs, token,
+                       (int64_t)1, V);
     return 0;
 }
 
@@ -121,24 +174,40 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
 }
 __device__ __forceinline__ float u01_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
-// One workgroup per (b, i): accepted[b,i] and recovered[b,i].
-//   accepted  = U < min(1, q[x]/p[x])
-//   recovered = argmax_v ( max(q_v - p_v, FLT_MIN) / S ) / E_v ,  S = sum_v max(q_v - p_v, FLT_MIN)
-// target_probs [B, k+1, V], draft_probs [B, k, V].  uniform [B,k] / exponential [B,k,V] may be injected
-// (tests); when null they come from Philox keyed by (seed, offset).
-__global__ __launch_bounds__(1024) void rejection_core_kernel(const float* __restrict__ target_probs,
-                                                              const float* __restrict__ draft_probs,
-                                                              const int64_t* __restrict__ draft_ids,
-                                                              const float* __restrict__ uniform,
-                                                              const float* __restrict__ exponential, uint64_t seed,
-                                                              uint64_t offset, const uint64_t* __restrict__ rng_state,
-                                                              int k, int V, int64_t dp_sb, int64_t dp_sk,
-                                                              int64_t di_sb, int64_t di_sk,
-                                                              uint8_t* __restrict__ accepted,
-                                                              int64_t* __restrict__ recovered) {
-    __shared__ ArgMax red_a[16];
-    __shared__ double red_d[16];
-    const int b = blockIdx.x / k, i = blockIdx.x % k;
+// accepted[b,i] = U < min(1, q[x]/p[x]);
+// recovered[b,i] = argmax_v ( max(q_v - p_v, FLT_MIN) / S ) / E_v ,  S = sum_v max(q_v - p_v, FLT_MIN)
+// target_probs [B, k+1, V], draft_probs (b,i,v) at b*dp_sb + i*dp_sk + v.  uniform [B,k] / exponential [B,k,V] may
+// be injected (tests); when null they come from Philox keyed by (seed, offset).
+// Same shape as the softmax: each (b,i) row is cut into QS_SM_CHUNKS chunks over the chip.
+//   1. per chunk sum of max(q-p, tiny) in fp64                       -> part_s
+//   2. S = float(total in chunk order); per chunk argmax of (f/S)/E  -> part_a
+//   3. one workgroup: final argmax per (b,i), accept test, output assembly + counters
+__global__ __launch_bounds__(256) void rejection_sum_kernel(const float* __restrict__ target_probs,
+                                                            const float* __restrict__ draft_probs, int k, int V,
+                                                            int64_t dp_sb, int64_t dp_sk,
+                                                            double* __restrict__ part_s) {
+    __shared__ double red_d[4];
+    const int c = blockIdx.x, bk = blockIdx.y, b = bk / k, i = bk % k;
+    int lo, hi;
+    sm_chunk_range(V, c, lo, hi);
+    const float* q = target_probs + ((size_t)b * (k + 1) + i) * V;
+    const float* p = draft_probs + b * dp_sb + i * dp_sk;
+    const float tiny = 1.17549435e-38f;
+    double s = 0.0;
+    for (int v = lo + threadIdx.x; v < hi; v += 256) s += (double)fmaxf(q[v] - p[v], tiny);
+    s = block_sum_f64(s, red_d);
+    if (threadIdx.x == 0) part_s[bk * QS_SM_CHUNKS + c] = s;
+}
+__global__ __launch_bounds__(256) void rejection_argmax_kernel(const float* __restrict__ target_probs,
+                                                               const float* __restrict__ draft_probs,
+                                                               const float* __restrict__ exponential, uint64_t seed,
+                                                               uint64_t offset, const uint64_t* __restrict__ rng_state,
+                                                               int k, int V, int64_t dp_sb, int64_t dp_sk,
+                                                               const double* part_s, SmPartA* __restrict__ part_a) {
+    __shared__ ArgMax red_a[4];
+    const int c = blockIdx.x, bk = blockIdx.y, b = bk / k, i = bk % k;
+    int lo, hi;
+    sm_chunk_range(V, c, lo, hi);
     const float* q = target_probs + ((size_t)b * (k + 1) + i) * V;
     const float* p = draft_probs + b * dp_sb + i * dp_sk;
     if (rng_state) {  // device-resident (seed, offset): lets a captured graph draw fresh numbers every replay
@@ -147,19 +216,18 @@ __global__ __launch_bounds__(1024) void rejection_core_kernel(const float* __res
     }
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const float tiny = 1.17549435e-38f;
-    double s = 0.0;
-    for (int v = threadIdx.x; v < V; v += blockDim.x) s += (double)fmaxf(q[v] - p[v], tiny);
-    s = block_sum_f64(s, red_d);
-    const float S = (float)s;
+    double tot = 0.0;
+    for (int cc = 0; cc < QS_SM_CHUNKS; cc++) tot += part_s[bk * QS_SM_CHUNKS + cc];
+    const float S = (float)tot;
     ArgMax am{-__builtin_inff(), 0x7fffffff};
-    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    for (int v = lo + threadIdx.x; v < hi; v += 256) {
         float f = fmaxf(q[v] - p[v], tiny) / S;
         float e;
         if (exponential) {
-            e = exponential[((size_t)b * k + i) * V + v];
+            e = exponential[(size_t)bk * V + v];
         } else {
             uint32_t r[4];
-            philox4x32((uint32_t)v, (uint32_t)blockIdx.x, (uint32_t)offset, (uint32_t)(offset >> 32), k0, k1, r);
+            philox4x32((uint32_t)v, (uint32_t)bk, (uint32_t)offset, (uint32_t)(offset >> 32), k0, k1, r);
             e = -__logf(u01_open(r[0]));
         }
         float val = f / e;
@@ -169,35 +237,47 @@ __global__ __launch_bounds__(1024) void rejection_core_kernel(const float* __res
         }
     }
     am = block_argmax(am, red_a);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) part_a[bk * QS_SM_CHUNKS + c] = SmPartA{am.v, am.i};
+}
+// Final step + output assembly + counters (spec_decode_base_sampler.py:94-131); one workgroup.
+// counters[0] += accepted.sum() (non-causal), counters[1] += #(out != -1), counters[2] += B*k.
+__global__ __launch_bounds__(1024) void rejection_output_kernel(
+    const float* __restrict__ target_probs, const float* __restrict__ draft_probs,
+    const int64_t* __restrict__ draft_ids, const int64_t* __restrict__ bonus_ids, const float* __restrict__ uniform,
+    uint64_t seed, uint64_t offset, uint64_t* __restrict__ rng_state, const SmPartA* part_a, int B, int k, int V,
+    int64_t dp_sb, int64_t dp_sk, int64_t di_sb, int64_t di_sk, int64_t bonus_stride, uint8_t* __restrict__ accepted,
+    int64_t* __restrict__ recovered, int64_t* __restrict__ out, int64_t* __restrict__ counters) {
+    if (rng_state) {
+        seed = rng_state[0];
+        offset = rng_state[1];
+    }
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int bk = threadIdx.x; bk < B * k; bk += blockDim.x) {
+        const int b = bk / k, i = bk % k;
+        ArgMax am{-__builtin_inff(), 0x7fffffff};
+        for (int c = 0; c < QS_SM_CHUNKS; c++) {
+            SmPartA pa = part_a[bk * QS_SM_CHUNKS + c];
+            am = argmax_combine(am, ArgMax{pa.v, pa.i});
+        }
         const int64_t x = draft_ids[b * di_sb + i * di_sk];
         float u;
         if (uniform) {
-            u = uniform[(size_t)b * k + i];
+            u = uniform[bk];
         } else {
             uint32_t r[4];
-            philox4x32(0xFFFFFFFFu, (uint32_t)blockIdx.x, (uint32_t)offset, (uint32_t)(offset >> 32), k0, k1, r);
+            philox4x32(0xFFFFFFFFu, (uint32_t)bk, (uint32_t)offset, (uint32_t)(offset >> 32), k0, k1, r);
             u = (float)(r[0] >> 8) * (1.0f / 16777216.0f);  // [0,1) like torch.rand
         }
-        const float rq = q[x] / p[x];
+        const float qx = target_probs[((size_t)b * (k + 1) + i) * V + x];
+        const float px = draft_probs[b * dp_sb + i * dp_sk + x];
+        const float rq = qx / px;
         // torch.minimum propagates NaN (0/0) and `u < NaN` is false: such a token is rejected
-        const bool acc = (rq == rq) && (u < fminf(rq, 1.0f));
-        accepted[(size_t)b * k + i] = acc ? 1 : 0;
-        recovered[(size_t)b * k + i] = am.i == 0x7fffffff ? 0 : am.i;
+        accepted[bk] = ((rq == rq) && (u < fminf(rq, 1.0f))) ? 1 : 0;
+        recovered[bk] = am.i == 0x7fffffff ? 0 : am.i;
     }
-}
-
-// Output assembly + counters (spec_decode_base_sampler.py:94-131); one thread per sequence.
-// counters[0] += accepted.sum() (non-causal), counters[1] += #(out != -1), counters[2] += B*k.
-__global__ void rejection_output_kernel(const uint8_t* __restrict__ accepted, const int64_t* __restrict__ recovered,
-                                        const int64_t* __restrict__ draft_ids, const int64_t* __restrict__ bonus_ids,
-                                        int B, int k, int64_t di_sb, int64_t di_sk, int64_t bonus_stride,
-                                        int64_t* __restrict__ out, int64_t* __restrict__ counters,
-                                        uint64_t* __restrict__ rng_state) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rng_state && b == 0) rng_state[1] += 1;  // runs after the core kernel on the same stream
+    __syncthreads();
     int acc_cnt = 0, emit_cnt = 0;
-    if (b < B) {
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
         int limit = k;
         for (int i = 0; i < k; i++) {
             if (accepted[b * k + i]) acc_cnt++;
@@ -213,24 +293,29 @@ __global__ void rejection_output_kernel(const uint8_t* __restrict__ accepted, co
         emit_cnt += last != -1;
     }
     if (counters) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(counters), (unsigned long long)acc_cnt);
-        atomicAdd(reinterpret_cast<unsigned long long*>(counters + 1), (unsigned long long)emit_cnt);
-        if (b == 0) atomicAdd(reinterpret_cast<unsigned long long*>(counters + 2), (unsigned long long)B * k);
+        if (acc_cnt) atomicAdd(reinterpret_cast<unsigned long long*>(counters), (unsigned long long)acc_cnt);
+        if (emit_cnt) atomicAdd(reinterpret_cast<unsigned long long*>(counters + 1), (unsigned long long)emit_cnt);
+        if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(counters + 2), (unsigned long long)B * k);
     }
+    if (rng_state && threadIdx.x == 0) rng_state[1] = offset + 1;  // after every draw of this call
 }
 
 int rejection_sample(const float* target_probs, const float* draft_probs, const int64_t* draft_ids,
                      const int64_t* bonus_ids, const float* uniform, const float* exponential, uint64_t seed,
                      uint64_t offset, uint64_t* rng_state, int B, int k, int V, int64_t dp_sb, int64_t dp_sk,
                      int64_t di_sb, int64_t di_sk, int64_t bonus_stride, int64_t* out_tokens, uint8_t* accepted,
-                     int64_t* recovered, int64_t* counters, hipStream_t st) {
+                     int64_t* recovered, int64_t* counters, void* ws, hipStream_t st) {
     if (B == 0) return 0;
     if (k < 1) return -1;
-    hipLaunchKernelGGL(rejection_core_kernel, dim3(B * k), dim3(1024), 0, st, target_probs, draft_probs, draft_ids,
-                       uniform, exponential, seed, offset, rng_state, k, V, dp_sb, dp_sk, di_sb, di_sk, accepted,
-                       recovered);
-    hipLaunchKernelGGL(rejection_output_kernel, dim3((B + 63) / 64), dim3(64), 0, st, accepted, recovered, draft_ids,
-                       bonus_ids, B, k, di_sb, di_sk, bonus_stride, out_tokens, counters, rng_state);
+    SmPartA* part_a = reinterpret_cast<SmPartA*>(ws);
+    double* part_s = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + (size_t)B * k * QS_SM_CHUNKS * 8);
+    hipLaunchKernelGGL(rejection_sum_kernel, dim3(QS_SM_CHUNKS, B * k), dim3(256), 0, st, target_probs, draft_probs, k,
+                       V, dp_sb, dp_sk, part_s);
+    hipLaunchKernelGGL(rejection_argmax_kernel, dim3(QS_SM_CHUNKS, B * k), dim3(256), 0, st, target_probs, draft_probs,
+                       exponential, seed, offset, rng_state, k, V, dp_sb, dp_sk, part_s, part_a);
+    hipLaunchKernelGGL(rejection_output_kernel, dim3(1), dim3(1024), 0, st, target_probs, draft_probs, draft_ids,
+                       bonus_ids, uniform, seed, offset, rng_state, part_a, B, k, V, dp_sb, dp_sk, di_sb, di_sk,
+                       bonus_stride, accepted, recovered, out_tokens, counters);
     return 0;
 }
 

@@ -277,15 +277,30 @@ def embedding(ids, table, out):
     return out
 
 
-def softmax_argmax(logits, probs, token):
+_ws_cache = {}
+
+
+def _sampler_ws(rows: int, device, workspace=None):
+    """Scratch for the chunked softmax / rejection kernels (64 partials per row); cached per (device, rows)."""
+    if workspace is not None:
+        return workspace
+    key = (str(device), rows)
+    if key not in _ws_cache:
+        n = int(_lib.load().qspec_sampler_workspace_bytes(rows))
+        _ws_cache[key] = torch.empty(n, dtype=torch.uint8, device=device)
+    return _ws_cache[key]
+
+
+def softmax_argmax(logits, probs, token, workspace=None):
     T, V = logits.shape
+    ws = _sampler_ws(T, logits.device, workspace)
     _call("qspec_softmax_argmax", _chk(logits, "logits", _F16), _chk(probs, "probs", _F32), _chk(token, "token", _I64),
-          T, V, _stream())
+          T, V, ws.data_ptr(), _stream())
 
 
 def rejection_sample(target_with_bonus_probs, bonus_token_ids, draft_probs, draft_token_ids, out_tokens, accepted,
                      recovered, counters=None, uniform=None, exponential=None, seed: int = 0, offset: int = 0,
-                     rng_state=None):
+                     rng_state=None, workspace=None):
     B, k, V = draft_probs.shape
     # draft_probs / draft_token_ids / bonus_token_ids may be strided views (step-major draft buffers)
     if draft_probs.stride(2) != 1 or draft_probs.dtype != _F32 or draft_token_ids.dtype != _I64 \
@@ -298,7 +313,7 @@ def rejection_sample(target_with_bonus_probs, bonus_token_ids, draft_probs, draf
           draft_token_ids.stride(0), draft_token_ids.stride(1),
           bonus_token_ids.stride(0) if bonus_token_ids.numel() > 1 else 1, _chk(out_tokens, "out_tokens", _I64),
           _chk(accepted, "accepted", _U8), _chk(recovered, "recovered", _I64), _opt(counters, "counters", _I64),
-          _stream())
+          _sampler_ws(B * k, draft_probs.device, workspace).data_ptr(), _stream())
 
 
 def advance_step_flashattn(num_seqs, num_queries, block_size, input_tokens, sampled_token_ids, input_positions,

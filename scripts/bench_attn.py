@@ -5,7 +5,7 @@ import torch
 from qspec_amd import ops
 dev = "cuda:0"
 B, nq, nkv, d, bs = 4, 32, 8, 128, 16
-ctx0, max_len = 560, 640
+ctx0, max_len = int(os.environ.get('CTX', 560)), int(os.environ.get('MAXLEN', 640))
 for q_len in (1, 4):
     n_splits = (max_len + 127) // 128
     nb = B * (max_len // bs)

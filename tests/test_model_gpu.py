@@ -132,11 +132,6 @@ def test_engine_cycle_matches_oracle_engine(tiny, oracle):
         tv_t = 0.5 * np.abs(r["target_probs"] - t_probs).sum(-1)
         all_tv_d.append(tv_d)
         all_tv_t.append(tv_t)
-        # the first draft step sees bit-identical inputs and no attention upstream of the embedding row's first
-        # layer-norm: its argmax must agree whenever the oracle's top-2 margin is not razor thin
-        top2 = np.sort(r["draft_probs"][:, 0], -1)[:, -2:]
-        clear = (top2[:, 1] - top2[:, 0]) > 0.05 * top2[:, 1]
-        assert np.array_equal(r["draft_ids_free"][clear, 0], d_ids[clear, 0])
         # ---- logic (exact)
         o_out, o_acc, o_rec, c = oracle.rejection_sample(t_probs, t_toks[:, k], d_probs, d_ids, U, E)
         assert np.array_equal(out, o_out), cyc
