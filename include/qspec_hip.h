@@ -105,9 +105,13 @@ int qspec_rowwise_scaled_linear_s4s4(const int8_t* xq, const qspec_half* xs, con
                                      const qspec_half* bias, qspec_half* out, int M, int N, int K, void* stream);
 
 /* bitblas.Matmul.__call__(x, w ^ 0x88, output=C, scale=ws, bias=bias)  (quarot_nn/linear.py:102-124,156-211).
- *   Takes the SAME wq buffer as the s4s4 op (no XOR copy).  x [M,K] fp16. */
+ *   Takes the SAME wq buffer as the s4s4 op (no XOR copy).  x [M,K] fp16.
+ *   workspace: NULL, or qspec_w4a16_workspace_bytes() bytes ZERO-FILLED once before first use: lets narrow layers
+ *   split K across workgroups (partial tiles + ticket counters, left zeroed by every call); with NULL the
+ *   layer runs unsplit.  Results are deterministic either way. */
+size_t qspec_w4a16_workspace_bytes(void);
 int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* ws, const qspec_half* bias,
-                       qspec_half* out, int M, int N, int K, void* stream);
+                       qspec_half* out, int M, int N, int K, void* workspace, void* stream);
 
 /* qkv_proj fused with what follows it in QuarotLlamaAttention.forward (quarot_llama.py:183-226): the GEMM
  * (s4s4: linear.py:82 / w4a16: linear.py:122) -> ops.rotary_embedding on q,k (csrc/pos_encoding_kernels.cu:71-122)
@@ -122,14 +126,15 @@ int qspec_qkv_rope_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int
 int qspec_qkv_rope_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M,
                                 int N, int K, const int64_t* positions, const qspec_half* cos_sin_cache,
                                 qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
-                                int num_heads, int num_kv_heads, int head_size, int rot_dim, void* stream);
+                                int num_heads, int num_kv_heads, int head_size, int rot_dim, void* workspace,
+                                void* stream);
 
 /* gate_up GEMM fused with `act_fn(gate) * up` (quarot_llama.py:276-284): wq rows are [up; gate] (fuse_gate_up,
  * :301-314), act [M, I] = h(h(silu(gate)) * up).  Bit-identical to GEMM followed by qspec_silu_mul. */
 int qspec_gate_up_silu_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
                                    qspec_half* act, int M, int intermediate, int K, void* stream);
 int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
-                                    int intermediate, int K, void* stream);
+                                    int intermediate, int K, void* workspace, void* stream);
 
 /* lm_head: F.linear(hidden, lm_head.weight)  (vllm/model_executor/layers/logits_processor.py:92-97). w [N,K] fp16. */
 int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, int M, int N, int K, void* stream);

@@ -136,14 +136,15 @@ int qspec_rowwise_scaled_linear_s4s4(const int8_t* xq, const qspec_half* xs, con
     if (N % 16 || K % 128 || K <= 0) return fail("%s: need N %% 16 == 0 and K %% 128 == 0 (N=%d K=%d)", op, N, K);
     return finish(op, qspec::gemm_w4a4(xq, CH(xs), wq, CH(ws), CH(bias), H(out), M, N, K, ST));
 }
+size_t qspec_w4a16_workspace_bytes(void) { return qspec::gemm_w4a16_ws_bytes(); }
 int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* ws, const qspec_half* bias,
-                       qspec_half* out, int M, int N, int K, void* stream) {
+                       qspec_half* out, int M, int N, int K, void* workspace, void* stream) {
     const char* op = "qspec_w4a16_linear";
     if (M < 0 || N < 0) return fail("%s: negative size", op);
     if (M == 0 || N == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, out);
     if (N % 16 || K % 128 || K <= 0) return fail("%s: need N %% 16 == 0 and K %% 128 == 0 (N=%d K=%d)", op, N, K);
-    return finish(op, qspec::gemm_w4a16(CH(x), wq, CH(ws), CH(bias), H(out), M, N, K, ST));
+    return finish(op, qspec::gemm_w4a16(CH(x), wq, CH(ws), CH(bias), H(out), M, N, K, workspace, ST));
 }
 int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, int M, int N, int K, void* stream) {
     const char* op = "qspec_linear_f16";
@@ -297,13 +298,14 @@ int qspec_qkv_rope_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int
 int qspec_qkv_rope_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M,
                                 int N, int K, const int64_t* positions, const qspec_half* cos_sin_cache,
                                 qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
-                                int num_heads, int num_kv_heads, int head_size, int rot_dim, void* stream) {
+                                int num_heads, int num_kv_heads, int head_size, int rot_dim, void* workspace,
+                                void* stream) {
     const char* op = "qspec_qkv_rope_linear_w4a16";
     if (M == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, qkv); NONNULL(op, positions);
     NONNULL(op, cos_sin_cache); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
     if (head_size != 128 || rot_dim != 128) return fail("%s: head_size and rot_dim must be 128", op);
-    return finish(op, qspec::gemm_w4a16_qkv_rope(CH(x), wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST));
+    return finish(op, qspec::gemm_w4a16_qkv_rope(CH(x), wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, workspace, ST));
 }
 int qspec_gate_up_silu_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
                                    qspec_half* act, int M, int intermediate, int K, void* stream) {
@@ -313,11 +315,11 @@ int qspec_gate_up_silu_linear_s4s4(const int8_t* xq, const qspec_half* xs, const
     return finish(op, qspec::gemm_w4a4_gate_up_silu(xq, CH(xs), wq, CH(ws), H(act), M, intermediate, K, ST));
 }
 int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
-                                    int intermediate, int K, void* stream) {
+                                    int intermediate, int K, void* workspace, void* stream) {
     const char* op = "qspec_gate_up_silu_linear_w4a16";
     if (M == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
-    return finish(op, qspec::gemm_w4a16_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, ST));
+    return finish(op, qspec::gemm_w4a16_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, workspace, ST));
 }
 
 }  // extern "C"

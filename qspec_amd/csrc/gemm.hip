@@ -283,48 +283,79 @@ __device__ __forceinline__ f16x8 shuffle_act8(u32x4 a) {
 }
 
 // out[m,n] = h( (sum_k f(x[m,k]) * w[n,k]) * f(sw[n]) (+ f(bias[n])) ), fp32 accumulate
+// Activations are 4x the bytes of the weight rows they multiply (fp16 vs int4), and as MFMA A fragments they
+// would be 64 scattered 16-byte pieces per load instruction (the address unit, not bandwidth, then bounds the
+// kernel: 4x slower measured).  So each round the workgroup copies the [16*MT rows x 512 k] activation tile it needs
+// into LDS with fully coalesced loads (one 1 KiB row segment per wave instruction, double buffered, one barrier
+// per round) and the waves take their fragments from there; 16-byte chunks are XOR-swizzled by the row so a
+// ds_read_b128 wave access sweeps all 64 banks exactly 4 times (the minimum).
 template <int MT, int EPI>
 __global__ __launch_bounds__(256) void gemm_w4a16_kernel(const f16* __restrict__ x, const int8_t* __restrict__ wq,
                                                           const f16* __restrict__ ws, const f16* __restrict__ bias,
                                                           f16* __restrict__ out, int M, int N, int K, int m_base,
                                                           EpiArgs ea) {
+    constexpr int ROWS = 16 * MT;
+    __shared__ __attribute__((aligned(16))) unsigned char atile[2][ROWS * 1024];  // [buf][row][1024 B = 4 steps]
     __shared__ float red[4][MT][256];
     __shared__ f16 ex[MT][256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int tb = blockIdx.x;
     const int Kb = K >> 1;
-    const int nsteps = Kb >> 6;
+    const int nsteps = Kb >> 6;              // 64 packed bytes (128 k) of every weight row per step
+    const int nrounds = (nsteps + 3) >> 2;   // 4 steps (one per wave) per round
     const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)tile_row<EPI>(tb, r, ea) * Kb + g * 16;
-    const f16* arow[MT];
-    bool aval[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-        int m = m_base + mt * 16 + r;
-        aval[mt] = m < M;
-        arow[mt] = x + (size_t)(aval[mt] ? m : 0) * K + g * 32;  // 16 packed bytes = 32 k
-    }
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int s = wave; s < nsteps; s += 4) {
-        u32x4 w = *reinterpret_cast<const u32x4*>(wrow + (size_t)s * 64);
-        u32x4 a[MT][4];
+    // cooperative A loader: chunk id c = tid + 256*j covers ROWS rows x 64 chunks of 16 B
+    constexpr int CPT = ROWS * 64 / 256;  // chunks per thread (4 * MT)
+    u32x4 areg[CPT];
+    auto load_a = [&](int round) {
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+        for (int j = 0; j < CPT; j++) {
+            const int c = tid + 256 * j, row = c >> 6, q = c & 63;
+            const int m = m_base + row;
+            const size_t koff = (size_t)round * 512 + q * 8;  // halves
+            areg[j] = u32x4{0, 0, 0, 0};
+            if (m < M && koff < (size_t)K) areg[j] = *reinterpret_cast<const u32x4*>(x + (size_t)m * K + koff);
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            const int c = tid + 256 * j, row = c >> 6, q = c & 63;
+            *reinterpret_cast<u32x4*>(&atile[buf][row * 1024 + ((q ^ (row & 15)) << 4)]) = areg[j];
+        }
+    };
+    load_a(0);
+    u32x4 wcur = u32x4{0, 0, 0, 0};
+    if (wave < nsteps) wcur = *reinterpret_cast<const u32x4*>(wrow + (size_t)wave * 64);
+    for (int rd = 0; rd < nrounds; rd++) {
+        const int buf = rd & 1;
+        store_a(buf);
+        __syncthreads();
+        const int s = rd * 4 + wave;
+        u32x4 wnext = u32x4{0, 0, 0, 0};
+        if (rd + 1 < nrounds) {
+            load_a(rd + 1);
+            if (s + 4 < nsteps) wnext = *reinterpret_cast<const u32x4*>(wrow + (size_t)(s + 4) * 64);
+        }
+        if (s < nsteps) {
 #pragma unroll
             for (int dd = 0; dd < 4; dd++) {
-                a[mt][dd] = u32x4{0, 0, 0, 0};
-                if (aval[mt]) a[mt][dd] = *reinterpret_cast<const u32x4*>(arow[mt] + (size_t)s * 128 + dd * 8);
+                const f16x8 b = dequant_s4x8(wcur[dd]);
+                const int q = wave * 16 + g * 4 + dd;  // 16-byte chunk of this lane's 8 k values inside the row
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const int row = mt * 16 + r;
+                    const u32x4 a = *reinterpret_cast<const u32x4*>(&atile[buf][row * 1024 + ((q ^ (row & 15)) << 4)]);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(shuffle_act8(a), b, acc[mt], 0, 0, 0);
+                }
             }
-#pragma unroll
-        for (int dd = 0; dd < 4; dd++) {
-            f16x8 b = dequant_s4x8(w[dd]);
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(shuffle_act8(a[mt][dd]), b, acc[mt], 0, 0, 0);
         }
+        wcur = wnext;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
@@ -351,9 +382,175 @@ __global__ __launch_bounds__(256) void gemm_w4a16_kernel(const f16* __restrict__
     }
 }
 
+// ---- W4A16, decode-sized M, 2-D decomposition (the kernel the verify pass uses).
+// A workgroup owns 64 weight rows (4 tiles, one per wave) x one K block (grid.y).  The 4 waves share every
+// activation tile through LDS, so activation bytes per workgroup equal weight bytes (a 16-row tile alone needs 4x its
+// weight bytes of activations at M = 16), and K blocks keep >= ~256 workgroups in flight for the narrow layers.
+// K blocks are combined by the last workgroup to arrive: fp32 partial tiles in the workspace, summed in block
+// order (deterministic), agent-scope release/acquire around a ticket counter that every call leaves at zero.
+#define QS_W16_CNT_SLOTS 2048
+#define QS_W16_PART_BYTES (8u * 1024u * 1024u)
+template <int MT, int EPI>
+__global__ __launch_bounds__(256) void gemm_w4a16_2d_kernel(const f16* __restrict__ x, const int8_t* __restrict__ wq,
+                                                             const f16* __restrict__ ws, const f16* __restrict__ bias,
+                                                             f16* __restrict__ out, int M, int N, int K,
+                                                             int rounds_per, int* cnt, float* part, EpiArgs ea) {
+    constexpr int ROWS = 16 * MT;
+    __shared__ __attribute__((aligned(16))) unsigned char atile[2][ROWS * 1024];  // [buf][row][512 k fp16]
+    __shared__ f16 ex[4][MT][256];
+    __shared__ int flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int nb = blockIdx.x, S = gridDim.y, split = blockIdx.y;
+    const int tb = nb * 4 + wave;
+    const int Kb = K >> 1;
+    const int nsteps = Kb >> 6;
+    const int nrounds = (nsteps + 3) >> 2;
+    const int rd_lo = split * rounds_per, rd_hi = min(nrounds, rd_lo + rounds_per);
+    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)tile_row<EPI>(tb, r, ea) * Kb + g * 16;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int CPT = ROWS * 64 / 256;
+    u32x4 areg[CPT];
+    auto load_a = [&](int round) {
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            const int c = tid + 256 * j, row = c >> 6, q = c & 63;
+            const size_t koff = (size_t)round * 512 + q * 8;
+            areg[j] = u32x4{0, 0, 0, 0};
+            if (row < M && koff < (size_t)K) areg[j] = *reinterpret_cast<const u32x4*>(x + (size_t)row * K + koff);
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            const int c = tid + 256 * j, row = c >> 6, q = c & 63;
+            *reinterpret_cast<u32x4*>(&atile[buf][row * 1024 + ((q ^ (row & 15)) << 4)]) = areg[j];
+        }
+    };
+    u32x4 wcur[4], wnext[4];
+    auto load_w = [&](u32x4* w, int round) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int s = round * 4 + u;
+            w[u] = u32x4{0, 0, 0, 0};
+            if (s < nsteps) w[u] = *reinterpret_cast<const u32x4*>(wrow + (size_t)s * 64);
+        }
+    };
+    if (rd_lo < rd_hi) {
+        load_a(rd_lo);
+        load_w(wcur, rd_lo);
+    }
+    for (int rd = rd_lo; rd < rd_hi; rd++) {
+        const int buf = (rd - rd_lo) & 1;
+        store_a(buf);
+        __syncthreads();
+        if (rd + 1 < rd_hi) {
+            load_a(rd + 1);
+            load_w(wnext, rd + 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int dd = 0; dd < 4; dd++) {
+                const f16x8 b = dequant_s4x8(wcur[u][dd]);
+                const int q = u * 16 + g * 4 + dd;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const int row = mt * 16 + r;
+                    const u32x4 a = *reinterpret_cast<const u32x4*>(&atile[buf][row * 1024 + ((q ^ (row & 15)) << 4)]);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(shuffle_act8(a), b, acc[mt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < 4; u++) wcur[u] = wnext[u];
+    }
+    if (S > 1) {
+        float* my = part + (((size_t)split * gridDim.x + nb) * 4 + wave) * (MT * 256);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) my[mt * 256 + reg * 64 + lane] = acc[mt][reg];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(cnt + nb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag = ticket == S - 1;
+        }
+        __syncthreads();
+        if (!flag) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(cnt + nb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        float pv[8][MT][4];  // up to 8 K blocks: all partial loads in flight before the first add
+#pragma unroll
+        for (int s2 = 0; s2 < 8; s2++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    pv[s2][mt][reg] = 0.0f;
+                    if (s2 < S)
+                        pv[s2][mt][reg] = part[(((size_t)s2 * gridDim.x + nb) * 4 + wave) * (MT * 256) + mt * 256 + reg * 64 + lane];
+                }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                float sum = pv[0][mt][reg];
+#pragma unroll
+                for (int s2 = 1; s2 < 8; s2++)
+                    if (s2 < S) sum += pv[s2][mt][reg];
+                acc[mt][reg] = sum;
+            }
+    }
+    const int n = tile_row<EPI>(tb, r, ea);
+    const float swn = h2f(ws[n]);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int row16 = 4 * g + reg;
+            const int m = mt * 16 + row16;
+            const bool valid = m < M;
+            float v = acc[mt][reg] * swn;
+            if (bias) v = v + h2f(bias[n]);
+            epilogue_store<EPI>(f2h(v), valid, m, r, tb, N, out, &ex[wave][mt][0], row16 * 16 + r, ea);
+        }
+}
+
+size_t gemm_w4a16_ws_bytes() { return QS_W16_CNT_SLOTS * sizeof(int) + QS_W16_PART_BYTES; }
+
 template <int EPI>
 static int launch_w4a16(const f16* x, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M, int N, int K,
-                        const EpiArgs& ea, hipStream_t st) {
+                        const EpiArgs& ea, void* wsp, hipStream_t st) {
+    // 2-D kernel where its activation sharing pays: wide layers (enough 64-row blocks without K blocks) and long K;
+    // the narrow K = 4096 layers are faster on the 16-row kernel (no split merge: ~4 us of fences and tickets)
+    if (N % 64 == 0 && M <= 32 && (N / 64 >= 192 || K >= 8192)) {
+        const int nblocks = N / 64, nrounds = (K / 128 + 3) / 4, MT = M <= 16 ? 1 : 2;
+        int S = 1;
+        if (wsp && nblocks <= QS_W16_CNT_SLOTS) {
+            S = (256 + nblocks - 1) / nblocks;
+            if (S > 8) S = 8;
+            while (S > 1 && nrounds / S < 2) S--;
+            while (S > 1 && (size_t)S * nblocks * 4 * MT * 256 * sizeof(float) > QS_W16_PART_BYTES) S--;
+        }
+        const int rounds_per = (nrounds + S - 1) / S;
+        S = (nrounds + rounds_per - 1) / rounds_per;  // no empty K blocks
+        int* cnt = reinterpret_cast<int*>(wsp);
+        float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(wsp) + QS_W16_CNT_SLOTS * sizeof(int));
+        if (MT == 1)
+            hipLaunchKernelGGL((gemm_w4a16_2d_kernel<1, EPI>), dim3(nblocks, S), dim3(256), 0, st, x, wq, ws, bias, out, M, N, K, rounds_per, cnt, part, ea);
+        else
+            hipLaunchKernelGGL((gemm_w4a16_2d_kernel<2, EPI>), dim3(nblocks, S), dim3(256), 0, st, x, wq, ws, bias, out, M, N, K, rounds_per, cnt, part, ea);
+        return 0;
+    }
     for (int mb = 0; mb < M; mb += 32) {
         int rows = M - mb;
         if (rows <= 16)
@@ -365,28 +562,28 @@ static int launch_w4a16(const f16* x, const int8_t* wq, const f16* ws, const f16
 }
 
 int gemm_w4a16(const f16* x, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M, int N, int K,
-               hipStream_t st) {
+               void* wsp, hipStream_t st) {
     if (M == 0 || N == 0) return 0;
     if (N % 16 || K % 128) return -1;
-    return launch_w4a16<EPI_PLAIN>(x, wq, ws, bias, out, M, N, K, EpiArgs{}, st);
+    return launch_w4a16<EPI_PLAIN>(x, wq, ws, bias, out, M, N, K, EpiArgs{}, wsp, st);
 }
 
 int gemm_w4a16_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                         const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
-                        const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st) {
+                        const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, void* wsp, hipStream_t st) {
     if (M == 0) return 0;
     if (check_qkv(N, K, nq, nkv, d, rot_dim)) return -1;
     EpiArgs ea{positions, cos_sin_cache, key_cache, value_cache, slot_mapping, nq, nkv, 0};
-    return launch_w4a16<EPI_QKV>(x, wq, ws, nullptr, qkv, M, N, K, ea, st);
+    return launch_w4a16<EPI_QKV>(x, wq, ws, nullptr, qkv, M, N, K, ea, wsp, st);
 }
 
-int gemm_w4a16_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K,
+int gemm_w4a16_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K, void* wsp,
                             hipStream_t st) {
     if (M == 0) return 0;
     if (I % 8 || K % 128) return -1;
     EpiArgs ea{};
     ea.I = I;
-    return launch_w4a16<EPI_GATEUP>(x, wq, ws, nullptr, act, M, 2 * I, K, ea, st);
+    return launch_w4a16<EPI_GATEUP>(x, wq, ws, nullptr, act, M, 2 * I, K, ea, wsp, st);
 }
 
 // ------------------------------------------------------------------ fp16 x fp16^T (lm_head)

@@ -26,17 +26,18 @@ int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t*
 // gemm.hip
 int gemm_w4a4(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M,
               int N, int K, hipStream_t st);
+size_t gemm_w4a16_ws_bytes();
 int gemm_w4a16(const f16* x, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M, int N, int K,
-               hipStream_t st);
+               void* wsp, hipStream_t st);
 int gemm_w4a4_qkv_rope(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                        const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
                        const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st);
 int gemm_w4a16_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                         const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
-                        const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st);
+                        const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, void* wsp, hipStream_t st);
 int gemm_w4a4_gate_up_silu(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, f16* act, int M, int I,
                            int K, hipStream_t st);
-int gemm_w4a16_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K,
+int gemm_w4a16_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K, void* wsp,
                             hipStream_t st);
 int gemm_f16(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st);
 int dequant_w4(const int8_t* wq, const f16* ws, f16* out, int N, int K, hipStream_t st);

@@ -154,14 +154,15 @@ def qkv_rope_linear(x, x_scale, wq, w_scale, qkv, positions, cos_sin_cache, key_
     M = x.shape[0]
     common = (_chk(positions, "positions", _I64), _chk(cos_sin_cache, "cos_sin_cache", _F16),
               _chk(key_cache, "key_cache", _F16), _chk(value_cache, "value_cache", _F16),
-              _chk(slot_mapping, "slot_mapping", _I64), num_heads, num_kv_heads, head_size, cos_sin_cache.shape[-1],
-              _stream())
+              _chk(slot_mapping, "slot_mapping", _I64), num_heads, num_kv_heads, head_size, cos_sin_cache.shape[-1])
     if x_scale is not None:
         _call("qspec_qkv_rope_linear_s4s4", _chk(x, "xq", (_I8, _U8)), _chk(x_scale, "x_scale", _F16),
-              _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16), _chk(qkv, "qkv", _F16), M, N, K, *common)
+              _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16), _chk(qkv, "qkv", _F16), M, N, K, *common,
+              _stream())
     else:
         _call("qspec_qkv_rope_linear_w4a16", _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)),
-              _chk(w_scale, "w_scale", _F16), _chk(qkv, "qkv", _F16), M, N, K, *common)
+              _chk(w_scale, "w_scale", _F16), _chk(qkv, "qkv", _F16), M, N, K, *common,
+              w4a16_workspace(x.device).data_ptr(), _stream())
     return qkv
 
 
@@ -175,7 +176,8 @@ def gate_up_silu_linear(x, x_scale, wq, w_scale, act):
               _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16), _chk(act, "act", _F16), M, I, K, _stream())
     else:
         _call("qspec_gate_up_silu_linear_w4a16", _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)),
-              _chk(w_scale, "w_scale", _F16), _chk(act, "act", _F16), M, I, K, _stream())
+              _chk(w_scale, "w_scale", _F16), _chk(act, "act", _F16), M, I, K, w4a16_workspace(x.device).data_ptr(),
+              _stream())
     return act
 
 
@@ -193,6 +195,18 @@ def rowwise_scaled_linear_cutlass_s4s4_unified(xq, x_scale, wq, w_scale, bias, o
     return out
 
 
+_w16_ws = {}
+
+
+def w4a16_workspace(device):
+    """Zero-initialised split-K scratch of the W4A16 kernels, one per device (calls on one stream are serialised,
+    so they can share it; every call leaves the ticket counters at zero)."""
+    key = str(device)
+    if key not in _w16_ws:
+        _w16_ws[key] = torch.zeros(int(_lib.load().qspec_w4a16_workspace_bytes()), dtype=torch.uint8, device=device)
+    return _w16_ws[key]
+
+
 def w4a16_linear(x, wq, w_scale, out, bias=None):
     """bitblas.Matmul(x, w ^ 0x88, output=out, scale=w_scale, bias=bias) on the SAME packed buffer
     (quarot_nn/linear.py:122)."""
@@ -201,7 +215,7 @@ def w4a16_linear(x, wq, w_scale, out, bias=None):
     if wq.shape[1] * 2 != K:
         raise RuntimeError(f"x and wq disagree on K: {x.shape} vs {wq.shape}")
     _call("qspec_w4a16_linear", _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
-          _opt(bias, "bias", _F16), _chk(out, "out", _F16), M, N, K, _stream())
+          _opt(bias, "bias", _F16), _chk(out, "out", _F16), M, N, K, w4a16_workspace(x.device).data_ptr(), _stream())
     return out
 
 
