@@ -235,6 +235,13 @@ int qspec_spec_prepare_verify(int batch, int k, int block_size, const int64_t* l
 int qspec_spec_commit(int batch, int k, const int64_t* out_tokens, int32_t* seq_lens, int64_t* last_token,
                       int64_t* gen_tokens, int32_t* gen_lens, int gen_capacity, void* stream);
 
+/* Synthetic-workload knob for bench.py only (no reference counterpart): with probability rho raise the target logit of
+ * the proposed token (verify logits [batch*(k+1), vocab]) so that random weights reproduce a chosen draft/target
+ * agreement; the kernels of the cycle run unchanged. */
+int qspec_bench_force_agreement(qspec_half* target_logits, const int64_t* draft_token_ids, int64_t ids_stride_b,
+                                int64_t ids_stride_k, float rho, const uint64_t* rng_state, int batch, int k, int vocab,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,14 +27,14 @@ class OracleModel:
         self.sm_scale = cfg.head_dim ** -0.5
 
     @classmethod
-    def from_torch_model(cls, m, block_size):
+    def from_torch_model(cls, m, block_size, max_layers=None):
         """Copy the weights of a qspec_amd.model.QuarotLlamaForCausalLM to the host (same bytes)."""
         c = lambda t: t.detach().cpu().numpy()  # noqa: E731
         layers = [dict(qkv_w=c(l.qkv_proj.weight), qkv_s=c(l.qkv_proj.weight_scales).reshape(-1),
                        o_w=c(l.o_proj.weight), o_s=c(l.o_proj.weight_scales).reshape(-1),
                        gate_up_w=c(l.gate_up.weight), gate_up_s=c(l.gate_up.weight_scales).reshape(-1),
                        down_w=c(l.down_proj.weight), down_s=c(l.down_proj.weight_scales).reshape(-1))
-                  for l in m.layers]
+                  for l in (m.layers if max_layers is None else m.layers[:max_layers])]
         had = c(m.had_rem_dim) if m.had_rem_dim is not None else None
         return cls(m.config, layers, c(m.embed_tokens), c(m.lm_head), had, m.had_K, c(m.cos_sin_cache), block_size)
 
@@ -105,6 +105,8 @@ class OracleEngine:
         self.last_token = np.zeros(B, np.int64)
         self.generated = [[] for _ in range(B)]
         self.counters = [0, 0, 0]
+        self.agreement_rho = None  # bench-only synthetic agreement (see qspec_bench_force_agreement)
+        self._agree_rng = np.random.default_rng(1234)
 
     def _slots(self, b, pos):
         pos = np.asarray(pos)
@@ -149,7 +151,13 @@ class OracleEngine:
         vs = np.concatenate([self._slots(b, np.arange(self.seq_lens[b] - 1, self.seq_lens[b] + k)) for b in range(B)])
         hs = m.forward(vt, vp, self.kv, vs, self.block_tables, (self.seq_lens + k).astype(np.int32),
                        (np.arange(B + 1) * (k + 1)).astype(np.int32), w4a4=False)
-        tp, tt = O.softmax_argmax(m.logits(hs))
+        logits = m.logits(hs)
+        if self.agreement_rho is not None:
+            for b in range(B):
+                for i in range(k):
+                    if self._agree_rng.random() < self.agreement_rho:
+                        logits[b * (k + 1) + i, draft_ids[b, i]] = np.float16(60000.0)
+        tp, tt = O.softmax_argmax(logits)
         tp, tt = tp.reshape(B, k + 1, V), tt.reshape(B, k + 1)
         out, accepted, recovered, c = O.rejection_sample(tp, tt[:, k], draft_probs, draft_ids, uniform, exponential)
         if forced_out is not None:

@@ -189,8 +189,11 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
     const int r0 = rb * QS_ATT_MAXR;
     const int R = min(QS_ATT_MAXR, (qlen << group_log2) - r0);
     if (R <= 0) return;  // uniform for the whole workgroup
-    const int k_begin = split * QS_ATT_CHUNK;
-    const int nkeys = max(0, min(ctx, k_begin + QS_ATT_CHUNK) - k_begin);
+    // keys per split adapt to the sequence: ceil(ctx / n_splits) rounded up to a 16-key tile (<= 128), so that a
+    // short context still spreads over all n_splits workgroups (each CU only draws ~25 GB/s)
+    const int chunk = min(QS_ATT_CHUNK, (((ctx + n_splits - 1) / n_splits) + 15) & ~15);
+    const int k_begin = split * chunk;
+    const int nkeys = max(0, min(ctx, k_begin + chunk) - k_begin);
     const int c16 = lane & 15, g4 = lane >> 4;
     const int32_t* bt = block_tables + (size_t)seq * max_blocks;
 #ifdef QS_ATT_STAMPS

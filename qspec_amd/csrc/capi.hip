@@ -322,4 +322,13 @@ int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const
     return finish(op, qspec::gemm_w4a16_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, workspace, ST));
 }
 
+int qspec_bench_force_agreement(qspec_half* target_logits, const int64_t* draft_token_ids, int64_t ids_stride_b,
+                                int64_t ids_stride_k, float rho, const uint64_t* rng_state, int batch, int k, int vocab,
+                                void* stream) {
+    const char* op = "qspec_bench_force_agreement";
+    if (batch == 0) return 0;
+    NONNULL(op, target_logits); NONNULL(op, draft_token_ids); NONNULL(op, rng_state);
+    return finish(op, qspec::spec_force_agreement(H(target_logits), draft_token_ids, ids_stride_b, ids_stride_k, rho, rng_state, batch, k, vocab, ST));
+}
+
 }  // extern "C"

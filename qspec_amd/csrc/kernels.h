@@ -68,6 +68,8 @@ int rejection_sample(const float* target_probs, const float* draft_probs, const 
 int advance_step(int n, int block_size, int64_t* input_tokens, const int64_t* sampled, int64_t* positions,
                  int32_t* seq_lens, int64_t* slot_mapping, const int32_t* block_tables, int64_t bt_stride,
                  hipStream_t st);
+int spec_force_agreement(f16* logits, const int64_t* draft_ids, int64_t di_sb, int64_t di_sk, float rho,
+                         const uint64_t* rng_state, int B, int k, int V, hipStream_t st);
 int spec_prepare_draft(int B, int block_size, const int64_t* last_token, const int32_t* seq_lens,
                        const int32_t* block_tables, int64_t bt_stride, int64_t* input_tokens, int64_t* positions,
                        int64_t* slot_mapping, int32_t* ctx_lens, hipStream_t st);

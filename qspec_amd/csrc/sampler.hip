@@ -398,6 +398,30 @@ __global__ void spec_commit_kernel(int B, int k, const int64_t* __restrict__ out
         if (gen_lens) gen_lens[b] += n;
     }
 }
+// Synthetic-workload knob (bench only): random int4 weights give a draft/target agreement near zero, a trained QSpec
+// checkpoint ~0.96.  With probability rho the target logit of the proposed token is raised to the fp16
+// maximum, so the verify pass "agrees" with the draft at a controlled rate.  Every kernel of the cycle still runs
+// on the same shapes; only the token values change.  Philox keyed by rng_state, offset bumped by 1<<32 lanes apart.
+__global__ void spec_force_agreement_kernel(f16* __restrict__ logits, const int64_t* __restrict__ draft_ids,
+                                            int64_t di_sb, int64_t di_sk, float rho,
+                                            const uint64_t* __restrict__ rng_state, int B, int k, int V) {
+    const int bk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bk >= B * k) return;
+    const int b = bk / k, i = bk % k;
+    uint32_t r[4];
+    philox4x32(0xA5A5A5A5u, (uint32_t)bk, (uint32_t)rng_state[1], (uint32_t)(rng_state[1] >> 32), (uint32_t)rng_state[0],
+               (uint32_t)(rng_state[0] >> 32) ^ 0x51ED27u, r);
+    if ((float)(r[0] >> 8) * (1.0f / 16777216.0f) < rho)
+        logits[((size_t)b * (k + 1) + i) * V + draft_ids[b * di_sb + i * di_sk]] = (f16)60000.0f;
+}
+int spec_force_agreement(f16* logits, const int64_t* draft_ids, int64_t di_sb, int64_t di_sk, float rho,
+                         const uint64_t* rng_state, int B, int k, int V, hipStream_t st) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(spec_force_agreement_kernel, dim3((B * k + 63) / 64), dim3(64), 0, st, logits, draft_ids, di_sb,
+                       di_sk, rho, rng_state, B, k, V);
+    return 0;
+}
+
 int spec_prepare_draft(int B, int block_size, const int64_t* last_token, const int32_t* seq_lens,
                        const int32_t* block_tables, int64_t bt_stride, int64_t* input_tokens, int64_t* positions,
                        int64_t* slot_mapping, int32_t* ctx_lens, hipStream_t st) {

@@ -369,3 +369,12 @@ def spec_commit(out_tokens, seq_lens, last_token, gen_tokens=None, gen_lens=None
     _call("qspec_spec_commit", B, k1 - 1, _chk(out_tokens, "out_tokens", _I64), _chk(seq_lens, "seq_lens", _I32),
           _chk(last_token, "last_token", _I64), _opt(gen_tokens, "gen_tokens", _I64),
           _opt(gen_lens, "gen_lens", _I32), cap, _stream())
+
+
+def bench_force_agreement(target_logits, draft_token_ids, rho: float, rng_state):
+    """bench.py only: raise the target logit of the proposed token with probability rho (synthetic agreement)."""
+    B, k = draft_token_ids.shape
+    V = target_logits.shape[-1]
+    _call("qspec_bench_force_agreement", _chk(target_logits, "target_logits", _F16), draft_token_ids.data_ptr(),
+          draft_token_ids.stride(0), draft_token_ids.stride(1), float(rho), _chk(rng_state, "rng_state", _I64), B, k, V,
+          _stream())

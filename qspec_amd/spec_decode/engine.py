@@ -28,8 +28,14 @@ from .rejection_sampler import RejectionSampler
 ATTN_CHUNK = 128  # keys per context split of the attention kernel (QS_ATT_CHUNK)
 
 
-def n_splits_for(ctx: int) -> int:
-    return max(1, (ctx + ATTN_CHUNK - 1) // ATTN_CHUNK)
+def n_splits_for(ctx: int, n_groups: int = 0) -> int:
+    """Context splits of the attention kernel: enough 128-key chunks for the longest context, and at least enough
+    workgroups (n_groups = sequences x kv heads x row blocks) to occupy the 256 CUs; the kernel shrinks the chunk
+    to ceil(ctx / n_splits) for shorter contexts."""
+    need = max(1, (ctx + ATTN_CHUNK - 1) // ATTN_CHUNK)
+    if n_groups > 0:
+        need = max(need, min(16, (256 + n_groups - 1) // n_groups))
+    return need
 
 
 class QSpecEngine:
@@ -60,7 +66,7 @@ class QSpecEngine:
         self.n_active = 0
         # ---- per-cycle buffers
         V = cfg.vocab_size
-        n_splits = n_splits_for(max_model_len)
+        n_splits = n_splits_for(max_model_len, B * cfg.num_key_value_heads)
         self.d_tokens = torch.zeros(B, dtype=i64, device=dev)
         self.d_pos = torch.zeros(B, dtype=i64, device=dev)
         self.d_slots = torch.zeros(B, dtype=i64, device=dev)
@@ -90,6 +96,8 @@ class QSpecEngine:
         self.inject_uniform: Optional[torch.Tensor] = None
         self.inject_exponential: Optional[torch.Tensor] = None
         self._prefill_scratch: Optional[Scratch] = None
+        # bench-only synthetic agreement between draft and target (None = the weights' own agreement)
+        self.agreement_rho: Optional[float] = None
 
     # ------------------------------------------------------------------ prefill (_run_no_spec, :666-720)
     @torch.no_grad()
@@ -146,6 +154,8 @@ class QSpecEngine:
                                 self.v_pos, self.v_slots, self.v_ctx)
         hs = m.forward(self.v_tokens, self.v_pos, self.kv_caches, self.md_verify, self.scratch_verify, w4a4=False)
         logits = m.compute_logits(hs, self.scratch_verify)
+        if self.agreement_rho is not None:
+            ops.bench_force_agreement(logits, draft_ids, self.agreement_rho, self.sampler.rng_state)
         ops.softmax_argmax(logits, self.target_probs.view(B * (k + 1), -1), self.target_tokens.view(-1))
         # _verify_tokens (:861-970): bonus = the target's own token at the last position
         self.sampler.forward(self.target_probs, self.target_tokens[:, k], draft_probs, draft_ids, out=self.out_tokens,
