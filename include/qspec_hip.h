@@ -136,6 +136,18 @@ int qspec_gate_up_silu_linear_s4s4(const int8_t* xq, const qspec_half* xs, const
 int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
                                     int intermediate, int K, void* workspace, void* stream);
 
+/* Tensor-parallel views of the SAME buffers (no reference counterpart: the reference QSpec model has no TP).
+ * _ksliced: row-parallel shard = a K range of x [M, *] (row stride ldx halves) and of wq [N, *] (row stride ldw_bytes);
+ *           the caller all-reduces the partial outputs.
+ * _shard:   column-parallel shard of gate_up = intermediate channels [first_channel, first_channel + num_channels);
+ *           act keeps its full [M, intermediate] layout, only the shard's columns are written. */
+int qspec_w4a16_linear_ksliced(const qspec_half* x, int64_t ldx, const int8_t* wq, int64_t ldw_bytes,
+                               const qspec_half* ws, qspec_half* out, int M, int N, int K, void* workspace,
+                               void* stream);
+int qspec_gate_up_silu_linear_w4a16_shard(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act,
+                                          int M, int intermediate, int K, int first_channel, int num_channels,
+                                          void* workspace, void* stream);
+
 /* lm_head: F.linear(hidden, lm_head.weight)  (vllm/model_executor/layers/logits_processor.py:92-97). w [N,K] fp16. */
 int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, int M, int N, int K, void* stream);
 

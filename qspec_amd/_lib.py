@@ -40,6 +40,8 @@ SIGNATURES = {
     "qspec_rowwise_scaled_linear_s4s4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_w4a16_workspace_bytes": (_sz, []),
     "qspec_w4a16_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "qspec_w4a16_linear_ksliced": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "qspec_gate_up_silu_linear_w4a16_shard": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "qspec_linear_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_dequant_w4": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "qspec_rotary_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _vp]),

@@ -319,7 +319,7 @@ int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const
     const char* op = "qspec_gate_up_silu_linear_w4a16";
     if (M == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
-    return finish(op, qspec::gemm_w4a16_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, workspace, ST));
+    return finish(op, qspec::gemm_w4a16_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, 0, intermediate, workspace, ST));
 }
 
 int qspec_bench_force_agreement(qspec_half* target_logits, const int64_t* draft_token_ids, int64_t ids_stride_b,
@@ -329,6 +329,24 @@ int qspec_bench_force_agreement(qspec_half* target_logits, const int64_t* draft_
     if (batch == 0) return 0;
     NONNULL(op, target_logits); NONNULL(op, draft_token_ids); NONNULL(op, rng_state);
     return finish(op, qspec::spec_force_agreement(H(target_logits), draft_token_ids, ids_stride_b, ids_stride_k, rho, rng_state, batch, k, vocab, ST));
+}
+
+int qspec_w4a16_linear_ksliced(const qspec_half* x, int64_t ldx, const int8_t* wq, int64_t ldw_bytes,
+                               const qspec_half* ws, qspec_half* out, int M, int N, int K, void* workspace,
+                               void* stream) {
+    const char* op = "qspec_w4a16_linear_ksliced";
+    if (M == 0 || N == 0) return 0;
+    NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, out);
+    if (N % 16 || K % 128 || ldw_bytes % 16 || ldx % 8) return fail("%s: need N%%16, K%%128, ldw%%16, ldx%%8 == 0", op);
+    return finish(op, qspec::gemm_w4a16_strided(CH(x), ldx, wq, ldw_bytes, CH(ws), H(out), M, N, K, workspace, ST));
+}
+int qspec_gate_up_silu_linear_w4a16_shard(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act,
+                                          int M, int intermediate, int K, int first_channel, int num_channels,
+                                          void* workspace, void* stream) {
+    const char* op = "qspec_gate_up_silu_linear_w4a16_shard";
+    if (M == 0 || num_channels == 0) return 0;
+    NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
+    return finish(op, qspec::gemm_w4a16_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, first_channel, num_channels, workspace, ST));
 }
 
 }  // extern "C"

@@ -62,6 +62,9 @@ struct EpiArgs {
     const int64_t* slot_mapping;  // [M]
     int nq, nkv;
     int I;                      // intermediate size (EPI_GATEUP)
+    int tb0;                    // first tile of this launch (tensor-parallel column shards launch a sub-range)
+    int64_t ldw;                // bytes between packed weight rows (0 = K/2): K-sliced views of the shared buffer
+    int64_t ldx;                // halves between fp16 activation rows (0 = K)
 };
 
 template <int EPI>
@@ -125,10 +128,11 @@ __global__ __launch_bounds__(256) void gemm_w4a4_kernel(const int8_t* __restrict
     __shared__ f16 ex[MT][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int tb = blockIdx.x;
+    const int tb = blockIdx.x + ea.tb0;
     const int Kb = K >> 1;
     const int nsteps = Kb >> 6;  // 64 bytes of every row per step
-    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)tile_row<EPI>(tb, r, ea) * Kb + g * 16;
+    const size_t ldw = ea.ldw ? (size_t)ea.ldw : (size_t)Kb;
+    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)tile_row<EPI>(tb, r, ea) * ldw + g * 16;
     const uint8_t* arow[MT];
     bool aval[MT];
 #pragma unroll
@@ -300,11 +304,12 @@ __global__ __launch_bounds__(256) void gemm_w4a16_kernel(const f16* __restrict__
     __shared__ f16 ex[MT][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int tb = blockIdx.x;
+    const int tb = blockIdx.x + ea.tb0;
     const int Kb = K >> 1;
     const int nsteps = Kb >> 6;              // 64 packed bytes (128 k) of every weight row per step
     const int nrounds = (nsteps + 3) >> 2;   // 4 steps (one per wave) per round
-    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)tile_row<EPI>(tb, r, ea) * Kb + g * 16;
+    const size_t ldw = ea.ldw ? (size_t)ea.ldw : (size_t)Kb, ldx = ea.ldx ? (size_t)ea.ldx : (size_t)K;
+    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)tile_row<EPI>(tb, r, ea) * ldw + g * 16;
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256) void gemm_w4a16_kernel(const f16* __restrict__
             const int m = m_base + row;
             const size_t koff = (size_t)round * 512 + q * 8;  // halves
             areg[j] = u32x4{0, 0, 0, 0};
-            if (m < M && koff < (size_t)K) areg[j] = *reinterpret_cast<const u32x4*>(x + (size_t)m * K + koff);
+            if (m < M && koff < (size_t)K) areg[j] = *reinterpret_cast<const u32x4*>(x + (size_t)m * ldx + koff);
         }
     };
     auto store_a = [&](int buf) {
@@ -402,12 +407,13 @@ __global__ __launch_bounds__(256) void gemm_w4a16_2d_kernel(const f16* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int nb = blockIdx.x, S = gridDim.y, split = blockIdx.y;
-    const int tb = nb * 4 + wave;
+    const int tb = nb * 4 + wave + ea.tb0;
     const int Kb = K >> 1;
     const int nsteps = Kb >> 6;
     const int nrounds = (nsteps + 3) >> 2;
     const int rd_lo = split * rounds_per, rd_hi = min(nrounds, rd_lo + rounds_per);
-    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)tile_row<EPI>(tb, r, ea) * Kb + g * 16;
+    const size_t ldw = ea.ldw ? (size_t)ea.ldw : (size_t)Kb, ldx = ea.ldx ? (size_t)ea.ldx : (size_t)K;
+    const uint8_t* wrow = reinterpret_cast<const uint8_t*>(wq) + (size_t)tile_row<EPI>(tb, r, ea) * ldw + g * 16;
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(256) void gemm_w4a16_2d_kernel(const f16* __restric
             const int c = tid + 256 * j, row = c >> 6, q = c & 63;
             const size_t koff = (size_t)round * 512 + q * 8;
             areg[j] = u32x4{0, 0, 0, 0};
-            if (row < M && koff < (size_t)K) areg[j] = *reinterpret_cast<const u32x4*>(x + (size_t)row * K + koff);
+            if (row < M && koff < (size_t)K) areg[j] = *reinterpret_cast<const u32x4*>(x + (size_t)row * ldx + koff);
         }
     };
     auto store_a = [&](int buf) {
@@ -568,6 +574,17 @@ int gemm_w4a16(const f16* x, const int8_t* wq, const f16* ws, const f16* bias, f
     return launch_w4a16<EPI_PLAIN>(x, wq, ws, bias, out, M, N, K, EpiArgs{}, wsp, st);
 }
 
+// K-sliced (row-parallel) view: x [M, K] with row stride ldx halves, wq [N, K/2] with row stride ldw bytes.
+int gemm_w4a16_strided(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, const f16* ws, f16* out, int M, int N,
+                       int K, void* wsp, hipStream_t st) {
+    if (M == 0 || N == 0) return 0;
+    if (N % 16 || K % 128 || ldw % 16 || ldx % 8) return -1;
+    EpiArgs ea{};
+    ea.ldw = ldw;
+    ea.ldx = ldx;
+    return launch_w4a16<EPI_PLAIN>(x, wq, ws, nullptr, out, M, N, K, ea, wsp, st);
+}
+
 int gemm_w4a16_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                         const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
                         const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, void* wsp, hipStream_t st) {
@@ -577,13 +594,15 @@ int gemm_w4a16_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv,
     return launch_w4a16<EPI_QKV>(x, wq, ws, nullptr, qkv, M, N, K, ea, wsp, st);
 }
 
-int gemm_w4a16_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K, void* wsp,
-                            hipStream_t st) {
-    if (M == 0) return 0;
-    if (I % 8 || K % 128) return -1;
+int gemm_w4a16_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K, int ch0,
+                            int nch, void* wsp, hipStream_t st) {
+    // channels [ch0, ch0 + nch) of the intermediate dimension (column-parallel shard; nch = I for all of it)
+    if (M == 0 || nch == 0) return 0;
+    if (I % 8 || K % 128 || ch0 % 8 || nch % 8 || ch0 + nch > I) return -1;
     EpiArgs ea{};
     ea.I = I;
-    return launch_w4a16<EPI_GATEUP>(x, wq, ws, nullptr, act, M, 2 * I, K, ea, wsp, st);
+    ea.tb0 = ch0 / 8;
+    return launch_w4a16<EPI_GATEUP>(x, wq, ws, nullptr, act, M, 2 * nch, K, ea, wsp, st);
 }
 
 // ------------------------------------------------------------------ fp16 x fp16^T (lm_head)

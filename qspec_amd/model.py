@@ -131,6 +131,7 @@ class QuarotLlamaForCausalLM:
         # module-wise mirrors share the same buffers
         self.norm = quarot_nn.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
         self.quantizer = quarot_nn.Quantizer()
+        self.tp = None   # qspec_amd.parallel.TensorParallel for the verify pass (None = single GPU)
 
     # ------------------------------------------------------------------ weights
     @torch.no_grad()
@@ -183,6 +184,8 @@ class QuarotLlamaForCausalLM:
         normed, had, had_mlp = s.normed[:T], s.act_buffer_had[:T], s.act_buffer_had_mlp[:T]
         row = cfg.q_size + 2 * cfg.kv_size
         fuse = cfg.head_dim == 128 and (w4a4 or T <= self.BIG_M)   # fused GEMM epilogues (decode-sized M)
+        # tensor parallelism only on the verify pass at decode-sized M; the draft pass and prefill run replicated
+        tp_on = self.tp is not None and self.tp.world > 1 and not w4a4 and fuse and T <= 32
         act = s.act_buffer_had_mlp[:T]                            # silu(gate)*up, [T, I]
         nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         for li, layer in enumerate(self.layers):
@@ -215,12 +218,23 @@ class QuarotLlamaForCausalLM:
                 x, xs = q1, sc
             else:
                 ops.heads_hadamard(attn, self.head_had_scale, out_f16=had, heads=nh)
-                self._w4a16(had, layer.o_proj, o)
+                if tp_on:   # row-parallel o_proj over this rank's K range of the shared buffer, then all-reduce
+                    k0, k1 = self.tp.k_range(cfg.hidden_size)
+                    ops.w4a16_linear_ksliced(had, layer.o_proj.weight, layer.o_proj._scales(), o, k0, k1)
+                    self.tp.all_reduce(o)
+                else:
+                    self._w4a16(had, layer.o_proj, o)
                 ops.add_rms_norm_fp16(normed, hidden, hidden, o, eps)
                 x, xs = normed, None
             # gate_up -> silu*up -> online hadamard (+ quant) -> down_proj                              :266-299
             if fuse:
-                ops.gate_up_silu_linear(x, xs, gu_w, gu_s, act)
+                if tp_on:   # column-parallel gate_up: own channels into a zeroed [T, I], all-reduce = concatenation
+                    c0, c1 = self.tp.channel_range(cfg.intermediate_size)
+                    act.zero_()
+                    ops.gate_up_silu_linear_shard(x, gu_w, gu_s, act, c0, c1 - c0)
+                    self.tp.all_reduce(act)
+                else:
+                    ops.gate_up_silu_linear(x, xs, gu_w, gu_s, act)
                 if w4a4:
                     ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, q=q3, scale=sc)
                 else:
@@ -236,6 +250,10 @@ class QuarotLlamaForCausalLM:
                     had_mlp_in = had_mlp
             if w4a4:
                 ops.rowwise_scaled_linear_cutlass_s4s4_unified(q3, sc, layer.down_proj.weight, layer.down_proj._scales(), None, o)
+            elif tp_on:     # row-parallel down_proj
+                k0, k1 = self.tp.k_range(cfg.intermediate_size)
+                ops.w4a16_linear_ksliced(had_mlp_in, layer.down_proj.weight, layer.down_proj._scales(), o, k0, k1)
+                self.tp.all_reduce(o)
             else:
                 self._w4a16(had_mlp_in, layer.down_proj, o)
             delta = o
@@ -243,10 +261,16 @@ class QuarotLlamaForCausalLM:
         ops.add_rms_norm_fp16(normed, hidden, hidden, delta, eps)
         return normed
 
-    def compute_logits(self, hidden_states, scratch: Scratch):
-        """LogitsProcessor with a plain nn.Linear lm_head (vllm/model_executor/layers/logits_processor.py:92-97)."""
+    def compute_logits(self, hidden_states, scratch: Scratch, shard_vocab: bool = False):
+        """LogitsProcessor with a plain nn.Linear lm_head (vllm/model_executor/layers/logits_processor.py:92-97).
+        shard_vocab (verify pass under TP): this rank's vocab range + all-gather (logits_processor.py:104-107)."""
         T = hidden_states.shape[0]
         logits = scratch.logits[:T]
+        if shard_vocab and self.tp is not None and self.tp.world > 1:
+            v0, v1 = self.tp.vocab_range(self.config.vocab_size)
+            local = torch.empty(T, v1 - v0, dtype=torch.float16, device=self.device)
+            ops.linear_f16(hidden_states, self.lm_head[v0:v1], local)
+            return self.tp.all_gather_vocab(local, logits, self.config.vocab_size)
         ops.linear_f16(hidden_states, self.lm_head, logits)
         return logits
 

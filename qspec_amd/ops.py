@@ -219,6 +219,29 @@ def w4a16_linear(x, wq, w_scale, out, bias=None):
     return out
 
 
+def w4a16_linear_ksliced(x, wq, w_scale, out, k0: int, k1: int):
+    """Row-parallel shard: out = x[:, k0:k1] @ dequant(wq)[:, k0:k1]^T * w_scale (partial sum; caller all-reduces).
+    x [M,K] and wq [N,K/2] are the FULL tensors; only the K range is read."""
+    M, K = x.shape
+    N = wq.shape[0]
+    _chk(x, "x", _F16); _chk(wq, "wq", (_I8, _U8))
+    _call("qspec_w4a16_linear_ksliced", x.data_ptr() + 2 * k0, K, wq.data_ptr() + k0 // 2, K // 2,
+          _chk(w_scale, "w_scale", _F16), _chk(out, "out", _F16), M, N, k1 - k0, w4a16_workspace(x.device).data_ptr(),
+          _stream())
+    return out
+
+
+def gate_up_silu_linear_shard(x, wq, w_scale, act, ch0: int, nch: int):
+    """Column-parallel shard of the fused gate_up + silu*up: writes act[:, ch0:ch0+nch] (act is the full [M, I])."""
+    M = x.shape[0]
+    I = wq.shape[0] // 2
+    K = wq.shape[1] * 2
+    _call("qspec_gate_up_silu_linear_w4a16_shard", _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)),
+          _chk(w_scale, "w_scale", _F16), _chk(act, "act", _F16), M, I, K, ch0, nch,
+          w4a16_workspace(x.device).data_ptr(), _stream())
+    return act
+
+
 def linear_f16(x, w, out):
     M, K = x.shape
     N = w.shape[0]

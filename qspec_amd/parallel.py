@@ -1,0 +1,104 @@
+"""Tensor parallelism for the verify pass (option A).
+
+The reference QSpec model has no TP (plain nn.Embedding / Linear4bit / HF lm_head).  Design here:
+
+  * every rank holds the FULL packed int4 buffer (Llama-3-70B: 35 GB << 288 GB), the full KV cache and the
+    full embedding / lm_head; sharding is a *view* (K range or channel range) of the same bytes;
+  * the DRAFT pass runs replicated, with zero collectives: all kernels are deterministic, every rank computes
+    bit-identical tokens (the Philox state of the rejection sampler is seeded identically);
+  * the VERIFY pass (decode-sized M) shards the three weight-heavy GEMMs that tolerate it:
+        o_proj    row-parallel  (K range of the Hadamard output)          -> all-reduce [T, H]  fp16
+        gate_up   column-parallel (channel range, silu*up fused)          -> all-reduce [T, I]  fp16 of zero-padded
+                                                                             shards (= concatenation, exact)
+        down_proj row-parallel  (K range of the Hadamard output)          -> all-reduce [T, H]  fp16
+        lm_head   vocab-parallel                                          -> all-gather [T, V/tp]
+    qkv_proj + RoPE + KV write + attention stay replicated (the online Hadamards mix all heads / all of I and
+    the per-token abs-max needs the whole row, so their inputs must be complete on every rank anyway; replicated
+    attention also keeps every rank's KV cache identical without a KV exchange).
+  * collectives: RCCL through torch.distributed (backend "nccl" on ROCm), enqueued on the current stream and
+    captured into the cycle's hipGraph.  Messages are tiny (128 KB .. 460 KB): latency-bound over xGMI.
+
+`gloo` is supported for tests (CPU tensors, or GPU tensors staged through the host).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, world: int, rank: int, align: int) -> Tuple[int, int]:
+    """[lo, hi) of rank's contiguous shard of n items, every boundary a multiple of `align`."""
+    assert n % align == 0
+    units = n // align
+    base, rem = divmod(units, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo * align, hi * align
+
+
+class TensorParallel:
+    def __init__(self, rank: int, world: int, group: Optional[dist.ProcessGroup] = None):
+        self.rank, self.world, self.group = rank, world, group
+        self.backend = dist.get_backend(group) if world > 1 else "none"
+
+    def k_range(self, K: int) -> Tuple[int, int]:
+        """Row-parallel K range: multiples of 128 (one MFMA step of the W4A16 kernel)."""
+        return shard_range(K, self.world, self.rank, 128)
+
+    def channel_range(self, I: int) -> Tuple[int, int]:
+        """Column-parallel gate_up channels: multiples of 32 (4 tiles of 8 up + 8 gate rows: one 2-D workgroup)."""
+        return shard_range(I, self.world, self.rank, 32)
+
+    def vocab_range(self, V: int) -> Tuple[int, int]:
+        return shard_range(V, self.world, self.rank, 16)
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return t
+        if self.backend == "gloo" and t.is_cuda:
+            c = t.cpu()
+            dist.all_reduce(c, group=self.group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, group=self.group)
+        return t
+
+    def all_gather_vocab(self, local: torch.Tensor, out: torch.Tensor, V: int) -> torch.Tensor:
+        """local [T, V_r] (this rank's vocab range) -> out [T, V].  Ranges may differ by one 16-column tile, so the
+        shards travel zero-padded to the widest range and are cut back on arrival."""
+        if self.world == 1:
+            out.copy_(local)
+            return out
+        T = local.shape[0]
+        widths = [shard_range(V, self.world, r, 16) for r in range(self.world)]
+        wmax = max(hi - lo for lo, hi in widths)
+        send = local if local.shape[1] == wmax else torch.nn.functional.pad(local, (0, wmax - local.shape[1]))
+        recv = torch.empty(self.world * T, wmax, dtype=local.dtype, device=local.device)  # rank-major rows
+        if self.backend == "gloo" and local.is_cuda:
+            rc = recv.cpu()
+            dist.all_gather_into_tensor(rc, send.contiguous().cpu(), group=self.group)
+            recv.copy_(rc)
+        else:
+            dist.all_gather_into_tensor(recv, send.contiguous(), group=self.group)
+        for r, (lo, hi) in enumerate(widths):
+            out[:, lo:hi] = recv[r * T:(r + 1) * T, :hi - lo]
+        return out
+
+
+def init_from_env(device: str) -> TensorParallel:
+    """torchrun environment -> process group (RCCL).  MASTER_ADDR must be 127.0.0.1 on the single-node boxes."""
+    import os
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=torch.device(device))
+    return TensorParallel(rank, world, None)
+
+
+def build_tp_model(cfg, device: str, world: int, rank: int, seed: int = 0, lm_head_std: float = 0.02):
+    """Same synthetic weights on every rank (same seed), TP context attached."""
+    from .model import QuarotLlamaForCausalLM
+    m = QuarotLlamaForCausalLM(cfg, device).init_synthetic(seed, lm_head_std)
+    m.tp = TensorParallel(rank, world, None)
+    return m

@@ -153,7 +153,7 @@ class QSpecEngine:
         ops.spec_prepare_verify(self.last_token, draft_ids, self.seq_lens, self.block_tables, bs, self.v_tokens,
                                 self.v_pos, self.v_slots, self.v_ctx)
         hs = m.forward(self.v_tokens, self.v_pos, self.kv_caches, self.md_verify, self.scratch_verify, w4a4=False)
-        logits = m.compute_logits(hs, self.scratch_verify)
+        logits = m.compute_logits(hs, self.scratch_verify, shard_vocab=True)
         if self.agreement_rho is not None:
             ops.bench_force_agreement(logits, draft_ids, self.agreement_rho, self.sampler.rng_state)
         ops.softmax_argmax(logits, self.target_probs.view(B * (k + 1), -1), self.target_tokens.view(-1))
@@ -172,6 +172,9 @@ class QSpecEngine:
             return
         if self._graph is None:
             self._capture()
+            if not self.use_graph:
+                self._cycle_body()
+                return
         self._graph.replay()
 
     def _capture(self):
@@ -185,10 +188,20 @@ class QSpecEngine:
             self._cycle_body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._cycle_body()
-        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._cycle_body()
+            torch.cuda.synchronize()
+        except Exception as exc:  # e.g. a collective backend that cannot be captured: run eagerly, loudly
+            import warnings
+            warnings.warn(f"hipGraph capture of the cycle failed ({exc!r}); running the cycle eagerly")
+            self.use_graph = False
+            torch.cuda.synchronize()
+            for t, s in zip((self.seq_lens, self.last_token, self.gen_tokens, self.gen_lens, self.sampler.counters,
+                             self.sampler.rng_state), state):
+                t.copy_(s)
+            return
         for t, s in zip((self.seq_lens, self.last_token, self.gen_tokens, self.gen_lens, self.sampler.counters,
                          self.sampler.rng_state), state):
             t.copy_(s)

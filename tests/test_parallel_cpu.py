@@ -1,0 +1,66 @@
+"""World-size-2 gloo tests of the tensor-parallel plumbing (CPU only): shard ranges, all-reduce of zero-padded
+column shards == concatenation, vocab all-gather with uneven ranges."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from qspec_amd.parallel import TensorParallel, shard_range
+
+
+def test_shard_range_covers_and_aligns():
+    for n, world, align in ((4096, 8, 128), (14336, 8, 128), (14336, 8, 32), (128256, 8, 16), (2048, 3, 16), (3584, 2, 32)):
+        prev = 0
+        for r in range(world):
+            lo, hi = shard_range(n, world, r, align)
+            assert lo == prev and lo % align == 0 and hi % align == 0 and hi >= lo
+            prev = hi
+        assert prev == n
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tp = TensorParallel(rank, world, None)
+    T, I, V = 3, 64, 16 * 5   # V: 5 tiles over 2 ranks -> uneven vocab ranges
+    full = torch.arange(T * I, dtype=torch.float32).view(T, I).to(torch.float16)
+    c0, c1 = tp.channel_range(I)
+    act = torch.zeros(T, I, dtype=torch.float16)
+    act[:, c0:c1] = full[:, c0:c1]
+    tp.all_reduce(act)
+    ok1 = torch.equal(act, full)
+    # row-parallel partial sums
+    x = torch.full((T, 8), float(rank + 1))
+    tp.all_reduce(x)
+    ok2 = bool((x == sum(range(1, world + 1))).all())
+    logits_full = torch.arange(T * V, dtype=torch.float32).view(T, V).to(torch.float16)
+    v0, v1 = tp.vocab_range(V)
+    out = torch.empty(T, V, dtype=torch.float16)
+    tp.all_gather_vocab(logits_full[:, v0:v1].contiguous(), out, V)
+    ok3 = torch.equal(out, logits_full)
+    ret[rank] = (ok1, ok2, ok3, (v0, v1))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gloo_world2_collectives():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        ok1, ok2, ok3, _ = ret[r]
+        assert ok1 and ok2 and ok3, (r, ret[r])
+    assert ret[0][3] != ret[1][3] and ret[0][3][1] == ret[1][3][0]
