@@ -136,6 +136,23 @@ int qspec_gate_up_silu_linear_s4s4(const int8_t* xq, const qspec_half* xs, const
 int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
                                     int intermediate, int K, void* workspace, void* stream);
 
+/* Draft pass, decode-sized M (<= 16): the residual add + LN-no-gamma + per-token int4 quantisation that feeds
+ * qkv_proj / gate_up (quarot_llama.py:373-374,380-388: `hidden = residual + proj_out; x = norm(hidden)`;
+ * kernel third-party/kernels/csrc/layernorm_kernels.cu:569-716) runs as the PROLOGUE of the GEMM launch:
+ *   h = fp16(hidden_in + delta) (delta NULL: h = hidden_in);  hidden_out = h;  (xq, xs) = ln_i4(h);  then the fused
+ *   GEMM of qspec_qkv_rope_linear_s4s4 / qspec_gate_up_silu_linear_s4s4.
+ * hidden_out must not alias hidden_in (every workgroup re-reads hidden_in; workgroup 0 writes hidden_out).
+ * Bit-identical to qspec_add_rms_norm_i4 followed by the GEMM entry.  K = hidden size in {2048, 4096, 5120, 8192}. */
+int qspec_ln_qkv_rope_linear_s4s4(const qspec_half* hidden_in, const qspec_half* delta, qspec_half* hidden_out,
+                                  float eps, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M, int N,
+                                  int K, const int64_t* positions, const qspec_half* cos_sin_cache,
+                                  qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
+                                  int num_heads, int num_kv_heads, int head_size, int rot_dim, void* stream);
+int qspec_ln_gate_up_silu_linear_s4s4(const qspec_half* hidden_in, const qspec_half* delta, qspec_half* hidden_out,
+                                      float eps, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
+                                      int intermediate, int K, void* stream);
+int qspec_ln_linear_s4s4_supported(int M, int N, int K);   /* 1 if the two entries above accept the shape */
+
 /* Tensor-parallel views of the SAME buffers (no reference counterpart: the reference QSpec model has no TP).
  * _ksliced: row-parallel shard = a K range of x [M, *] (row stride ldx halves) and of wq [N, *] (row stride ldw_bytes);
  *           the caller all-reduces the partial outputs.

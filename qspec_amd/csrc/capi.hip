@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/qspec_hip.h"
 #include "kernels.h"
@@ -28,6 +29,16 @@ static int finish(const char* op, int rc) {
 #define ST ((hipStream_t)stream)
 #define H(p) reinterpret_cast<f16*>(p)
 #define CH(p) reinterpret_cast<const f16*>(p)
+
+// QSPEC_OLD_GEMM=1 keeps the first-generation one-tile-per-workgroup W4A4 kernel (A/B measurements)
+static bool use_stream() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("QSPEC_OLD_GEMM");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v == 1;
+}
 
 extern "C" {
 
@@ -134,6 +145,11 @@ int qspec_rowwise_scaled_linear_s4s4(const int8_t* xq, const qspec_half* xs, con
     if (M == 0 || N == 0) return 0;
     NONNULL(op, xq); NONNULL(op, xs); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, out);
     if (N % 16 || K % 128 || K <= 0) return fail("%s: need N %% 16 == 0 and K %% 128 == 0 (N=%d K=%d)", op, N, K);
+    if (!bias && use_stream() && qspec::gemm_w4a4_stream_supported(M, N, K, false)) {
+        qspec::StreamActs x;
+        x.xq = xq; x.xs = CH(xs);
+        return finish(op, qspec::gemm_w4a4_stream(x, wq, CH(ws), H(out), M, N, K, ST));
+    }
     return finish(op, qspec::gemm_w4a4(xq, CH(xs), wq, CH(ws), CH(bias), H(out), M, N, K, ST));
 }
 size_t qspec_w4a16_workspace_bytes(void) { return qspec::gemm_w4a16_ws_bytes(); }
@@ -293,6 +309,11 @@ int qspec_qkv_rope_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int
     NONNULL(op, xq); NONNULL(op, xs); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, qkv); NONNULL(op, positions);
     NONNULL(op, cos_sin_cache); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
     if (head_size != 128 || rot_dim != 128) return fail("%s: head_size and rot_dim must be 128", op);
+    if (use_stream() && qspec::gemm_w4a4_stream_supported(M, N, K, false)) {
+        qspec::StreamActs x;
+        x.xq = xq; x.xs = CH(xs);
+        return finish(op, qspec::gemm_w4a4_stream_qkv_rope(x, wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST));
+    }
     return finish(op, qspec::gemm_w4a4_qkv_rope(xq, CH(xs), wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST));
 }
 int qspec_qkv_rope_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M,
@@ -312,6 +333,11 @@ int qspec_gate_up_silu_linear_s4s4(const int8_t* xq, const qspec_half* xs, const
     const char* op = "qspec_gate_up_silu_linear_s4s4";
     if (M == 0) return 0;
     NONNULL(op, xq); NONNULL(op, xs); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
+    if (use_stream() && qspec::gemm_w4a4_stream_supported(M, 2 * intermediate, K, false)) {
+        qspec::StreamActs x;
+        x.xq = xq; x.xs = CH(xs);
+        return finish(op, qspec::gemm_w4a4_stream_gate_up_silu(x, wq, CH(ws), H(act), M, intermediate, K, ST));
+    }
     return finish(op, qspec::gemm_w4a4_gate_up_silu(xq, CH(xs), wq, CH(ws), H(act), M, intermediate, K, ST));
 }
 int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
@@ -348,5 +374,37 @@ int qspec_gate_up_silu_linear_w4a16_shard(const qspec_half* x, const int8_t* wq,
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
     return finish(op, qspec::gemm_w4a16_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, first_channel, num_channels, workspace, ST));
 }
+
+int qspec_ln_qkv_rope_linear_s4s4(const qspec_half* hidden_in, const qspec_half* delta, qspec_half* hidden_out,
+                                  float eps, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M, int N,
+                                  int K, const int64_t* positions, const qspec_half* cos_sin_cache,
+                                  qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
+                                  int num_heads, int num_kv_heads, int head_size, int rot_dim, void* stream) {
+    const char* op = "qspec_ln_qkv_rope_linear_s4s4";
+    if (M == 0) return 0;
+    NONNULL(op, hidden_in); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, qkv); NONNULL(op, positions);
+    NONNULL(op, cos_sin_cache); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
+    if (hidden_out == hidden_in) return fail("%s: hidden_out must not alias hidden_in (every workgroup reads it)", op);
+    if (head_size != 128 || rot_dim != 128) return fail("%s: head_size and rot_dim must be 128", op);
+    if (!qspec::gemm_w4a4_stream_supported(M, N, K, true))
+        return fail("%s: need M <= 16, N %% 16 == 0, K in {1024, 2048, 4096, 5120, 8192} (M=%d N=%d K=%d)", op, M, N, K);
+    qspec::StreamActs x;
+    x.hidden_in = CH(hidden_in); x.delta = CH(delta); x.hidden_out = H(hidden_out); x.eps = eps;
+    return finish(op, qspec::gemm_w4a4_stream_qkv_rope(x, wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST));
+}
+int qspec_ln_gate_up_silu_linear_s4s4(const qspec_half* hidden_in, const qspec_half* delta, qspec_half* hidden_out,
+                                      float eps, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
+                                      int intermediate, int K, void* stream) {
+    const char* op = "qspec_ln_gate_up_silu_linear_s4s4";
+    if (M == 0) return 0;
+    NONNULL(op, hidden_in); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
+    if (hidden_out == hidden_in) return fail("%s: hidden_out must not alias hidden_in (every workgroup reads it)", op);
+    if (!qspec::gemm_w4a4_stream_supported(M, 2 * intermediate, K, true) || intermediate % 8)
+        return fail("%s: need M <= 16, intermediate %% 8 == 0, K in {1024, 2048, 4096, 5120, 8192} (M=%d I=%d K=%d)", op, M, intermediate, K);
+    qspec::StreamActs x;
+    x.hidden_in = CH(hidden_in); x.delta = CH(delta); x.hidden_out = H(hidden_out); x.eps = eps;
+    return finish(op, qspec::gemm_w4a4_stream_gate_up_silu(x, wq, CH(ws), H(act), M, intermediate, K, ST));
+}
+int qspec_ln_linear_s4s4_supported(int M, int N, int K) { return qspec::gemm_w4a4_stream_supported(M, N, K, true) ? 1 : 0; }
 
 }  // extern "C"

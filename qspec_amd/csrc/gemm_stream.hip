@@ -1,0 +1,592 @@
+// Weight-streaming W4A4 GEMM for decode-sized M (<= 16 tokens), second generation: the kernel of the draft pass.
+//
+// Same arithmetic and the same shared packed-int4 weight buffer as gemm.hip:gemm_w4a4_kernel (reference:
+// third-party/ao/torchao/csrc/cuda/rowwise_scaled_linear_cutlass/rowwise_scaled_linear_cutlass_unified.cuh:240-488,
+// Python quarot_nn/linear.py:67-84), restructured around what bounds it at M = 4: bytes in flight and launches.
+//
+//   * A workgroup of NW waves (4 / 8 / 16 by K) owns 16-row weight tiles and LOOPS over them (stride gridDim.x).
+//     The waves interleave over K in 64-byte steps, 8 steps (8 KiB per wave) per batch; the loads of the NEXT
+//     batch -- usually the next tile -- are issued before the current one is consumed, so every wave keeps 8 KiB
+//     in flight across the reduce / epilogue of a tile.  With K = 4096 and NW = 4, or K = 14336 and NW = 16, one
+//     batch is one tile: all of a tile's bytes are requested at once.
+//   * Activations live in LDS (int4-packed, [M][K/2 + 32]: the 32-byte pad spreads the token rows over the banks),
+//     fragments are ds_read_b128 -- LDS reads count in lgkmcnt and never queue behind the weight loads in vmcnt.
+//   * PRO_LN: the residual add + LayerNorm-no-gamma + per-token int4 quantisation that feeds qkv_proj / gate_up
+//     (layernorm_kernels.cu:569-716, quarot_llama.py:373-388) runs as the PROLOGUE of the GEMM, redundantly in every
+//     workgroup, underneath the latency of the first weight batch: the LN kernel and its launch boundary disappear.
+//     It is the same code path as norm_quant.hip:ln_kernel (reference reduction tree, bit for bit), batched over
+//     rows.  Workgroup 0 also writes the updated residual stream (hidden_out != hidden_in: ping-pong, no race).
+//   * Epilogues as in gemm.hip (plain / RoPE + KV-cache write / silu(gate)*up), with their operands (channel
+//     scale, cos/sin, position, slot) prefetched together with the tile's weights.
+//   * Cross-wave K reduction through LDS in wave order: int32, exact, deterministic.
+#include <stdlib.h>
+
+#include "common.cuh"
+#include "kernels.h"
+
+namespace qspec {
+
+enum { SEPI_PLAIN = 0, SEPI_QKV = 1, SEPI_GATEUP = 2 };
+enum { PRO_Q = 0, PRO_LN = 1 };
+
+struct StreamArgs {
+    const int8_t* xq;       // PRO_Q : [M, K/2] packed int4 activations
+    const f16* xs;          // PRO_Q : [M] activation scales
+    const f16* hidden_in;   // PRO_LN: [M, K] residual stream
+    const f16* delta;       // PRO_LN: [M, K] output of the previous projection (added first) or nullptr
+    f16* hidden_out;        // PRO_LN: [M, K] updated residual stream (written by workgroup 0) or nullptr
+    float eps;
+    const uint8_t* wq;      // [N, K/2]
+    const f16* ws;          // [N]
+    f16* out;
+    int M, N, K, ntiles;
+    const int64_t* positions;
+    const f16* cos_sin_cache;
+    f16* key_cache;
+    f16* value_cache;
+    const int64_t* slot_mapping;
+    int nq, nkv, I;
+};
+
+__device__ __forceinline__ i32x4 widen16(u32 p0, u32 p1) {
+    return i32x4{(int)((p0 << 4) & 0xF0F0F0F0u), (int)(p0 & 0xF0F0F0F0u), (int)((p1 << 4) & 0xF0F0F0F0u),
+                 (int)(p1 & 0xF0F0F0F0u)};
+}
+
+// Byte offset (inside one batch of NW*UB*64 bytes of a weight row) of step u of `wave`.  Steps are paired so that a
+// wave's two consecutive loads cover one 128-byte line of every row (a 16x16 MFMA tile puts only 4 lanes = 64 bytes
+// on a row per load instruction); an odd UB leaves one unpaired step at the end of the batch.
+template <int NW, int UB>
+__device__ __forceinline__ int step_off(int wave, int u) {
+    constexpr int UE = UB & ~1;
+    if (u < UE) return (u >> 1) * (2 * NW * 64) + wave * 128 + (u & 1) * 64;
+    return UE * NW * 64 + wave * 64;
+}
+
+template <int EPI>
+__device__ __forceinline__ int stile_row(int tb, int r, int I) {
+    if (EPI == SEPI_QKV) return (tb >> 3) * 128 + (r >> 3) * 64 + (tb & 7) * 8 + (r & 7);
+    if (EPI == SEPI_GATEUP) return (r >> 3) * I + tb * 8 + (r & 7);
+    return tb * 16 + r;
+}
+
+// lane ^ M for M in {1, 2, 4, 8} as DPP moves (no LDS round trip, ~8 cycles instead of a ~100-cycle ds_bpermute):
+// quad_perm for 1 and 2, row_ror:8 for 8, and for 4 a row_shl:4 into the even 4-lane banks + row_shr:4 into the odd.
+template <int M>
+__device__ __forceinline__ float dpp_xor(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    int r;
+    if (M == 1) r = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, false);        // quad_perm:[1,0,3,2]
+    else if (M == 2) r = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, false);   // quad_perm:[2,3,0,1]
+    else if (M == 8) r = __builtin_amdgcn_update_dpp(0, xi, 0x128, 0xF, 0xF, false);  // row_ror:8
+    else {
+        r = __builtin_amdgcn_update_dpp(0, xi, 0x104, 0xF, 0x5, false);               // row_shl:4 -> banks 0,2
+        r = __builtin_amdgcn_update_dpp(r, xi, 0x114, 0xF, 0xA, false);               // row_shr:4 -> banks 1,3
+    }
+    return __builtin_bit_cast(float, r);
+}
+
+// Reference summation tree over 1024 virtual-thread partials held 4 per lane (norm_quant.hip:ref_tree_sum_1024),
+// for RB rows at once.  j = index inside the 256-thread group; red = [RB][32] floats of this group, written once.
+// Same pairings, same order as the reference's two xor butterflies (so the same bits); the second butterfly is
+// evaluated directly from the 32 warp sums (every lane of a butterfly ends with the same value, so any one
+// lane's expression tree will do) instead of through five cross-lane exchanges.
+template <int RB>
+__device__ __forceinline__ void tree_sum_rows(float (&p)[RB][4], float* red, int j, float (&out)[RB]) {
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) p[i][c] = p[i][c] + dpp_xor<4>(p[i][c]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) p[i][c] = p[i][c] + dpp_xor<2>(p[i][c]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) p[i][c] = p[i][c] + dpp_xor<1>(p[i][c]);
+        const float r0 = p[i][0] + p[i][2], r1 = p[i][1] + p[i][3];
+        const float s = r0 + r1;
+        if ((j & 7) == 0) red[i * 32 + (j >> 3)] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+        float v[32];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(red + i * 32 + 4 * q);
+            v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+        }
+        // lane 0 of the butterfly: level m pairs index k with k ^ m, m = 16, 8, 4, 2, 1
+#pragma unroll
+        for (int m = 16; m > 0; m >>= 1)
+#pragma unroll
+            for (int k = 0; k < m; k++) v[k] = v[k] + v[k + m];
+        out[i] = v[0];
+    }
+}
+
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_xor<1>(v));
+    v = fmaxf(v, dpp_xor<2>(v));
+    v = fmaxf(v, dpp_xor<4>(v));
+    v = fmaxf(v, dpp_xor<8>(v));
+    v = fmaxf(v, shfl_xor_f(v, 16));
+    v = fmaxf(v, shfl_xor_f(v, 32));
+    return v;
+}
+
+// Residual add + LN-no-gamma + int4 quant of all M rows into LDS (xq_lds [MP][RS] bytes, xs_lds [16] floats).
+// NG groups of 256 threads, RB rows per group per pass.  Split in a load half and a compute half so that the caller
+// can put the first weight batch between them: vector-memory results return in issue order, so the residual
+// stream must be requested BEFORE the weights for the norm to run underneath their latency.
+// Arithmetic = norm_quant.hip:ln_kernel (layernorm_kernels.cu:569-716), with cheaper but bit-equivalent forms:
+// |fp16| maxima compared as fp16, round-to-nearest-even to integer by adding 1.5 * 2^23.
+template <int NI, int RB>
+struct LnRegs {
+    f16x4 x[RB][NI], d[RB][NI];
+};
+
+template <int NI, int NG, int RB>
+__device__ __forceinline__ void ln_load(const StreamArgs& a, int base, LnRegs<NI, RB>& rg) {
+    const int tid = threadIdx.x, j = tid & 255, grp = tid >> 8;
+    const int H = a.K;
+    const f16* dptr = a.delta ? a.delta : a.hidden_in;
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+        const int row = base + grp * RB + i;
+        const int rr = row < a.M ? row : 0;
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
+            // no branch around a load: hipcc answers control flow with s_waitcnt vmcnt(0), which would serialise
+            // every load of the prologue (delta == nullptr re-reads hidden_in and the value is discarded)
+            rg.x[i][it] = *reinterpret_cast<const f16x4*>(a.hidden_in + (size_t)rr * H + it * 1024 + 4 * j);
+            rg.d[i][it] = *reinterpret_cast<const f16x4*>(dptr + (size_t)rr * H + it * 1024 + 4 * j);
+        }
+    }
+}
+
+template <int NI, int NG, int RB>
+__device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs<NI, RB>& rg,
+                                           unsigned char* xq_lds, int RS, float* xs_lds,
+                                           float* lnred /* [3][NG][RB][32] */, bool write_hidden) {
+    const int tid = threadIdx.x, j = tid & 255, grp = tid >> 8;
+    const int H = a.K;
+    float* red_mean = lnred + (0 * NG + grp) * RB * 32;
+    float* red_var = lnred + (1 * NG + grp) * RB * 32;
+    float* red_max = lnred + (2 * NG + grp) * RB * 32;
+    float v[RB][NI][4];
+    int row[RB];
+    bool act[RB];
+    if (a.delta) {  // uniform; no load inside
+#pragma unroll
+        for (int i = 0; i < RB; i++)
+#pragma unroll
+            for (int it = 0; it < NI; it++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) rg.x[i][it][c] = f2h(h2f(rg.x[i][it][c]) + h2f(rg.d[i][it][c]));
+    }
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+        row[i] = base + grp * RB + i;
+        act[i] = row[i] < a.M;
+        const int rr = act[i] ? row[i] : 0;
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
+            if (write_hidden && act[i])
+                *reinterpret_cast<f16x4*>(a.hidden_out + (size_t)rr * H + it * 1024 + 4 * j) = rg.x[i][it];
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[i][it][c] = h2f(rg.x[i][it][c]);
+        }
+    }
+    float p[RB][4], mean[RB], var[RB];
+#pragma unroll
+    for (int i = 0; i < RB; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float s = 0.0f;
+#pragma unroll
+            for (int it = 0; it < NI; it++) s = s + v[i][it][c];
+            p[i][c] = s;
+        }
+    tree_sum_rows<RB>(p, red_mean, j, mean);
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+        mean[i] = mean[i] / (float)H;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float s = 0.0f;
+#pragma unroll
+            for (int it = 0; it < NI; it++) {
+                const float d = v[i][it][c] - mean[i];
+                s = __builtin_fmaf(d, d, s);
+            }
+            p[i][c] = s;
+        }
+    }
+    tree_sum_rows<RB>(p, red_var, j, var);
+    float amax[RB];
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+        const float rstd = 1.0f / __builtin_sqrtf(var[i] / (float)H + a.eps);
+        // v <- (x - mean) * rstd (kept in fp32 for the quantiser); amax over its fp16 rounding, compared as fp16
+        f16x2 am2 = {f2h(1e-6f), f2h(1e-6f)};
+#pragma unroll
+        for (int it = 0; it < NI; it++)
+#pragma unroll
+            for (int c = 0; c < 4; c += 2) {
+                const float t0 = (v[i][it][c] - mean[i]) * rstd, t1 = (v[i][it][c + 1] - mean[i]) * rstd;
+                v[i][it][c] = t0;
+                v[i][it][c + 1] = t1;
+                const f16x2 r2 = {f2h(t0), f2h(t1)};
+                const u32 ab = __builtin_bit_cast(u32, r2) & 0x7FFF7FFFu;
+                const f16x2 a2 = __builtin_bit_cast(f16x2, ab);
+                // NaN (possible only for non-finite input) compares false, as in the reference's `a > amax ? a : amax`
+                am2[0] = a2[0] > am2[0] ? a2[0] : am2[0];
+                am2[1] = a2[1] > am2[1] ? a2[1] : am2[1];
+            }
+        float am = fmaxf(h2f(am2[0]), h2f(am2[1]));
+        am = wave_max_dpp(am);
+        if ((j & 63) == 0) red_max[i * 32 + (j >> 6)] = am;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(red_max + i * 32);
+        amax[i] = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        const float s = 7.0f / amax[i];
+        if (act[i]) {
+#pragma unroll
+            for (int it = 0; it < NI; it++) {
+                u32 nib[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float t = v[i][it][c] * s;
+                    t = fmaxf(fminf(t, 7.0f), -8.0f);
+                    // round to nearest even: the low bits of (t + 1.5 * 2^23) are the two's complement integer
+                    float mg = t + 12582912.0f;
+                    asm("" : "+v"(mg));
+                    nib[c] = __builtin_bit_cast(u32, mg);
+                }
+                const u32 lo = (nib[0] & 0xFu) | (nib[1] << 4), hi = (nib[2] & 0xFu) | (nib[3] << 4);
+                const uint16_t two = (uint16_t)((lo & 0xFFu) | (hi << 8));
+                *reinterpret_cast<uint16_t*>(xq_lds + (size_t)row[i] * RS + it * 512 + 2 * j) = two;
+            }
+            if (j == 0) xs_lds[row[i]] = h2f(f2h(amax[i] / 7.0f));
+        }
+    }
+    __syncthreads();  // the reduction scratch is reused by the next pass; also publishes xq_lds / xs_lds
+}
+
+// NW waves; UB steps of 64 packed bytes per wave and batch (K/2 = 64 * NW * UB * NB bytes, NB batches per tile);
+// NI = K / 1024 for the LN prologue (0 otherwise).
+template <int EPI, int PRO, int NW, int UB, int NI>
+__global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NG = NW / 4;
+    constexpr int RB = NW == 4 ? 4 : (NW == 8 ? 2 : 1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int Kb = a.K >> 1, RS = Kb + 32;
+    const int MP = a.M <= 4 ? 4 : (a.M <= 8 ? 8 : 16);
+    unsigned char* xq_lds = smem;
+    float* xs_lds = reinterpret_cast<float*>(smem + (size_t)MP * RS);
+    int* red = reinterpret_cast<int*>(xs_lds + 16);                 // [2][NW][256]
+    f16* ex = reinterpret_cast<f16*>(red + 2 * NW * 256);            // [2][256]
+    float* lnred = reinterpret_cast<float*>(ex + 2 * 256);           // [3][NG][RB][32]
+    const int NB = Kb / (64 * NW * UB);                              // batches per tile (exact: checked on the host)
+
+    // epilogue thread (tid < 256) owns accumulator element (token m, tile column c)
+    const int el = tid & 63, reg = (tid >> 6) & 3;
+    const int c = el & 15, m = 4 * (el >> 4) + reg;
+    const bool ethread = tid < 256 && m < a.M;
+    const int mc = m < a.M ? m : 0;
+
+    // No load in this kernel sits behind a branch: hipcc resolves control flow around vector-memory operations
+    // with s_waitcnt vmcnt(0), which would drain the weight stream.  Addresses are clamped instead.
+    int64_t pos_m = 0, slot_m = -1;
+    if (EPI == SEPI_QKV) {  // the kernel's first loads
+        pos_m = a.positions[mc];
+        slot_m = a.slot_mapping[mc];
+    }
+    struct Pre {
+        f16 swn, cf, sf;
+    };
+    auto load_pre = [&](Pre& pre, int tile) {  // epilogue operands of (token m, column c) of `tile`
+        pre.swn = a.ws[stile_row<EPI>(tile, c, a.I)];
+        if (EPI == SEPI_QKV) {
+            const int o = (tile & 7) * 8 + (c & 7);
+            const f16* cs = a.cos_sin_cache + pos_m * 128;
+            pre.cf = cs[o];
+            pre.sf = cs[64 + o];
+        }
+    };
+    auto wptr = [&](int tile, int b) -> const uint8_t* {
+        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I) * Kb + (size_t)(b * UB * NW) * 64 + g * 16;
+    };
+    const unsigned char* arow = xq_lds + (size_t)(r & (MP - 1)) * RS + g * 16;
+    i32x4 acc = {0, 0, 0, 0};
+    auto use = [&](const u32x4& w, int b, int u) {
+        const u32x4 av = *reinterpret_cast<const u32x4*>(arow + (size_t)b * (UB * NW * 64) + step_off<NW, UB>(wave, u));
+        const i32x4 b0 = widen16(w[0], w[1]), b1 = widen16(w[2], w[3]);
+        const i32x4 a0 = widen16(av[0], av[1]), a1 = widen16(av[2], av[3]);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
+    };
+    auto finish = [&](int tile, int par, const Pre& pre) {
+        int* rb = red + par * NW * 256;
+#pragma unroll
+        for (int i = 0; i < 4; i++) rb[wave * 256 + i * 64 + lane] = acc[i];
+        acc = i32x4{0, 0, 0, 0};
+        __syncthreads();
+        f16 hv = (f16)0.0f;
+        if (ethread) {
+            int sum = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2++) sum += rb[w2 * 256 + tid];
+            const float v = ((float)(sum >> 8) * xs_lds[m]) * h2f(pre.swn);  // both operands carried a factor 16
+            hv = f2h(v);
+        }
+        if (EPI == SEPI_PLAIN) {
+            if (ethread) a.out[(size_t)m * a.N + tile * 16 + c] = hv;
+            return;
+        }
+        f16* e = ex + par * 256;
+        if (tid < 256) e[m * 16 + c] = hv;
+        __syncthreads();
+        if (!ethread) return;
+        const f16 partner = e[(m * 16 + c) ^ 8];
+        if (EPI == SEPI_GATEUP) {
+            if (c < 8) {  // hv = up, partner = gate
+                const float gt = h2f(partner);
+                const float act = h2f(f2h(gt / (1.0f + qexpf(-gt))));
+                a.out[(size_t)m * a.I + tile * 8 + c] = f2h(act * h2f(hv));
+            }
+            return;
+        }
+        // SEPI_QKV
+        const int head = tile >> 3, o = (tile & 7) * 8 + (c & 7);
+        const int n = head * 128 + (c >> 3) * 64 + o;
+        f16 res = hv;
+        if (head < a.nq + a.nkv) {
+            const float cff = h2f(pre.cf), sff = h2f(pre.sf);
+            const float xf = h2f(c < 8 ? hv : partner), yf = h2f(c < 8 ? partner : hv);
+            res = c < 8 ? f2h(h2f(f2h(xf * cff)) - h2f(f2h(yf * sff))) : f2h(h2f(f2h(yf * cff)) + h2f(f2h(xf * sff)));
+        }
+        a.out[(size_t)m * a.N + n] = res;
+        if (head >= a.nq && slot_m >= 0) {
+            const bool is_k = head < a.nq + a.nkv;
+            const int kvh = is_k ? head - a.nq : head - a.nq - a.nkv;
+            f16* cache = is_k ? a.key_cache : a.value_cache;
+            cache[(slot_m * a.nkv + kvh) * 128 + (c >> 3) * 64 + o] = res;
+        }
+    };
+
+    int tile = blockIdx.x, b = 0, par = 0;
+    const int my_tiles = (a.ntiles - tile + (int)gridDim.x - 1) / (int)gridDim.x;  // >= 1: grid <= ntiles
+    const int n_units = my_tiles * NB;
+    u32x4 w[UB];
+    Pre pre = {};
+    const uint8_t* wp0 = wptr(tile, 0);
+
+    // ---- prologue: activations -> LDS.  Their loads are issued BEFORE the first weight batch (results return in
+    // issue order), the arithmetic runs underneath the weights' latency.
+    if (PRO == PRO_LN) {
+        LnRegs<NI, RB> rg;
+        ln_load<NI, NG, RB>(a, 0, rg);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; u++) w[u] = *reinterpret_cast<const u32x4*>(wp0 + step_off<NW, UB>(wave, u));
+        load_pre(pre, tile);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool wh = blockIdx.x == 0 && a.hidden_out != nullptr;
+        ln_compute<NI, NG, RB>(a, 0, rg, xq_lds, RS, xs_lds, lnred, wh);
+        for (int base = NG * RB; base < a.M; base += NG * RB) {
+            ln_load<NI, NG, RB>(a, base, rg);
+            ln_compute<NI, NG, RB>(a, base, rg, xq_lds, RS, xs_lds, lnred, wh);
+        }
+    } else {
+        const int chunks_per_row = Kb >> 4;
+        const int total = a.M * chunks_per_row;
+        constexpr int XA = 4;
+        u32x4 xa[XA];
+        int xoff[XA];
+#pragma unroll
+        for (int q2 = 0; q2 < XA; q2++) {
+            const int i = min(tid + q2 * NW * 64, total - 1);
+            const int row = i / chunks_per_row, q = i - row * chunks_per_row;
+            xoff[q2] = row * RS + q * 16;
+            xa[q2] = *reinterpret_cast<const u32x4*>(a.xq + (size_t)row * Kb + q * 16);
+        }
+        const float xsv = h2f(a.xs[tid < a.M ? tid : 0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; u++) w[u] = *reinterpret_cast<const u32x4*>(wp0 + step_off<NW, UB>(wave, u));
+        load_pre(pre, tile);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q2 = 0; q2 < XA; q2++) *reinterpret_cast<u32x4*>(xq_lds + xoff[q2]) = xa[q2];  // duplicates rewrite the same bytes
+        for (int i = tid + XA * NW * 64; i < total; i += NW * 64) {  // M * K beyond XA chunks per thread (M > 4)
+            const int row = i / chunks_per_row, q = i - row * chunks_per_row;
+            *reinterpret_cast<u32x4*>(xq_lds + (size_t)row * RS + q * 16) =
+                *reinterpret_cast<const u32x4*>(a.xq + (size_t)row * Kb + q * 16);
+        }
+        if (tid < a.M) xs_lds[tid] = xsv;
+        __syncthreads();
+    }
+
+    // ---- main loop: one unit = UB steps of every wave.  Each step's register is refilled with the same step of
+    // the NEXT unit as soon as it has been consumed: UB loads per wave stay in flight across tile boundaries,
+    // reductions and epilogues.  The last unit is peeled (nothing to refill), so the loop body has no branch
+    // around a load and the waits hipcc inserts are the exact counted ones.
+    for (int q = 0; q < n_units - 1; q++) {
+        int nb = b + 1, nt = tile;
+        if (nb == NB) {
+            nb = 0;
+            nt = tile + gridDim.x;
+        }
+        const uint8_t* wp = wptr(nt, nb);
+        Pre npre;
+        load_pre(npre, nt);
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            use(w[u], b, u);
+            // pin the refill right behind its consumer: left alone, the scheduler sinks all UB loads below the last
+            // use and the stream drains every unit
+            __builtin_amdgcn_sched_barrier(0);
+            w[u] = *reinterpret_cast<const u32x4*>(wp + step_off<NW, UB>(wave, u));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (b == NB - 1) {
+            finish(tile, par, pre);
+            par ^= 1;
+        }
+        pre = npre;
+        tile = nt;
+        b = nb;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; u++) use(w[u], b, u);
+    finish(tile, par, pre);
+}
+
+// Shape classes: K/2 bytes of a weight row = 64 * NW * UB * NB exactly.
+struct StreamShape {
+    int NW, UB, NI;
+};
+static bool stream_shape(int K, StreamShape* sh) {
+    const int nsteps = K / 128;
+    if (K % 128) return false;
+    static const StreamShape cand[] = {{8, 4, 0}, {16, 7, 0}, {8, 8, 0}, {8, 5, 0}, {4, 4, 0}, {4, 2, 0}};
+    // preferred order: one batch per tile first
+    for (int pass = 0; pass < 2; pass++)
+        for (const StreamShape& c : cand) {
+            const int per = c.NW * c.UB;
+            if (nsteps % per) continue;
+            if (pass == 0 && nsteps != per) continue;
+            *sh = c;
+            sh->NI = (K % 1024 == 0 && K / 1024 <= 8) ? K / 1024 : 0;
+            return true;
+        }
+    return false;
+}
+
+static size_t stream_lds_bytes(int M, int K, int NW) {
+    const int MP = M <= 4 ? 4 : (M <= 8 ? 8 : 16);
+    const int NG = NW / 4, RB = NW == 4 ? 4 : (NW == 8 ? 2 : 1);
+    return (size_t)MP * (K / 2 + 32) + 64 + (size_t)2 * NW * 1024 + 1024 + (size_t)3 * NG * RB * 32 * 4;
+}
+
+static int g_stream_cap = 0;  // workgroups per launch above which a workgroup loops over several tiles
+static int stream_cap() {
+    if (g_stream_cap == 0) {
+        const char* e = getenv("QSPEC_STREAM_CAP");
+        g_stream_cap = e ? atoi(e) : 512;
+        if (g_stream_cap < 1) g_stream_cap = 512;
+    }
+    return g_stream_cap;
+}
+
+template <int EPI, int PRO, int NW, int UB, int NI>
+static int launch_stream_inst(const StreamArgs& a, hipStream_t st) {
+    const size_t lds = stream_lds_bytes(a.M, a.K, NW);
+    if (lds > 160 * 1024) return -7;
+    static size_t attr_set = 0;  // per instantiation
+    auto kern = gemm_w4a4_stream_kernel<EPI, PRO, NW, UB, NI>;
+    if (lds > 64 * 1024 && lds > attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -8;
+        attr_set = lds;
+    }
+    const int cap = stream_cap();
+    int grid = a.ntiles;
+    if (grid > cap) {
+        const int per = (a.ntiles + cap - 1) / cap;
+        grid = (a.ntiles + per - 1) / per;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
+    return 0;
+}
+
+template <int EPI>
+static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
+    StreamShape sh;
+    if (a.M < 1 || a.M > 16 || !stream_shape(a.K, &sh)) return -1;
+    if (!ln) {
+        if (sh.NW == 8 && sh.UB == 4) return launch_stream_inst<EPI, PRO_Q, 8, 4, 0>(a, st);
+        if (sh.NW == 16 && sh.UB == 7) return launch_stream_inst<EPI, PRO_Q, 16, 7, 0>(a, st);
+        if (sh.NW == 8 && sh.UB == 8) return launch_stream_inst<EPI, PRO_Q, 8, 8, 0>(a, st);
+        if (sh.NW == 8 && sh.UB == 5) return launch_stream_inst<EPI, PRO_Q, 8, 5, 0>(a, st);
+        if (sh.NW == 4 && sh.UB == 4) return launch_stream_inst<EPI, PRO_Q, 4, 4, 0>(a, st);
+        if (sh.NW == 4 && sh.UB == 2) return launch_stream_inst<EPI, PRO_Q, 4, 2, 0>(a, st);
+        return -1;
+    }
+    // LN prologue: the reference's 1024 virtual threads -> K a multiple of 1024; one batch per tile
+    if (a.K == 4096) return launch_stream_inst<EPI, PRO_LN, 8, 4, 4>(a, st);
+    if (a.K == 8192) return launch_stream_inst<EPI, PRO_LN, 8, 8, 8>(a, st);
+    if (a.K == 5120) return launch_stream_inst<EPI, PRO_LN, 8, 5, 5>(a, st);
+    if (a.K == 2048) return launch_stream_inst<EPI, PRO_LN, 4, 4, 2>(a, st);
+    if (a.K == 1024) return launch_stream_inst<EPI, PRO_LN, 4, 2, 1>(a, st);
+    return -1;
+}
+
+bool gemm_w4a4_stream_supported(int M, int N, int K, bool ln) {
+    StreamShape sh;
+    if (M < 1 || M > 16 || N % 16 || K > (1 << 19) || !stream_shape(K, &sh)) return false;
+    if (ln && !(K == 1024 || K == 2048 || K == 4096 || K == 5120 || K == 8192)) return false;
+    return stream_lds_bytes(M, K, sh.NW) <= 160 * 1024;
+}
+
+// act: either (xq, xs) or (hidden_in, delta, hidden_out, eps) -- see StreamArgs.
+int gemm_w4a4_stream(const StreamActs& x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K,
+                     hipStream_t st) {
+    if (!gemm_w4a4_stream_supported(M, N, K, x.hidden_in != nullptr)) return -1;
+    StreamArgs a{};
+    a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps;
+    a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = out; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
+    return launch_stream<SEPI_PLAIN>(a, x.hidden_in != nullptr, st);
+}
+
+int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
+                              const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
+                              const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st) {
+    if (d != 128 || rot_dim != 128 || N != (nq + 2 * nkv) * 128) return -1;
+    if (!gemm_w4a4_stream_supported(M, N, K, x.hidden_in != nullptr)) return -1;
+    StreamArgs a{};
+    a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps;
+    a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = qkv; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
+    a.positions = positions; a.cos_sin_cache = cos_sin_cache; a.key_cache = key_cache; a.value_cache = value_cache;
+    a.slot_mapping = slot_mapping; a.nq = nq; a.nkv = nkv;
+    return launch_stream<SEPI_QKV>(a, x.hidden_in != nullptr, st);
+}
+
+int gemm_w4a4_stream_gate_up_silu(const StreamActs& x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K,
+                                  hipStream_t st) {
+    if (I % 8) return -1;
+    if (!gemm_w4a4_stream_supported(M, 2 * I, K, x.hidden_in != nullptr)) return -1;
+    StreamArgs a{};
+    a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps;
+    a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = act; a.M = M; a.N = 2 * I; a.K = K; a.ntiles = I / 8;
+    a.I = I;
+    return launch_stream<SEPI_GATEUP>(a, x.hidden_in != nullptr, st);
+}
+
+}  // namespace qspec

@@ -44,6 +44,26 @@ int gemm_w4a16_strided(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw,
 int gemm_f16(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st);
 int dequant_w4(const int8_t* wq, const f16* ws, f16* out, int N, int K, hipStream_t st);
 
+// gemm_stream.hip: W4A4 for M <= 16 with the activations produced in the prologue.
+// Either (xq, xs) -- packed int4 rows + scales -- or (hidden_in, delta, hidden_out, eps): the residual add +
+// LN-no-gamma + int4 quant of quarot_llama.py:373-388 fused in front of the GEMM (hidden_out != hidden_in).
+struct StreamActs {
+    const int8_t* xq = nullptr;
+    const f16* xs = nullptr;
+    const f16* hidden_in = nullptr;
+    const f16* delta = nullptr;
+    f16* hidden_out = nullptr;
+    float eps = 0.0f;
+};
+bool gemm_w4a4_stream_supported(int M, int N, int K, bool ln);
+int gemm_w4a4_stream(const StreamActs& x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K,
+                     hipStream_t st);
+int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
+                              const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
+                              const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st);
+int gemm_w4a4_stream_gate_up_silu(const StreamActs& x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K,
+                                  hipStream_t st);
+
 // attention.hip
 int rope_kv_write(const int64_t* positions, f16* qkv, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
                   const int64_t* slot_mapping, int T, int nq, int nkv, int d, int rot_dim, hipStream_t st);

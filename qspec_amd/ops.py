@@ -181,6 +181,36 @@ def gate_up_silu_linear(x, x_scale, wq, w_scale, act):
     return act
 
 
+def ln_linear_s4s4_supported(M: int, N: int, K: int) -> bool:
+    return bool(_lib.load().qspec_ln_linear_s4s4_supported(M, N, K))
+
+
+def ln_qkv_rope_linear(hidden_in, delta, hidden_out, eps, wq, w_scale, qkv, positions, cos_sin_cache, key_cache,
+                       value_cache, slot_mapping, num_heads, num_kv_heads, head_size):
+    """Draft pass: hidden_out = hidden_in + delta; LN + int4 quant; qkv GEMM; RoPE; KV write -- one launch
+    (quarot_llama.py:373-374 + 183-226)."""
+    M, K = hidden_in.shape
+    N = wq.shape[0]
+    _call("qspec_ln_qkv_rope_linear_s4s4", _chk(hidden_in, "hidden_in", _F16), _opt(delta, "delta", _F16),
+          _chk(hidden_out, "hidden_out", _F16), float(eps), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
+          _chk(qkv, "qkv", _F16), M, N, K, _chk(positions, "positions", _I64), _chk(cos_sin_cache, "cos_sin_cache", _F16),
+          _chk(key_cache, "key_cache", _F16), _chk(value_cache, "value_cache", _F16),
+          _chk(slot_mapping, "slot_mapping", _I64), num_heads, num_kv_heads, head_size, cos_sin_cache.shape[-1],
+          _stream())
+    return qkv
+
+
+def ln_gate_up_silu_linear(hidden_in, delta, hidden_out, eps, wq, w_scale, act):
+    """Draft pass: hidden_out = hidden_in + delta; LN + int4 quant; gate_up GEMM; silu(gate)*up -- one launch
+    (quarot_llama.py:380-388 + 276-284)."""
+    M, K = hidden_in.shape
+    I = wq.shape[0] // 2
+    _call("qspec_ln_gate_up_silu_linear_s4s4", _chk(hidden_in, "hidden_in", _F16), _opt(delta, "delta", _F16),
+          _chk(hidden_out, "hidden_out", _F16), float(eps), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
+          _chk(act, "act", _F16), M, I, K, _stream())
+    return act
+
+
 def rowwise_scaled_linear_cutlass_s4s4_unified(xq, x_scale, wq, w_scale, bias, out):
     """torch.ops.torchao.rowwise_scaled_linear_cutlass_s4s4_unified (third-party/ao/torchao/ops.py:600-636)."""
     M, Kb = xq.shape

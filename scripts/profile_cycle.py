@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Decode-only workload for rocprofv3: the QSpec cycle graph replayed N times with NO prefill in the process
+(the KV cache is filled with random values and the sequence state is set directly), so every kernel in the
+trace belongs to the timed region of bench.py.
+
+    rocprofv3 --kernel-trace --stats -d gpurun_out/profX -- python3 scripts/profile_cycle.py --steps 20
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--model", default="llama-3-8b")
+    p.add_argument("--k", type=int, default=3)
+    p.add_argument("--batch", type=int, default=4)
+    p.add_argument("--ctx", type=int, default=512)
+    p.add_argument("--agreement", type=float, default=0.96)
+    p.add_argument("--eager", action="store_true")
+    a = p.parse_args()
+    from qspec_amd.model import CONFIGS, QuarotLlamaForCausalLM
+    from qspec_amd.spec_decode import QSpecEngine
+    dev = "cuda:0"
+    cfg = CONFIGS[a.model]
+    model = QuarotLlamaForCausalLM(cfg, dev).init_synthetic(0, 0.02)
+    total = a.steps + 8
+    eng = QSpecEngine(model, a.k, a.batch, max_model_len=a.ctx + total * (a.k + 1) + 32, block_size=16,
+                      max_new_tokens=total * (a.k + 1) + 8, use_graph=not a.eager, seed=0)
+    eng.agreement_rho = a.agreement
+    g = torch.Generator(device=dev).manual_seed(1)
+    for kc, vc in eng.kv_caches:
+        kc.copy_((torch.randn(kc.shape, generator=g, device=dev) * 0.5).half())
+        vc.copy_((torch.randn(vc.shape, generator=g, device=dev) * 0.5).half())
+    eng.seq_lens.fill_(a.ctx + 1)
+    eng.last_token.copy_(torch.randint(0, cfg.vocab_size, (a.batch,), generator=g, device=dev))
+    eng.gen_lens.fill_(1)
+    eng.n_active = a.batch
+    for _ in range(3):
+        eng.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"cycle_ms={dt / a.steps * 1e3:.3f} metrics={eng.metrics()}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -331,6 +331,66 @@ def test_gate_up_silu_linear_and_mlp_hadamard_equal_unfused(ops, oracle, golden_
     assert torch.equal(o0.view(torch.int16), o1.view(torch.int16))
 
 
+@pytest.mark.parametrize("M,K,with_delta", [(4, 4096, True), (1, 4096, False), (16, 4096, True), (3, 2048, True),
+                                            (7, 5120, True), (4, 8192, True), (5, 1024, True)])
+def test_ln_prologue_gemms_equal_ln_then_gemm(ops, oracle, M, K, with_delta):
+    """The draft pass's fused launches (residual add + LN + int4 quant in the GEMM prologue) against the separate
+    LN kernel (oracle-checked above) followed by the GEMM entry (oracle-checked above): bit for bit, including the
+    residual stream written by workgroup 0 and the KV cache."""
+    rng = np.random.default_rng(M * 7 + K)
+    nq, nkv, d, bs = 4, 2, 128, 16
+    N = (nq + 2 * nkv) * d
+    I = 1792
+    hidden = dev(rand_hidden(rng, M, K))
+    delta = dev(rand_hidden(rng, M, K, 0.3)) if with_delta else None
+    wq = dev(oracle.pack_i4(rand_w4(rng, N, K)))
+    ws = dev((rng.random(N) * 0.01 + 0.001).astype(np.float16))
+    wg = dev(oracle.pack_i4(rand_w4(rng, 2 * I, K)))
+    wgs = dev((rng.random(2 * I) * 0.01 + 0.001).astype(np.float16))
+    cs = dev(oracle.make_cos_sin_cache(d, 2048, 10000.0))
+    pos = dev(rng.integers(0, 2048, M).astype(np.int64))
+    slots_np = rng.permutation(64 * bs)[:M].astype(np.int64)
+    if M > 1:
+        slots_np[1] = -1
+    slots = dev(slots_np)
+    # reference: LN kernel, then the GEMM entries on its (q, scale)
+    q = torch.empty(M, K // 2, dtype=torch.int8, device=DEV)
+    sc = torch.empty(M, dtype=torch.float16, device=DEV)
+    h_ref = torch.empty_like(hidden)
+    ops.add_rms_norm_i4(q, sc, h_ref, hidden, delta, 1e-5)
+    if delta is None:
+        h_ref.copy_(hidden)
+    qkv_ref = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    kc0 = torch.zeros(64, bs, nkv, d, dtype=torch.float16, device=DEV); vc0 = torch.zeros_like(kc0)
+    ops.qkv_rope_linear(q, sc, wq, ws, qkv_ref, pos, cs, kc0, vc0, slots, nq, nkv, d)
+    act_ref = ops.gate_up_silu_linear(q, sc, wg, wgs, torch.empty(M, I, dtype=torch.float16, device=DEV))
+    # fused
+    assert ops.ln_linear_s4s4_supported(M, N, K)
+    h1 = torch.full_like(hidden, float("nan")); h2 = torch.full_like(hidden, float("nan"))
+    qkv = torch.empty_like(qkv_ref)
+    kc1 = torch.zeros_like(kc0); vc1 = torch.zeros_like(kc0)
+    ops.ln_qkv_rope_linear(hidden, delta, h1, 1e-5, wq, ws, qkv, pos, cs, kc1, vc1, slots, nq, nkv, d)
+    act = ops.ln_gate_up_silu_linear(hidden, delta, h2, 1e-5, wg, wgs, torch.empty(M, I, dtype=torch.float16, device=DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(h1.view(torch.int16), h_ref.view(torch.int16))
+    assert torch.equal(h2.view(torch.int16), h_ref.view(torch.int16))
+    assert torch.equal(qkv.view(torch.int16), qkv_ref.view(torch.int16))
+    assert torch.equal(kc1, kc0) and torch.equal(vc1, vc0)
+    assert torch.equal(act.view(torch.int16), act_ref.view(torch.int16))
+
+
+def test_ln_prologue_rejects_aliasing_and_big_m(ops, oracle):
+    rng = np.random.default_rng(0)
+    K, I = 4096, 64
+    hidden = dev(rand_hidden(rng, 4, K))
+    wg = dev(oracle.pack_i4(rand_w4(rng, 2 * I, K)))
+    wgs = dev(np.ones(2 * I, np.float16))
+    with pytest.raises(RuntimeError):
+        ops.ln_gate_up_silu_linear(hidden, None, hidden, 1e-5, wg, wgs, torch.empty(4, I, dtype=torch.float16, device=DEV))
+    assert not ops.ln_linear_s4s4_supported(17, 128, 4096)
+    assert not ops.ln_linear_s4s4_supported(4, 128, 3072)
+
+
 @pytest.mark.parametrize("M,N,K", [(4, 1000, 4096), (16, 128256, 256), (20, 2048, 2048)])
 def test_linear_f16_within_1e3(ops, oracle, M, N, K):
     rng = np.random.default_rng(N)
