@@ -195,13 +195,25 @@ int qspec_rope_kv_write(const int64_t* positions, qspec_half* qkv, const qspec_h
  * cache  (vllm/attention/backends/flash_attn.py:741-830).  q rows of sequence s are tokens q_start[s]..q_start[s+1]-1
  * and sit at absolute positions ctx_lens[s]-q_len .. ctx_lens[s]-1.  head_size must be 128.
  * workspace: qspec_paged_attention_workspace_bytes(n_seqs*max_q_len, ...) bytes, ZERO-FILLED once before its
- * first use (it starts with the split-merge ticket counters, which every call leaves at zero again). */
+ * first use (it starts with the split-merge ticket counters, which every call leaves at zero again).
+ * out == NULL: the context splits are NOT merged; their partials (o, m, l) stay in the workspace for
+ * qspec_heads_hadamard_merged, which merges them in front of the head transform (the launch boundary then is the
+ * hand-off between the split workgroups and no ticket / fence is needed). */
 size_t qspec_paged_attention_workspace_bytes(int max_tokens, int num_heads, int head_size, int n_splits);
 int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_half* key_cache,
                           const qspec_half* value_cache, const int32_t* block_tables, int max_blocks_per_seq,
                           const int32_t* ctx_lens, const int32_t* q_start, int n_seqs, int tokens, int max_q_len,
                           int num_heads, int num_kv_heads, int head_size, int block_size, float sm_scale, int n_splits,
                           void* workspace, qspec_half* out, void* stream);
+
+/* qspec_heads_hadamard on the un-merged output of qspec_paged_attention(..., out = NULL): split merge (same
+ * expression as the attention kernel's own merge, rounded to fp16 where flash-attn returns fp16) + head Hadamard
+ * (+ row-absmax int4 quant when q != NULL).  attn_workspace / max_tokens (= n_seqs * max_q_len) / n_splits are
+ * those of the attention call.  head_dim 128, 32 or 64 heads.  Bit-identical to merging inside the attention
+ * kernel and calling qspec_heads_hadamard. */
+int qspec_heads_hadamard_merged(const void* attn_workspace, int max_tokens, int n_splits, qspec_half* out_f16, int8_t* q,
+                                qspec_half* scale, float had_scale, float clip_ratio, int tokens, int heads,
+                                int head_dim, void* stream);
 
 /* ---- token side ------------------------------------------------------------------------------- */
 

@@ -11,7 +11,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libqspec_hip.so")
+LIB_PATH = os.environ.get("QSPEC_HIP_LIB") or os.path.join(_HERE, "csrc", "libqspec_hip.so")  # env: instrumented dev builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "qspec_hip.h")
 
 _vp, _i, _f, _i64, _u64, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_uint64,
@@ -51,6 +51,7 @@ SIGNATURES = {
     "qspec_rotary_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _vp]),
     "qspec_reshape_and_cache_flash": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp]),
     "qspec_rope_kv_write": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "qspec_heads_hadamard_merged": (_i, [_vp, _i, _i, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
     "qspec_paged_attention_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "qspec_paged_attention": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp,
                                    _vp, _vp]),

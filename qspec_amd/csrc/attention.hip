@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
     const f16* __restrict__ q, int64_t q_stride, const f16* __restrict__ key_cache, const f16* __restrict__ value_cache,
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
     const int32_t* __restrict__ q_start, int nq, int nkv, int bs_log2, int group_log2, float sm_scale, int n_splits,
-    int n_rb, int* cnt, float* ws_o, float* ws_ml, f16* __restrict__ out) {
+    int n_rb, int* cnt, float* ws_o, float* ws_ml, f16* __restrict__ out, int merge) {
     constexpr int D = 128;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sc = reinterpret_cast<float*>(smem_raw);                          // [16 rows][128 keys] fp32 scores
@@ -357,6 +357,8 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
         ws_ml[o + 1] = row_l[tid];
     }
     QS_STAMP(5);
+    // merge == 0: the consumer kernel (heads_hadamard_merge) combines the splits; the launch boundary is the hand-off
+    if (!merge) return;
     // ---- hand-off: every storing wave drains, one lane releases and takes a ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -444,6 +446,11 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
 #endif
 }
 
+// float offsets of the partials inside the workspace (shared with hadamard.hip:heads_hadamard_merge)
+size_t paged_attention_ws_o_offset() { return QS_ATT_CNT_SLOTS; }
+size_t paged_attention_ws_ml_offset(int Tmax, int nq, int d, int n_splits) {
+    return QS_ATT_CNT_SLOTS + (size_t)Tmax * nq * n_splits * d;
+}
 size_t paged_attention_ws_bytes(int T, int nq, int d, int n_splits) {
     return QS_ATT_CNT_SLOTS * sizeof(int) + (size_t)T * nq * n_splits * (d + 2) * sizeof(float);
 }
@@ -459,6 +466,7 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
                     const int32_t* block_tables, int max_blocks, const int32_t* ctx_lens, const int32_t* q_start,
                     int n_seqs, int max_q_len, int nq, int nkv, int d, int block_size, float sm_scale, int n_splits,
                     float* ws, f16* out, hipStream_t st) {
+    // out == nullptr: leave the per-split partials (o, m, l) in the workspace for heads_hadamard_merge
     if (n_seqs == 0) return 0;
     if (d != 128 || nq % nkv) return -1;
     if (n_splits < 1 || n_splits > QS_ATT_MAXSPLIT) return -3;
@@ -476,7 +484,7 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
                        QS_ATT_CHUNK * QS_ATT_VSTRIDE * 2 + (2 * QS_ATT_MAXR + QS_ATT_MAXR * QS_ATT_MAXSPLIT + 4) * 4;
     hipLaunchKernelGGL(paged_attention_kernel, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), lds, st, q, q_stride,
                        key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv, bs_log2,
-                       group_log2, sm_scale, n_splits, n_rb, cnt, ws_o, ws_ml, out);
+                       group_log2, sm_scale, n_splits, n_rb, cnt, ws_o, ws_ml, out, out != nullptr ? 1 : 0);
     return 0;
 }
 

@@ -211,11 +211,23 @@ int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_hal
     const char* op = "qspec_paged_attention";
     if (n_seqs == 0 || tokens == 0) return 0;
     NONNULL(op, q); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, block_tables); NONNULL(op, ctx_lens);
-    NONNULL(op, q_start); NONNULL(op, workspace); NONNULL(op, out);
+    NONNULL(op, q_start); NONNULL(op, workspace);   /* out == NULL: partials only, see qspec_heads_hadamard_merged */
     if (head_size != 128) return fail("%s: head_size=%d (only 128 is built)", op, head_size);
     if (tokens > n_seqs * max_q_len) return fail("%s: tokens=%d > n_seqs*max_q_len=%d", op, tokens, n_seqs * max_q_len);
     int rc = qspec::paged_attention(CH(q), q_stride, CH(key_cache), CH(value_cache), block_tables, max_blocks_per_seq, ctx_lens, q_start, n_seqs, max_q_len, num_heads, num_kv_heads, head_size, block_size, sm_scale, n_splits, (float*)workspace, H(out), ST);
     return finish(op, rc);
+}
+int qspec_heads_hadamard_merged(const void* attn_workspace, int max_tokens, int n_splits, qspec_half* out_f16, int8_t* q,
+                                qspec_half* scale, float had_scale, float clip_ratio, int tokens, int heads,
+                                int head_dim, void* stream) {
+    const char* op = "qspec_heads_hadamard_merged";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, attn_workspace);
+    if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
+    if (head_dim != 128 || !(heads == 32 || heads == 64))
+        return fail("%s: built for head_dim 128 and 32 / 64 heads (got %d x %d)", op, heads, head_dim);
+    return finish(op, qspec::heads_hadamard_merge((const float*)attn_workspace, max_tokens, n_splits, H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, heads, head_dim, ST));
 }
 int qspec_embedding(const int64_t* ids, const qspec_half* table, qspec_half* out, int tokens, int hidden, int vocab,
                     void* stream) {

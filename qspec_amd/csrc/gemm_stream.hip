@@ -277,9 +277,18 @@ __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs
 
 // NW waves; UB steps of 64 packed bytes per wave and batch (K/2 = 64 * NW * UB * NB bytes, NB batches per tile);
 // NI = K / 1024 for the LN prologue (0 otherwise).
+#ifdef QS_STREAM_STAMPS
+#define QS_SSTAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i])::"memory")
+#else
+#define QS_SSTAMP(i)
+#endif
 template <int EPI, int PRO, int NW, int UB, int NI>
 __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef QS_STREAM_STAMPS
+    long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    QS_SSTAMP(0);
     constexpr int NG = NW / 4;
     constexpr int RB = NW == 4 ? 4 : (NW == 8 ? 2 : 1);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -398,6 +407,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
         load_pre(pre, tile);
         __builtin_amdgcn_sched_barrier(0);
         const bool wh = blockIdx.x == 0 && a.hidden_out != nullptr;
+        QS_SSTAMP(1);
         ln_compute<NI, NG, RB>(a, 0, rg, xq_lds, RS, xs_lds, lnred, wh);
         for (int base = NG * RB; base < a.M; base += NG * RB) {
             ln_load<NI, NG, RB>(a, base, rg);
@@ -437,6 +447,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
     // the NEXT unit as soon as it has been consumed: UB loads per wave stay in flight across tile boundaries,
     // reductions and epilogues.  The last unit is peeled (nothing to refill), so the loop body has no branch
     // around a load and the waits hipcc inserts are the exact counted ones.
+    QS_SSTAMP(2);
     for (int q = 0; q < n_units - 1; q++) {
         int nb = b + 1, nt = tile;
         if (nb == NB) {
@@ -463,9 +474,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
         tile = nt;
         b = nb;
     }
+    QS_SSTAMP(3);
 #pragma unroll
     for (int u = 0; u < UB; u++) use(w[u], b, u);
+    QS_SSTAMP(4);
     finish(tile, par, pre);
+    QS_SSTAMP(5);
+#ifdef QS_STREAM_STAMPS
+    if (PRO == PRO_LN && a.hidden_out && blockIdx.x == 100 && tid == 0) {  // debug build only: stamps into the tail of hidden_out
+        long long* sb = reinterpret_cast<long long*>(a.hidden_out + (size_t)a.M * a.K) - 8;
+        for (int i = 0; i < 6; i++) sb[i] = stamp[i];
+    }
+#endif
 }
 
 // Shape classes: K/2 bytes of a weight row = 64 * NW * UB * NB exactly.

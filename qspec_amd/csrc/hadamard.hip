@@ -246,6 +246,183 @@ __global__ __launch_bounds__(NH * 8) void heads_hadamard_wide_kernel(const f16* 
     }
 }
 
+// heads_hadamard_wide_kernel with the split merge of the attention kernel in front of it: the attention launch
+// (attention.hip, merge = 0) leaves per-split partials o [T, NH, S, 128] and (m, l) [T, NH, S, 2] in its workspace and
+// this kernel combines them -- out = sum_s w_s o_s / sum_s w_s l_s, w_s = e^(m_s - M), splits in order, the same
+// expression as attention.hip's in-kernel merge, rounded to fp16 exactly where flash-attn returns fp16 -- before the
+// head transform.  The launch boundary replaces the release / ticket / acquire hand-off (6 of the kernel's 12 us).
+// Thread (head = tid / 8, 16 columns) merges with 16-byte loads, all issued up front; the merged row goes through
+// LDS to the Hadamard thread mapping.
+template <int NH, bool QUANT>
+__global__ __launch_bounds__(NH * 8) void heads_hadamard_merge_kernel(const float* __restrict__ ws_o,
+                                                                       const float* __restrict__ ws_ml, int S,
+                                                                       f16* __restrict__ out16, int8_t* __restrict__ q,
+                                                                       f16* __restrict__ scale, float had_scale,
+                                                                       float clip) {
+    constexpr int HG = NH / 8, D = 128, SMAX = 8;
+    __shared__ float xl[NH][D];
+    __shared__ __attribute__((aligned(16))) f16 al[NH][D];
+    __shared__ float red[HG];
+    const int t = blockIdx.x, tid = threadIdx.x, dc = tid & 63, hg = tid >> 6;
+    {   // ---- merge
+        const int head = tid >> 3, c0 = (tid & 7) * 16;
+        const size_t th = (size_t)t * NH + head;
+        const float* ob = ws_o + th * S * D + c0;
+        const float* mlb = ws_ml + th * S * 2;
+        float num[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) num[e] = 0.0f;
+        float den = 0.0f;
+        float M = -__builtin_inff();
+        for (int s0 = 0; s0 < S; s0 += SMAX) {   // S <= 8 in one trip: every load in flight before the first use
+            float2 ml[SMAX];
+            f32x4 o[SMAX][4];
+#pragma unroll
+            for (int s2 = 0; s2 < SMAX; s2++) {
+                const int sc = min(s0 + s2, S - 1);
+                ml[s2] = *reinterpret_cast<const float2*>(mlb + sc * 2);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < SMAX; s2++) {
+                const int sc = min(s0 + s2, S - 1);
+#pragma unroll
+                for (int v4 = 0; v4 < 4; v4++) o[s2][v4] = *reinterpret_cast<const f32x4*>(ob + (size_t)sc * D + v4 * 4);
+            }
+            if (s0 == 0) {   // M over ALL splits first (as attention.hip does), the (m, l) of later trips re-read
+                for (int s2 = 0; s2 < S; s2++) M = fmaxf(M, mlb[s2 * 2]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < SMAX; s2++) {
+                if (s0 + s2 < S) {
+                    const float m = ml[s2].x;
+                    const float w = m == -__builtin_inff() ? 0.0f : qexpf(m - M);
+                    den = __builtin_fmaf(w, ml[s2].y, den);
+#pragma unroll
+                    for (int v4 = 0; v4 < 4; v4++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) num[v4 * 4 + e] = __builtin_fmaf(w, o[s2][v4][e], num[v4 * 4 + e]);
+                }
+            }
+        }
+        f16x8 h0, h1;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            h0[e] = f2h(num[e] / den);
+            h1[e] = f2h(num[8 + e] / den);
+        }
+        *reinterpret_cast<f16x8*>(&al[head][c0]) = h0;
+        *reinterpret_cast<f16x8*>(&al[head][c0 + 8]) = h1;
+    }
+    __syncthreads();
+    float v0[8], v1[8];
+#pragma unroll
+    for (int h = 0; h < 8; h++) {
+        const f16x2 a = *reinterpret_cast<const f16x2*>(&al[hg * 8 + h][2 * dc]);
+        v0[h] = h2f(a[0]);
+        v1[h] = h2f(a[1]);
+    }
+#pragma unroll
+    for (int stride = 1; stride < 8; stride <<= 1)
+#pragma unroll
+        for (int h = 0; h < 8; h++)
+            if (!(h & stride)) {
+                float a = v0[h], b = v0[h + stride];
+                v0[h] = a + b;
+                v0[h + stride] = a - b;
+                a = v1[h];
+                b = v1[h + stride];
+                v1[h] = a + b;
+                v1[h + stride] = a - b;
+            }
+#pragma unroll
+    for (int h = 0; h < 8; h++) *reinterpret_cast<float2*>(&xl[hg * 8 + h][2 * dc]) = float2{v0[h], v1[h]};
+    __syncthreads();
+    float amax = 0.0f;
+#pragma unroll
+    for (int h = 0; h < 8; h++) {
+        float x0[HG], x1[HG];
+#pragma unroll
+        for (int j = 0; j < HG; j++) {
+            const float2 p = *reinterpret_cast<const float2*>(&xl[j * 8 + h][2 * dc]);
+            x0[j] = p.x;
+            x1[j] = p.y;
+        }
+#pragma unroll
+        for (int stride = 1; stride < HG; stride <<= 1)
+#pragma unroll
+            for (int j = 0; j < HG; j++)
+                if (!(j & stride)) {
+                    float a = x0[j], b = x0[j + stride];
+                    x0[j] = a + b;
+                    x0[j + stride] = a - b;
+                    a = x1[j];
+                    b = x1[j + stride];
+                    x1[j] = a + b;
+                    x1[j + stride] = a - b;
+                }
+        float r0 = x0[0], r1 = x1[0];
+#pragma unroll
+        for (int j = 1; j < HG; j++) {
+            r0 = hg == j ? x0[j] : r0;
+            r1 = hg == j ? x1[j] : r1;
+        }
+        v0[h] = h2f(f2h(r0 * had_scale));
+        v1[h] = h2f(f2h(r1 * had_scale));
+        if (QUANT) {
+            float a0 = __builtin_fabsf(v0[h]), a1 = __builtin_fabsf(v1[h]);
+            amax = a0 > amax ? a0 : amax;
+            amax = a1 > amax ? a1 : amax;
+        }
+    }
+    const size_t obase = (size_t)t * NH * D + (size_t)hg * 8 * D + 2 * dc;
+    if (!QUANT) {
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            f16x2 o = {f2h(v0[h]), f2h(v1[h])};
+            *reinterpret_cast<f16x2*>(out16 + obase + (size_t)h * D) = o;
+        }
+        return;
+    }
+    amax = wave_max_f(amax);
+    if (dc == 0) red[hg] = amax;
+    __syncthreads();
+    amax = red[0];
+#pragma unroll
+    for (int j = 1; j < HG; j++) amax = fmaxf(amax, red[j]);
+    const f16 sc = f2h(h2f(f2h(amax / 7.0f)) * h2f(f2h(clip)));
+    const float scf = h2f(sc);
+    if (tid == 0) scale[t] = sc;
+#pragma unroll
+    for (int h = 0; h < 8; h++) {
+        int q0 = rni_sat(h2f(f2h(v0[h] / scf)), -8, 7);
+        int q1 = rni_sat(h2f(f2h(v1[h] / scf)), -8, 7);
+        q[(obase + (size_t)h * D) / 2] = (int8_t)pack_nib(q0, q1);
+    }
+}
+
+// partials: the workspace of paged_attention(..., out = nullptr) called for `max_tokens` = n_seqs * max_q_len tokens
+int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out_f16, int8_t* q, f16* scale,
+                         float had_scale, float clip, int T, int heads, int d, hipStream_t st) {
+    if (T == 0) return 0;
+    if (d != 128 || !(heads == 32 || heads == 64) || n_splits < 1 || T > max_tokens) return -1;
+    const float* ws_o = ws + paged_attention_ws_o_offset();
+    const float* ws_ml = ws + paged_attention_ws_ml_offset(max_tokens, heads, d, n_splits);
+    const bool quant = q != nullptr;
+#define QS_HHM(NHV)                                                                                                \
+    if (heads == NHV) {                                                                                             \
+        if (quant)                                                                                                  \
+            hipLaunchKernelGGL((heads_hadamard_merge_kernel<NHV, true>), dim3(T), dim3(NHV * 8), 0, st, ws_o, ws_ml, \
+                               n_splits, out_f16, q, scale, had_scale, clip);                                       \
+        else                                                                                                        \
+            hipLaunchKernelGGL((heads_hadamard_merge_kernel<NHV, false>), dim3(T), dim3(NHV * 8), 0, st, ws_o, ws_ml, \
+                               n_splits, out_f16, q, scale, had_scale, clip);                                       \
+        return 0;                                                                                                   \
+    }
+    QS_HHM(32) QS_HHM(64)
+#undef QS_HHM
+    return -1;
+}
+
 int heads_hadamard(const f16* attn, f16* out_f16, int8_t* q, f16* scale, float had_scale, float clip, int T, int heads,
                    int d, hipStream_t st) {
     if (T == 0) return 0;

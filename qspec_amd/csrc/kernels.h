@@ -19,6 +19,8 @@ int fwht(const f16* x, float scale, f16* out, int64_t rows, int N, hipStream_t s
 int hadk_mix(const f16* y, const f16* hadK, f16* out, int T, int K, int M, hipStream_t st);
 int heads_hadamard(const f16* attn, f16* out_f16, int8_t* q, f16* scale, float had_scale, float clip, int T,
                    int heads, int d, hipStream_t st);
+int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out_f16, int8_t* q, f16* scale,
+                         float had_scale, float clip, int T, int heads, int d, hipStream_t st);
 int silu_mul(const f16* gate_up, f16* out, int T, int I, hipStream_t st);
 int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,
                       float clip, int T, int I, int K, int pre_activated, hipStream_t st);
@@ -77,6 +79,8 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
                     int n_seqs, int max_q_len, int nq, int nkv, int d, int block_size, float sm_scale, int n_splits,
                     float* ws, f16* out, hipStream_t st);
 size_t paged_attention_ws_bytes(int T, int nq, int d, int n_splits);
+size_t paged_attention_ws_o_offset();
+size_t paged_attention_ws_ml_offset(int Tmax, int nq, int d, int n_splits);
 
 // sampler.hip
 int embedding(const int64_t* ids, const f16* table, f16* out, int T, int H, int V, hipStream_t st);

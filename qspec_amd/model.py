@@ -167,6 +167,25 @@ class QuarotLlamaForCausalLM:
         wd = ops.dequant_w4(lin.weight, lin._scales(), self._dq[key])
         return torch.matmul(x, wd.t(), out=out)
 
+    MERGE_IN_HADAMARD = True   # False: the attention kernel merges its context splits itself (ticket + fences)
+
+    def _attention_hadamard(self, qkv, row, kc, vc, md, T, s, attn, q1, sc, had):
+        """Attention + head Hadamard (+ quant when q1 is given, else fp16 into `had`) (quarot_llama.py:213-238).
+        For 32 / 64 heads of 128 the split merge of the attention kernel runs at the head of the Hadamard launch."""
+        cfg = self.config
+        nh = cfg.num_attention_heads
+        B = md.ctx_lens.numel()
+        merged = self.MERGE_IN_HADAMARD and cfg.head_dim == 128 and nh in (32, 64) and md.n_splits <= 64
+        ops.paged_attention(qkv, row, kc, vc, md.block_tables, md.ctx_lens, md.q_start, T, md.max_q_len, nh,
+                            self.sm_scale, md.n_splits, s.attn_ws, None if merged else attn)
+        if merged:
+            ops.heads_hadamard_merged(s.attn_ws, B * md.max_q_len, md.n_splits, T, nh, cfg.head_dim,
+                                      self.head_had_scale, out_f16=had, q=q1, scale=sc)
+        elif q1 is not None:
+            ops.heads_hadamard(attn, self.head_had_scale, q=q1, scale=sc, heads=nh)
+        else:
+            ops.heads_hadamard(attn, self.head_had_scale, out_f16=had, heads=nh)
+
     def weight_bytes(self):
         n = sum(lin.weight.numel() + lin.weight_scales.numel() * 2 for l in self.layers for lin in l.linears())
         return n + self.embed_tokens.numel() * 2 + self.lm_head.numel() * 2
@@ -203,9 +222,7 @@ class QuarotLlamaForCausalLM:
                 # hidden2 = hidden + delta; LN+quant; qkv_proj; rope; kv write                       :373-374,183-226
                 ops.ln_qkv_rope_linear(hidden, delta, hidden2, eps, qkv_w, qkv_s, qkv, positions, self.cos_sin_cache,
                                        kc, vc, md.slot_mapping, nh, nkv, hd)
-                ops.paged_attention(qkv, row, kc, vc, md.block_tables, md.ctx_lens, md.q_start, T, md.max_q_len, nh,
-                                    self.sm_scale, md.n_splits, s.attn_ws, attn)
-                ops.heads_hadamard(attn, self.head_had_scale, q=q1, scale=sc, heads=nh)
+                self._attention_hadamard(qkv, row, kc, vc, md, T, s, attn, q1, sc, None)
                 ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, layer.o_proj.weight, layer.o_proj._scales(), None, o)
                 # hidden = hidden2 + o; LN+quant; gate_up; silu*up                                   :380-388,266-284
                 ops.ln_gate_up_silu_linear(hidden2, o, hidden, eps, gu_w, gu_s, act)
@@ -229,16 +246,14 @@ class QuarotLlamaForCausalLM:
                 else:
                     self._w4a16(normed, layer.qkv_proj, qkv)
                 ops.rope_kv_write(positions, qkv, self.cos_sin_cache, kc, vc, md.slot_mapping, nh, nkv, hd)
-            ops.paged_attention(qkv, row, kc, vc, md.block_tables, md.ctx_lens, md.q_start, T, md.max_q_len, nh,
-                                self.sm_scale, md.n_splits, s.attn_ws, attn)
-            # heads hadamard (+ quant) -> o_proj -> residual + post_attention_layernorm                 :231-243,380-387
+            # attention -> heads hadamard (+ quant) -> o_proj -> residual + post_attention_layernorm     :231-243,380-387
             if w4a4:
-                ops.heads_hadamard(attn, self.head_had_scale, q=q1, scale=sc, heads=nh)
+                self._attention_hadamard(qkv, row, kc, vc, md, T, s, attn, q1, sc, None)
                 ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, layer.o_proj.weight, layer.o_proj._scales(), None, o)
                 ops.add_rms_norm_i4(q1, sc, hidden, hidden, o, eps)
                 x, xs = q1, sc
             else:
-                ops.heads_hadamard(attn, self.head_had_scale, out_f16=had, heads=nh)
+                self._attention_hadamard(qkv, row, kc, vc, md, T, s, attn, None, None, had)
                 if tp_on:   # row-parallel o_proj over this rank's K range of the shared buffer, then all-reduce
                     k0, k1 = self.tp.k_range(cfg.hidden_size)
                     ops.w4a16_linear_ksliced(had, layer.o_proj.weight, layer.o_proj._scales(), o, k0, k1)

@@ -331,7 +331,15 @@ def paged_attention(q, q_stride, key_cache, value_cache, block_tables, ctx_lens,
     _call("qspec_paged_attention", q.data_ptr(), q_stride, _chk(key_cache, "key_cache", _F16),
           _chk(value_cache, "value_cache", _F16), _chk(block_tables, "block_tables", _I32), block_tables.shape[1],
           _chk(ctx_lens, "ctx_lens", _I32), _chk(q_start, "q_start", _I32), n_seqs, tokens, max_q_len, num_heads, nkv,
-          d, bs, float(sm_scale), n_splits, workspace.data_ptr(), _chk(out, "out", _F16), _stream())
+          d, bs, float(sm_scale), n_splits, workspace.data_ptr(), _opt(out, "out", _F16), _stream())
+
+
+def heads_hadamard_merged(workspace, max_tokens, n_splits, tokens, heads, head_dim, had_scale: float, out_f16=None,
+                          q=None, scale=None, clip_ratio: float = 1.0):
+    """Split merge of paged_attention(..., out=None) + heads_hadamard in one launch."""
+    _call("qspec_heads_hadamard_merged", workspace.data_ptr(), max_tokens, n_splits, _opt(out_f16, "out_f16", _F16),
+          _opt(q, "q", _I8), _opt(scale, "scale", _F16), float(had_scale), float(clip_ratio), tokens, heads, head_dim,
+          _stream())
 
 
 # ------------------------------------------------------------------ token side

@@ -1,0 +1,16 @@
+"""Dev tool: phase stamps of the LN-prologue W4A4 GEMM (needs the -DQS_STREAM_STAMPS build via QSPEC_HIP_LIB)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from qspec_amd import ops
+dev = "cuda:0"
+M, H, I = int(os.environ.get("M", 4)), 4096, 14336
+hidden = torch.randn(M, H, device=dev).half(); delta = (torch.randn(M, H, device=dev) * 0.3).half(); hout = torch.empty_like(hidden)
+ws = [torch.randint(-128, 127, (2 * I, H // 2), dtype=torch.int8, device=dev) for _ in range(6)]
+sc = torch.rand(2 * I, device=dev).half() * 0.01
+act = torch.empty(M, I, dtype=torch.float16, device=dev)
+for w in ws:
+    ops.ln_gate_up_silu_linear(hidden, delta, hout, 1e-5, w, sc, act)
+torch.cuda.synchronize()
+st = hout.view(-1)[-32:].view(torch.int64).cpu().tolist()
+print("cycles [load issue, LN compute, main loop, last compute, last finish]:", [st[i + 1] - st[i] for i in range(5)])

@@ -476,6 +476,40 @@ def test_paged_attention_within_1e3(ops, oracle, ctx_lens, q_len):
 
 # ------------------------------------------------------------------ token side
 
+@pytest.mark.parametrize("ctx_lens,q_len,n_splits", [([37, 128, 129, 500], 1, 8), ([37, 130, 260, 515], 4, 5),
+                                                     ([1500], 2, 12), ([5, 9], 4, 3)])
+def test_heads_hadamard_merged_equals_attention_merge_then_hadamard(ops, oracle, ctx_lens, q_len, n_splits):
+    """Split merge moved from the attention kernel into the head-Hadamard launch: bit-identical outputs (int4 bytes,
+    scales, fp16 rows) to the attention kernel merging its own splits followed by the plain head Hadamard."""
+    rng = np.random.default_rng(sum(ctx_lens) * 3 + q_len)
+    nq, nkv, d, bs = 32, 8, 128, 16
+    n_seqs = len(ctx_lens)
+    bt, kc, vc = make_paged(rng, n_seqs, ctx_lens, nkv, d, bs)
+    T = n_seqs * q_len
+    row = (nq + 2 * nkv) * d
+    qkv = dev((rng.standard_normal((T, row)) * 0.5).astype(np.float16))
+    q_start = dev((np.arange(n_seqs + 1) * q_len).astype(np.int32))
+    ctx = dev(np.array(ctx_lens, np.int32))
+    sc = d ** -0.5
+    had_scale = oracle.rsqrt_scale(nq)
+    args = (qkv, row, dev(kc), dev(vc), dev(bt), ctx, q_start, T, q_len, nq, sc, n_splits)
+    ws = torch.zeros(ops.paged_attention_workspace_bytes(T, nq, d, n_splits), dtype=torch.uint8, device=DEV)
+    attn = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
+    ops.paged_attention(*args, ws, attn)
+    q0 = torch.empty(T, nq * d // 2, dtype=torch.int8, device=DEV); s0 = torch.empty(T, dtype=torch.float16, device=DEV)
+    o0 = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
+    ops.heads_hadamard(attn, had_scale, q=q0, scale=s0, heads=nq)
+    ops.heads_hadamard(attn, had_scale, out_f16=o0, heads=nq)
+    ws2 = torch.zeros_like(ws)
+    ops.paged_attention(*args, ws2, None)
+    q1 = torch.empty_like(q0); s1 = torch.empty_like(s0); o1 = torch.empty_like(o0)
+    ops.heads_hadamard_merged(ws2, T, n_splits, T, nq, d, had_scale, q=q1, scale=s1)
+    ops.heads_hadamard_merged(ws2, T, n_splits, T, nq, d, had_scale, out_f16=o1)
+    torch.cuda.synchronize()
+    assert torch.equal(q0, q1) and torch.equal(s0.view(torch.int16), s1.view(torch.int16))
+    assert torch.equal(o0.view(torch.int16), o1.view(torch.int16))
+
+
 def test_embedding(ops):
     rng = np.random.default_rng(0)
     V, H = 1000, 4096
