@@ -147,10 +147,11 @@ int qspec_ln_qkv_rope_linear_s4s4(const qspec_half* hidden_in, const qspec_half*
                                   float eps, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M, int N,
                                   int K, const int64_t* positions, const qspec_half* cos_sin_cache,
                                   qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
-                                  int num_heads, int num_kv_heads, int head_size, int rot_dim, void* stream);
+                                  int num_heads, int num_kv_heads, int head_size, int rot_dim, void* sync_workspace,
+                                  void* stream);
 int qspec_ln_gate_up_silu_linear_s4s4(const qspec_half* hidden_in, const qspec_half* delta, qspec_half* hidden_out,
                                       float eps, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
-                                      int intermediate, int K, void* stream);
+                                      int intermediate, int K, void* sync_workspace, void* stream);
 int qspec_ln_linear_s4s4_supported(int M, int N, int K);   /* 1 if the two entries above accept the shape */
 
 /* Tensor-parallel views of the SAME buffers (no reference counterpart: the reference QSpec model has no TP).

@@ -391,7 +391,8 @@ int qspec_ln_qkv_rope_linear_s4s4(const qspec_half* hidden_in, const qspec_half*
                                   float eps, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M, int N,
                                   int K, const int64_t* positions, const qspec_half* cos_sin_cache,
                                   qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
-                                  int num_heads, int num_kv_heads, int head_size, int rot_dim, void* stream) {
+                                  int num_heads, int num_kv_heads, int head_size, int rot_dim, void* sync_workspace,
+                                  void* stream) {
     const char* op = "qspec_ln_qkv_rope_linear_s4s4";
     if (M == 0) return 0;
     NONNULL(op, hidden_in); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, qkv); NONNULL(op, positions);
@@ -402,11 +403,12 @@ int qspec_ln_qkv_rope_linear_s4s4(const qspec_half* hidden_in, const qspec_half*
         return fail("%s: need M <= 16, N %% 16 == 0, K in {1024, 2048, 4096, 5120, 8192} (M=%d N=%d K=%d)", op, M, N, K);
     qspec::StreamActs x;
     x.hidden_in = CH(hidden_in); x.delta = CH(delta); x.hidden_out = H(hidden_out); x.eps = eps;
+    x.sync = reinterpret_cast<int*>(sync_workspace);
     return finish(op, qspec::gemm_w4a4_stream_qkv_rope(x, wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST));
 }
 int qspec_ln_gate_up_silu_linear_s4s4(const qspec_half* hidden_in, const qspec_half* delta, qspec_half* hidden_out,
                                       float eps, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
-                                      int intermediate, int K, void* stream) {
+                                      int intermediate, int K, void* sync_workspace, void* stream) {
     const char* op = "qspec_ln_gate_up_silu_linear_s4s4";
     if (M == 0) return 0;
     NONNULL(op, hidden_in); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
@@ -415,8 +417,10 @@ int qspec_ln_gate_up_silu_linear_s4s4(const qspec_half* hidden_in, const qspec_h
         return fail("%s: need M <= 16, intermediate %% 8 == 0, K in {1024, 2048, 4096, 5120, 8192} (M=%d I=%d K=%d)", op, M, intermediate, K);
     qspec::StreamActs x;
     x.hidden_in = CH(hidden_in); x.delta = CH(delta); x.hidden_out = H(hidden_out); x.eps = eps;
+    x.sync = reinterpret_cast<int*>(sync_workspace);
     return finish(op, qspec::gemm_w4a4_stream_gate_up_silu(x, wq, CH(ws), H(act), M, intermediate, K, ST));
 }
+size_t qspec_ln_linear_workspace_bytes(void) { return qspec::gemm_w4a4_stream_sync_bytes(); }
 int qspec_ln_linear_s4s4_supported(int M, int N, int K) { return qspec::gemm_w4a4_stream_supported(M, N, K, true) ? 1 : 0; }
 
 }  // extern "C"

@@ -27,7 +27,7 @@
 namespace qspec {
 
 enum { SEPI_PLAIN = 0, SEPI_QKV = 1, SEPI_GATEUP = 2 };
-enum { PRO_Q = 0, PRO_LN = 1 };
+enum { PRO_Q = 0, PRO_LN = 1, PRO_LNH = 2 };  // LNH: LN by a few producer workgroups, handed to the rest through L2
 
 struct StreamArgs {
     const int8_t* xq;       // PRO_Q : [M, K/2] packed int4 activations
@@ -36,6 +36,7 @@ struct StreamArgs {
     const f16* delta;       // PRO_LN: [M, K] output of the previous projection (added first) or nullptr
     f16* hidden_out;        // PRO_LN: [M, K] updated residual stream (written by workgroup 0) or nullptr
     float eps;
+    int* sync;              // PRO_LNH: hand-off workspace (gemm_w4a4_stream_sync_bytes(), zero-filled once)
     const uint8_t* wq;      // [N, K/2]
     const f16* ws;          // [N]
     f16* out;
@@ -398,7 +399,86 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
 
     // ---- prologue: activations -> LDS.  Their loads are issued BEFORE the first weight batch (results return in
     // issue order), the arithmetic runs underneath the weights' latency.
-    if (PRO == PRO_LN) {
+    if (PRO == PRO_LNH) {
+        // The norm is NOT recomputed by every workgroup: the first P workgroups ("producers") each normalise and
+        // quantise NG rows (one per 256-thread group) and publish the packed rows through memory; every workgroup
+        // meanwhile has its first weight batch in flight, waits for the P flags and copies the M x K/2 bytes into
+        // LDS.  Hand-off without fences (MI355X_MICROARCH.md, "Valid forms"): write-through (sc0 sc1) stores, every
+        // storing wave drains vmcnt, workgroup barrier, one lane's flag store; the consumer's polling lane sees the
+        // flags, the workgroup barrier releases the other waves, every load of the published bytes is an sc1 load.
+        // The call cleans up after itself: each workgroup takes a ticket once it has read the rows, the last one
+        // zeroes flags and ticket counter for the next call (launch boundary orders that against the next call).
+        const int P = (a.M + NG - 1) / NG;
+        int* flags = a.sync;
+        int* done = a.sync + 16;
+        unsigned char* xq_glob = reinterpret_cast<unsigned char*>(a.sync + 32);
+        u32* xs_glob = reinterpret_cast<u32*>(xq_glob + (size_t)16 * Kb);
+        if ((int)blockIdx.x < P) {
+            LnRegs<NI, 1> rg;
+            const int base = blockIdx.x * NG;
+            ln_load<NI, NG, 1>(a, base, rg);
+            ln_compute<NI, NG, 1>(a, base, rg, xq_lds, RS, xs_lds, lnred, a.hidden_out != nullptr);
+            const int nrows = min(NG, a.M - base), per_row = Kb >> 3;
+            for (int i = tid; i < nrows * per_row; i += NW * 64) {
+                const int row = base + i / per_row, q8 = i % per_row;
+                const uint64_t v = *reinterpret_cast<const uint64_t*>(xq_lds + (size_t)row * RS + q8 * 8);
+                __hip_atomic_store(reinterpret_cast<uint64_t*>(xq_glob + (size_t)row * Kb + q8 * 8), v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid < nrows)
+                __hip_atomic_store(&xs_glob[base + tid], __builtin_bit_cast(u32, xs_lds[base + tid]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(&flags[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++) w[u] = *reinterpret_cast<const u32x4*>(wp0 + step_off<NW, UB>(wave, u));
+        load_pre(pre, tile);
+        QS_SSTAMP(1);
+        if (tid == 0) {
+            for (int guard = 0; guard < (1 << 22); guard++) {   // bounded: a lost producer gives wrong numbers, not a hang
+                int ok = 1;
+                for (int i = 0; i < P; i++)
+                    ok &= __hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        __syncthreads();
+        {
+            const int per_row = Kb >> 3, total = a.M * per_row;
+            constexpr int FI = 2;   // M = 4, K = 4096, 512 threads: both items of a thread in flight together
+            uint64_t v[FI];
+            int off[FI];
+#pragma unroll
+            for (int f = 0; f < FI; f++) {
+                const int i = min(tid + f * NW * 64, total - 1);
+                const int row = i / per_row, q8 = i - row * per_row;
+                off[f] = row * RS + q8 * 8;
+                v[f] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(xq_glob + (size_t)row * Kb + q8 * 8),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const u32 xsb = __hip_atomic_load(&xs_glob[tid < a.M ? tid : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int f = 0; f < FI; f++) *reinterpret_cast<uint64_t*>(xq_lds + off[f]) = v[f];
+            for (int i = tid + FI * NW * 64; i < total; i += NW * 64) {
+                const int row = i / per_row, q8 = i - row * per_row;
+                *reinterpret_cast<uint64_t*>(xq_lds + (size_t)row * RS + q8 * 8) =
+                    __hip_atomic_load(reinterpret_cast<const uint64_t*>(xq_glob + (size_t)row * Kb + q8 * 8),
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid < a.M) xs_lds[tid] = __builtin_bit_cast(float, xsb);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int ticket = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == (int)gridDim.x - 1) {
+                for (int i = 0; i < P; i++) __hip_atomic_store(&flags[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    } else if (PRO == PRO_LN) {
         LnRegs<NI, RB> rg;
         ln_load<NI, NG, RB>(a, 0, rg);
         __builtin_amdgcn_sched_barrier(0);
@@ -481,7 +561,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
     finish(tile, par, pre);
     QS_SSTAMP(5);
 #ifdef QS_STREAM_STAMPS
-    if (PRO == PRO_LN && a.hidden_out && blockIdx.x == 100 && tid == 0) {  // debug build only: stamps into the tail of hidden_out
+    if (PRO != PRO_Q && a.hidden_out && blockIdx.x == 100 && tid == 0) {  // debug build only: stamps into the tail of hidden_out
         long long* sb = reinterpret_cast<long long*>(a.hidden_out + (size_t)a.M * a.K) - 8;
         for (int i = 0; i < 6; i++) sb[i] = stamp[i];
     }
@@ -519,8 +599,8 @@ static int g_stream_cap = 0;  // workgroups per launch above which a workgroup l
 static int stream_cap() {
     if (g_stream_cap == 0) {
         const char* e = getenv("QSPEC_STREAM_CAP");
-        g_stream_cap = e ? atoi(e) : 512;
-        if (g_stream_cap < 1) g_stream_cap = 512;
+        g_stream_cap = e ? atoi(e) : 256;   // one workgroup per CU measured best (bench_stream.py)
+        if (g_stream_cap < 1) g_stream_cap = 256;
     }
     return g_stream_cap;
 }
@@ -536,7 +616,8 @@ static int launch_stream_inst(const StreamArgs& a, hipStream_t st) {
             return -8;
         attr_set = lds;
     }
-    const int cap = stream_cap();
+    int cap = stream_cap();
+    if (PRO == PRO_LNH && cap > 256) cap = 256;   // the fence-free hand-off is calibrated for one workgroup per CU
     int grid = a.ntiles;
     if (grid > cap) {
         const int per = (a.ntiles + cap - 1) / cap;
@@ -560,6 +641,14 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
         return -1;
     }
     // LN prologue: the reference's 1024 virtual threads -> K a multiple of 1024; one batch per tile
+    if (a.sync) {   // producers + hand-off
+        if (a.K == 4096) return launch_stream_inst<EPI, PRO_LNH, 8, 4, 4>(a, st);
+        if (a.K == 8192) return launch_stream_inst<EPI, PRO_LNH, 8, 8, 8>(a, st);
+        if (a.K == 5120) return launch_stream_inst<EPI, PRO_LNH, 8, 5, 5>(a, st);
+        if (a.K == 2048) return launch_stream_inst<EPI, PRO_LNH, 4, 4, 2>(a, st);
+        if (a.K == 1024) return launch_stream_inst<EPI, PRO_LNH, 4, 2, 1>(a, st);
+        return -1;
+    }
     if (a.K == 4096) return launch_stream_inst<EPI, PRO_LN, 8, 4, 4>(a, st);
     if (a.K == 8192) return launch_stream_inst<EPI, PRO_LN, 8, 8, 8>(a, st);
     if (a.K == 5120) return launch_stream_inst<EPI, PRO_LN, 8, 5, 5>(a, st);
@@ -567,6 +656,8 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
     if (a.K == 1024) return launch_stream_inst<EPI, PRO_LN, 4, 2, 1>(a, st);
     return -1;
 }
+
+size_t gemm_w4a4_stream_sync_bytes() { return 32 * sizeof(int) + (size_t)16 * (8192 / 2) + 16 * sizeof(float) + 64; }
 
 bool gemm_w4a4_stream_supported(int M, int N, int K, bool ln) {
     StreamShape sh;
@@ -580,7 +671,7 @@ int gemm_w4a4_stream(const StreamActs& x, const int8_t* wq, const f16* ws, f16* 
                      hipStream_t st) {
     if (!gemm_w4a4_stream_supported(M, N, K, x.hidden_in != nullptr)) return -1;
     StreamArgs a{};
-    a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps;
+    a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps; a.sync = x.sync;
     a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = out; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
     return launch_stream<SEPI_PLAIN>(a, x.hidden_in != nullptr, st);
 }
@@ -591,7 +682,7 @@ int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* 
     if (d != 128 || rot_dim != 128 || N != (nq + 2 * nkv) * 128) return -1;
     if (!gemm_w4a4_stream_supported(M, N, K, x.hidden_in != nullptr)) return -1;
     StreamArgs a{};
-    a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps;
+    a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps; a.sync = x.sync;
     a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = qkv; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
     a.positions = positions; a.cos_sin_cache = cos_sin_cache; a.key_cache = key_cache; a.value_cache = value_cache;
     a.slot_mapping = slot_mapping; a.nq = nq; a.nkv = nkv;
@@ -603,7 +694,7 @@ int gemm_w4a4_stream_gate_up_silu(const StreamActs& x, const int8_t* wq, const f
     if (I % 8) return -1;
     if (!gemm_w4a4_stream_supported(M, 2 * I, K, x.hidden_in != nullptr)) return -1;
     StreamArgs a{};
-    a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps;
+    a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps; a.sync = x.sync;
     a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = act; a.M = M; a.N = 2 * I; a.K = K; a.ntiles = I / 8;
     a.I = I;
     return launch_stream<SEPI_GATEUP>(a, x.hidden_in != nullptr, st);

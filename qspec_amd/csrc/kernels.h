@@ -56,7 +56,9 @@ struct StreamActs {
     const f16* delta = nullptr;
     f16* hidden_out = nullptr;
     float eps = 0.0f;
+    int* sync = nullptr;   // gemm_w4a4_stream_sync_bytes() bytes, zero-filled once: LN by producer workgroups + hand-off
 };
+size_t gemm_w4a4_stream_sync_bytes();
 bool gemm_w4a4_stream_supported(int M, int N, int K, bool ln);
 int gemm_w4a4_stream(const StreamActs& x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K,
                      hipStream_t st);

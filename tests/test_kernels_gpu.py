@@ -333,10 +333,13 @@ def test_gate_up_silu_linear_and_mlp_hadamard_equal_unfused(ops, oracle, golden_
 
 @pytest.mark.parametrize("M,K,with_delta", [(4, 4096, True), (1, 4096, False), (16, 4096, True), (3, 2048, True),
                                             (7, 5120, True), (4, 8192, True), (5, 1024, True)])
-def test_ln_prologue_gemms_equal_ln_then_gemm(ops, oracle, M, K, with_delta):
+@pytest.mark.parametrize("handoff", [False, True])
+def test_ln_prologue_gemms_equal_ln_then_gemm(ops, oracle, M, K, with_delta, handoff, monkeypatch):
     """The draft pass's fused launches (residual add + LN + int4 quant in the GEMM prologue) against the separate
     LN kernel (oracle-checked above) followed by the GEMM entry (oracle-checked above): bit for bit, including the
     residual stream written by workgroup 0 and the KV cache."""
+    monkeypatch.setattr(ops, "LN_HANDOFF", handoff)   # norm recomputed per workgroup / by producers + hand-off
+    monkeypatch.setattr(ops, "LN_HANDOFF_MIN_M", 1)
     rng = np.random.default_rng(M * 7 + K)
     nq, nkv, d, bs = 4, 2, 128, 16
     N = (nq + 2 * nkv) * d
@@ -377,6 +380,49 @@ def test_ln_prologue_gemms_equal_ln_then_gemm(ops, oracle, M, K, with_delta):
     assert torch.equal(qkv.view(torch.int16), qkv_ref.view(torch.int16))
     assert torch.equal(kc1, kc0) and torch.equal(vc1, vc0)
     assert torch.equal(act.view(torch.int16), act_ref.view(torch.int16))
+
+
+def test_ln_handoff_stress_back_to_back(ops, oracle, monkeypatch):
+    """The fence-free producer -> consumer hand-off of the LN-prologue GEMMs under back-to-back launches with
+    different inputs each time (a stale flag or a stale row would reuse the previous launch's activations), at the
+    real layer shapes, eagerly and replayed from a hipGraph; every output word is checked."""
+    rng = np.random.default_rng(11)
+    M, K, I = 4, 4096, 14336
+    nin = 6
+    hid = [dev(rand_hidden(rng, M, K)) for _ in range(nin)]
+    dlt = [dev(rand_hidden(rng, M, K, 0.3)) for _ in range(nin)]
+    wg = dev(rng.integers(-128, 128, (2 * I, K // 2)).astype(np.int8))
+    wgs = dev((rng.random(2 * I) * 0.01 + 0.001).astype(np.float16))
+    hout = torch.empty_like(hid[0])
+    monkeypatch.setattr(ops, "LN_HANDOFF_MIN_M", 1)
+    ops.LN_HANDOFF = False
+    try:
+        ref = [ops.ln_gate_up_silu_linear(hid[i], dlt[i], hout, 1e-5, wg, wgs,
+                                          torch.empty(M, I, dtype=torch.float16, device=DEV)).clone() for i in range(nin)]
+    finally:
+        ops.LN_HANDOFF = True
+    n = 60
+    outs = [torch.empty(M, I, dtype=torch.float16, device=DEV) for _ in range(n)]
+
+    def body():
+        for j in range(n):
+            ops.ln_gate_up_silu_linear(hid[j % nin], dlt[j % nin], hout, 1e-5, wg, wgs, outs[j])
+    body()
+    torch.cuda.synchronize()
+    for j in range(n):
+        assert torch.equal(outs[j].view(torch.int16), ref[j % nin].view(torch.int16)), j
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    for rep in range(5):
+        for o in outs:
+            o.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for j in range(n):
+            assert torch.equal(outs[j].view(torch.int16), ref[j % nin].view(torch.int16)), (rep, j)
+    ws = ops.ln_linear_workspace(torch.device(DEV))
+    assert int(ws[:128].view(torch.int32).abs().sum().item()) == 0   # flags and ticket counter left at zero
 
 
 def test_ln_prologue_rejects_aliasing_and_big_m(ops, oracle):
