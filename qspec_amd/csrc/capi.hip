@@ -160,6 +160,8 @@ int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* 
     if (M == 0 || N == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, out);
     if (N % 16 || K % 128 || K <= 0) return fail("%s: need N %% 16 == 0 and K %% 128 == 0 (N=%d K=%d)", op, N, K);
+    if (!bias && use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K))
+        return finish(op, qspec::gemm_w4a16_stream(CH(x), 0, wq, 0, CH(ws), H(out), M, N, K, ST));
     return finish(op, qspec::gemm_w4a16(CH(x), wq, CH(ws), CH(bias), H(out), M, N, K, workspace, ST));
 }
 int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, int M, int N, int K, void* stream) {
@@ -338,6 +340,8 @@ int qspec_qkv_rope_linear_w4a16(const qspec_half* x, const int8_t* wq, const qsp
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, qkv); NONNULL(op, positions);
     NONNULL(op, cos_sin_cache); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
     if (head_size != 128 || rot_dim != 128) return fail("%s: head_size and rot_dim must be 128", op);
+    if (use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K))
+        return finish(op, qspec::gemm_w4a16_stream_qkv_rope(CH(x), wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST));
     return finish(op, qspec::gemm_w4a16_qkv_rope(CH(x), wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, workspace, ST));
 }
 int qspec_gate_up_silu_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
@@ -357,6 +361,8 @@ int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const
     const char* op = "qspec_gate_up_silu_linear_w4a16";
     if (M == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
+    if (use_stream() && qspec::gemm_w4a16_stream_supported(M, 2 * intermediate, K))
+        return finish(op, qspec::gemm_w4a16_stream_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, 0, intermediate, ST));
     return finish(op, qspec::gemm_w4a16_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, 0, intermediate, workspace, ST));
 }
 
@@ -376,6 +382,8 @@ int qspec_w4a16_linear_ksliced(const qspec_half* x, int64_t ldx, const int8_t* w
     if (M == 0 || N == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, out);
     if (N % 16 || K % 128 || ldw_bytes % 16 || ldx % 8) return fail("%s: need N%%16, K%%128, ldw%%16, ldx%%8 == 0", op);
+    if (use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K))
+        return finish(op, qspec::gemm_w4a16_stream(CH(x), ldx, wq, ldw_bytes, CH(ws), H(out), M, N, K, ST));
     return finish(op, qspec::gemm_w4a16_strided(CH(x), ldx, wq, ldw_bytes, CH(ws), H(out), M, N, K, workspace, ST));
 }
 int qspec_gate_up_silu_linear_w4a16_shard(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act,
@@ -384,6 +392,8 @@ int qspec_gate_up_silu_linear_w4a16_shard(const qspec_half* x, const int8_t* wq,
     const char* op = "qspec_gate_up_silu_linear_w4a16_shard";
     if (M == 0 || num_channels == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
+    if (use_stream() && qspec::gemm_w4a16_stream_supported(M, 2 * intermediate, K))
+        return finish(op, qspec::gemm_w4a16_stream_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, first_channel, num_channels, ST));
     return finish(op, qspec::gemm_w4a16_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, first_channel, num_channels, workspace, ST));
 }
 

@@ -37,6 +37,9 @@ struct StreamArgs {
     f16* hidden_out;        // PRO_LN: [M, K] updated residual stream (written by workgroup 0) or nullptr
     float eps;
     int* sync;              // PRO_LNH: hand-off workspace (gemm_w4a4_stream_sync_bytes(), zero-filled once)
+    const f16* x;           // W4A16: [M, K] fp16 activations, row stride ldx halves
+    int64_t ldx, ldw;       // W4A16: activation row stride (halves) / packed weight row stride (bytes); 0 = dense
+    int tile0;              // W4A16: first tile of the launch (column-parallel shards)
     const uint8_t* wq;      // [N, K/2]
     const f16* ws;          // [N]
     f16* out;
@@ -568,6 +571,170 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
 #endif
 }
 
+// ------------------------------------------------------------------ W4A16 (verify pass), same streaming skeleton
+// out[m,n] = h( (sum_k f(x[m,k]) * w[n,k]) * f(sw[n]) ), fp32 accumulate  (bitblas.Matmul, quarot_nn/linear.py:102-124)
+// over the SAME packed buffer.  A wave always owns the same K steps of every tile, so its activation fragments
+// (M <= 16 rows x its K slice, 16 * UB registers per lane) are loaded ONCE, pre-shuffled into the nibble order of
+// the dequantiser, and stay in registers for the whole kernel: no LDS tile, no per-step activation traffic (a
+// 16-row weight tile alone would need 4x its own bytes in activations per step).
+__device__ __forceinline__ f16x8 sdequant_s4x8(u32 p) {   // = gemm.hip:dequant_s4x8
+    p ^= 0x88888888u;
+    const u32 q = p >> 8;
+    const u32 r0 = (p & 0x000F000Fu) | 0x64006400u, r1 = (p & 0x00F000F0u) | 0x64006400u;
+    const u32 r2 = (q & 0x000F000Fu) | 0x64006400u, r3 = (q & 0x00F000F0u) | 0x64006400u;
+    const f16x2 c1032 = {(f16)1032.0f, (f16)1032.0f}, c16 = {(f16)0.0625f, (f16)0.0625f}, c72 = {(f16)72.0f, (f16)72.0f};
+    const f16x2 h0 = __builtin_bit_cast(f16x2, r0) - c1032;
+    const f16x2 h1 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, r1), c16, -c72);
+    const f16x2 h2 = __builtin_bit_cast(f16x2, r2) - c1032;
+    const f16x2 h3 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, r3), c16, -c72);
+    return f16x8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+}
+__device__ __forceinline__ f16x8 sshuffle_act8(u32x4 a) {  // 8 consecutive fp16 -> order 0,4,1,5,2,6,3,7
+    u32x4 o;
+    o[0] = __builtin_amdgcn_perm(a[2], a[0], 0x05040100u);
+    o[1] = __builtin_amdgcn_perm(a[2], a[0], 0x07060302u);
+    o[2] = __builtin_amdgcn_perm(a[3], a[1], 0x05040100u);
+    o[3] = __builtin_amdgcn_perm(a[3], a[1], 0x07060302u);
+    return __builtin_bit_cast(f16x8, o);
+}
+
+template <int EPI, int NW, int UB>
+__global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int Kb = a.K >> 1;
+    const size_t ldw = a.ldw ? (size_t)a.ldw : (size_t)Kb, ldx = a.ldx ? (size_t)a.ldx : (size_t)a.K;
+    float* red = reinterpret_cast<float*>(smem);                     // [2][NW][256]
+    f16* ex = reinterpret_cast<f16*>(red + 2 * NW * 256);            // [2][256]
+    const int el = tid & 63, reg = (tid >> 6) & 3;
+    const int c = el & 15, m = 4 * (el >> 4) + reg;
+    const bool ethread = tid < 256 && m < a.M;
+    const int mc = m < a.M ? m : 0;
+    int64_t pos_m = 0, slot_m = -1;
+    if (EPI == SEPI_QKV) {
+        pos_m = a.positions[mc];
+        slot_m = a.slot_mapping[mc];
+    }
+    struct Pre {
+        f16 swn, cf, sf;
+    };
+    auto load_pre = [&](Pre& pre, int tile) {
+        pre.swn = a.ws[stile_row<EPI>(tile, c, a.I)];
+        if (EPI == SEPI_QKV) {
+            const int o = (tile & 7) * 8 + (c & 7);
+            const f16* cs = a.cos_sin_cache + pos_m * 128;
+            pre.cf = cs[o];
+            pre.sf = cs[64 + o];
+        }
+    };
+    auto wptr = [&](int tile) -> const uint8_t* {
+        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I) * ldw + g * 16;
+    };
+    // activation fragments of this wave's K slice (rows >= M repeat row 0: their outputs are never stored)
+    u32x4 araw[UB][4];
+    {
+        const f16* xrow = a.x + (size_t)(r < a.M ? r : 0) * ldx + g * 32;
+#pragma unroll
+        for (int u = 0; u < UB; u++)
+#pragma unroll
+            for (int dd = 0; dd < 4; dd++)
+                araw[u][dd] = *reinterpret_cast<const u32x4*>(xrow + 2 * step_off<NW, UB>(wave, u) + dd * 8);
+    }
+    int tile = a.tile0 + blockIdx.x, par = 0;
+    const int tile_end = a.tile0 + a.ntiles;
+    const int my_tiles = (tile_end - tile + (int)gridDim.x - 1) / (int)gridDim.x;
+    u32x4 w[UB];
+    Pre pre = {};
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const uint8_t* wp0 = wptr(tile);
+#pragma unroll
+        for (int u = 0; u < UB; u++) w[u] = *reinterpret_cast<const u32x4*>(wp0 + step_off<NW, UB>(wave, u));
+        load_pre(pre, tile);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f16x8 af[UB][4];
+#pragma unroll
+    for (int u = 0; u < UB; u++)
+#pragma unroll
+        for (int dd = 0; dd < 4; dd++) af[u][dd] = sshuffle_act8(araw[u][dd]);
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto use = [&](const u32x4& wv, int u) {
+#pragma unroll
+        for (int dd = 0; dd < 4; dd++)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u][dd], sdequant_s4x8(wv[dd]), acc, 0, 0, 0);
+    };
+    auto finish = [&](int tile, int par, const Pre& pre) {
+        float* rb = red + par * NW * 256;
+#pragma unroll
+        for (int i = 0; i < 4; i++) rb[wave * 256 + i * 64 + lane] = acc[i];
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        f16 hv = (f16)0.0f;
+        if (ethread) {
+            float sum = rb[tid];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[w2 * 256 + tid];   // wave order: deterministic
+            hv = f2h(sum * h2f(pre.swn));
+        }
+        if (EPI == SEPI_PLAIN) {
+            if (ethread) a.out[(size_t)m * a.N + tile * 16 + c] = hv;
+            return;
+        }
+        f16* e = ex + par * 256;
+        if (tid < 256) e[m * 16 + c] = hv;
+        __syncthreads();
+        if (!ethread) return;
+        const f16 partner = e[(m * 16 + c) ^ 8];
+        if (EPI == SEPI_GATEUP) {
+            if (c < 8) {
+                const float gt = h2f(partner);
+                const float act = h2f(f2h(gt / (1.0f + qexpf(-gt))));
+                a.out[(size_t)m * a.I + tile * 8 + c] = f2h(act * h2f(hv));
+            }
+            return;
+        }
+        const int head = tile >> 3, o = (tile & 7) * 8 + (c & 7);
+        const int n = head * 128 + (c >> 3) * 64 + o;
+        f16 res = hv;
+        if (head < a.nq + a.nkv) {
+            const float cff = h2f(pre.cf), sff = h2f(pre.sf);
+            const float xf = h2f(c < 8 ? hv : partner), yf = h2f(c < 8 ? partner : hv);
+            res = c < 8 ? f2h(h2f(f2h(xf * cff)) - h2f(f2h(yf * sff))) : f2h(h2f(f2h(yf * cff)) + h2f(f2h(xf * sff)));
+        }
+        a.out[(size_t)m * a.N + n] = res;
+        if (head >= a.nq && slot_m >= 0) {
+            const bool is_k = head < a.nq + a.nkv;
+            const int kvh = is_k ? head - a.nq : head - a.nq - a.nkv;
+            f16* cache = is_k ? a.key_cache : a.value_cache;
+            cache[(slot_m * a.nkv + kvh) * 128 + (c >> 3) * 64 + o] = res;
+        }
+    };
+    for (int q = 0; q < my_tiles - 1; q++) {
+        const int nt = tile + gridDim.x;
+        const uint8_t* wp = wptr(nt);
+        Pre npre;
+        load_pre(npre, nt);
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            use(w[u], u);
+            __builtin_amdgcn_sched_barrier(0);
+            w[u] = *reinterpret_cast<const u32x4*>(wp + step_off<NW, UB>(wave, u));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        finish(tile, par, pre);
+        par ^= 1;
+        pre = npre;
+        tile = nt;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; u++) use(w[u], u);
+    finish(tile, par, pre);
+}
+
 // Shape classes: K/2 bytes of a weight row = 64 * NW * UB * NB exactly.
 struct StreamShape {
     int NW, UB, NI;
@@ -658,6 +825,78 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
 }
 
 size_t gemm_w4a4_stream_sync_bytes() { return 32 * sizeof(int) + (size_t)16 * (8192 / 2) + 16 * sizeof(float) + 64; }
+
+template <int EPI, int NW, int UB>
+static int launch_stream16_inst(const StreamArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * NW * 1024 + 1024;
+    const int cap = stream_cap();
+    int grid = a.ntiles;
+    if (grid > cap) {
+        const int per = (a.ntiles + cap - 1) / cap;
+        grid = (a.ntiles + per - 1) / per;
+    }
+    hipLaunchKernelGGL((gemm_w4a16_stream_kernel<EPI, NW, UB>), dim3(grid), dim3(NW * 64), lds, st, a);
+    return 0;
+}
+
+// one batch per tile only (the activation fragments of a wave's K slice live in registers): K = 128 * NW * UB
+static bool stream16_shape(int K, int* NW, int* UB) {
+    // (16, 7) = K 14336 is NOT here: 16 rows x 14336 k of fp16 activations (458 KB) do not fit one CU's registers
+    // (16 waves x 112 VGPRs would leave nothing else); that layer stays on gemm.hip's 2-D kernel
+    static const int cand[][2] = {{8, 4}, {8, 8}, {8, 5}, {4, 4}, {4, 2}, {8, 7}, {4, 7}, {4, 1}};
+    if (K % 128) return false;
+    for (const auto& c : cand)
+        if (K / 128 == c[0] * c[1]) {
+            *NW = c[0];
+            *UB = c[1];
+            return true;
+        }
+    return false;
+}
+
+bool gemm_w4a16_stream_supported(int M, int N, int K) {
+    int NW, UB;
+    return M >= 1 && M <= 16 && N % 16 == 0 && stream16_shape(K, &NW, &UB);
+}
+
+template <int EPI>
+static int launch_stream16(const StreamArgs& a, hipStream_t st) {
+    int NW, UB;
+    if (a.M < 1 || a.M > 16 || !stream16_shape(a.K, &NW, &UB)) return -1;
+#define QS_S16(NWV, UBV) if (NW == NWV && UB == UBV) return launch_stream16_inst<EPI, NWV, UBV>(a, st);
+    QS_S16(8, 4) QS_S16(8, 8) QS_S16(8, 5) QS_S16(4, 4) QS_S16(4, 2) QS_S16(8, 7) QS_S16(4, 7) QS_S16(4, 1)
+#undef QS_S16
+    return -1;
+}
+
+int gemm_w4a16_stream(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, const f16* ws, f16* out, int M, int N,
+                      int K, hipStream_t st) {
+    if (!gemm_w4a16_stream_supported(M, N, K) || (ldx && ldx % 8) || (ldw && ldw % 16)) return -1;
+    StreamArgs a{};
+    a.x = x; a.ldx = ldx; a.ldw = ldw; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = out;
+    a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
+    return launch_stream16<SEPI_PLAIN>(a, st);
+}
+
+int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
+                               const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
+                               const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st) {
+    if (d != 128 || rot_dim != 128 || N != (nq + 2 * nkv) * 128 || !gemm_w4a16_stream_supported(M, N, K)) return -1;
+    StreamArgs a{};
+    a.x = x; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = qkv; a.M = M; a.N = N; a.K = K;
+    a.ntiles = N / 16; a.positions = positions; a.cos_sin_cache = cos_sin_cache; a.key_cache = key_cache;
+    a.value_cache = value_cache; a.slot_mapping = slot_mapping; a.nq = nq; a.nkv = nkv;
+    return launch_stream16<SEPI_QKV>(a, st);
+}
+
+int gemm_w4a16_stream_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K, int ch0,
+                                   int nch, hipStream_t st) {
+    if (I % 8 || ch0 % 8 || nch % 8 || ch0 + nch > I || !gemm_w4a16_stream_supported(M, 2 * I, K)) return -1;
+    StreamArgs a{};
+    a.x = x; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = act; a.M = M; a.N = 2 * I; a.K = K;
+    a.I = I; a.tile0 = ch0 / 8; a.ntiles = nch / 8;
+    return launch_stream16<SEPI_GATEUP>(a, st);
+}
 
 bool gemm_w4a4_stream_supported(int M, int N, int K, bool ln) {
     StreamShape sh;

@@ -68,6 +68,16 @@ int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* 
 int gemm_w4a4_stream_gate_up_silu(const StreamActs& x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K,
                                   hipStream_t st);
 
+// W4A16 on the same streaming skeleton (M <= 16, K = 128 * NW * UB for a built (NW, UB))
+bool gemm_w4a16_stream_supported(int M, int N, int K);
+int gemm_w4a16_stream(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, const f16* ws, f16* out, int M, int N,
+                      int K, hipStream_t st);
+int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
+                               const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
+                               const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st);
+int gemm_w4a16_stream_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K, int ch0,
+                                   int nch, hipStream_t st);
+
 // attention.hip
 int rope_kv_write(const int64_t* positions, f16* qkv, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
                   const int64_t* slot_mapping, int T, int nq, int nkv, int d, int rot_dim, hipStream_t st);

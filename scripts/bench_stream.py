@@ -44,3 +44,23 @@ for M in Ms:
             res["q"] = timeit([(lambda w=w: ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq, xs, w, sc, None, out)) for w in ws])
         print(f"M={M:2d} {name:8s} " + "  ".join(f"{k}: {v:6.2f} us ({gb/v*1e6:5.0f} GB/s)" for k, v in res.items()), flush=True)
         del ws
+# ---- W4A16 (verify pass) at M = 16
+M = 16
+x = torch.randn(M, 14336, device=dev).half()
+cs = torch.randn(8192, 128, device=dev).half(); pos = torch.randint(0, 8192, (M,), device=dev)
+kc = torch.zeros(256, 16, nkv, d, device=dev, dtype=torch.float16); vc = torch.zeros_like(kc)
+slots = torch.arange(M, device=dev, dtype=torch.int64)
+for name, N, K in (("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336)):
+    L = max(2, int(600e6 // (N * K // 2)))
+    ws = [torch.randint(-128, 127, (N, K // 2), dtype=torch.int8, device=dev) for _ in range(L)]
+    sc = torch.rand(N, device=dev).half() * 0.01
+    xx = x[:, :K].contiguous()
+    out = torch.empty(M, N, dtype=torch.float16, device=dev); act = torch.empty(M, I, dtype=torch.float16, device=dev)
+    if name == "qkv":
+        t = timeit([(lambda w=w: ops.qkv_rope_linear(xx, None, w, sc, out, pos, cs, kc, vc, slots, nq, nkv, d)) for w in ws])
+    elif name == "gate_up":
+        t = timeit([(lambda w=w: ops.gate_up_silu_linear(xx, None, w, sc, act)) for w in ws])
+    else:
+        t = timeit([(lambda w=w: ops.w4a16_linear(xx, w, sc, out)) for w in ws])
+    print(f"W4A16 M=16 {name:8s} {t:6.2f} us ({N * K / 2 / 1e9 / t * 1e6:5.0f} GB/s)", flush=True)
+    del ws
