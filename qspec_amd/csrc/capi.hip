@@ -431,6 +431,13 @@ int qspec_ln_gate_up_silu_linear_s4s4(const qspec_half* hidden_in, const qspec_h
     return finish(op, qspec::gemm_w4a4_stream_gate_up_silu(x, wq, CH(ws), H(act), M, intermediate, K, ST));
 }
 size_t qspec_ln_linear_workspace_bytes(void) { return qspec::gemm_w4a4_stream_sync_bytes(); }
+int qspec_prefetch(const void* p, size_t bytes, int workgroups, void* stream) {
+    const char* op = "qspec_prefetch";
+    if (bytes == 0) return 0;
+    NONNULL(op, p);
+    if (((uintptr_t)p) % 16) return fail("%s: pointer must be 16-byte aligned", op);
+    return finish(op, qspec::prefetch_l2(p, bytes, workgroups, ST));
+}
 int qspec_ln_linear_s4s4_supported(int M, int N, int K) { return qspec::gemm_w4a4_stream_supported(M, N, K, true) ? 1 : 0; }
 
 }  // extern "C"

@@ -735,6 +735,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
     finish(tile, par, pre);
 }
 
+// ------------------------------------------------------------------ weight prefetch into the Infinity Cache
+// Reads `bytes` at `p` and throws them away: the lines end up in the 256 MiB memory-side cache (and some in L2).
+// Launched on a side stream while the latency-bound kernels between two GEMMs (attention, Hadamard, ...) leave the
+// HBM idle, so that the next GEMM streams its weights from the cache.  Pure hint: no effect on results.
+__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ p, size_t n16, unsigned* sink) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    u32x4 acc = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += 4 * stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const size_t j = i + u * stride;
+            v[u] = p[j < n16 ? j : i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc ^= v[u];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9E3779B9u && sink) sink[0] = 1;   // keeps the loads alive
+}
+int prefetch_l2(const void* p, size_t bytes, int workgroups, hipStream_t st) {
+    if (bytes < 16 || workgroups < 1) return 0;
+    hipLaunchKernelGGL(prefetch_kernel, dim3(workgroups), dim3(256), 0, st, reinterpret_cast<const u32x4*>(p), bytes / 16,
+                       (unsigned*)nullptr);
+    return 0;
+}
+
 // Shape classes: K/2 bytes of a weight row = 64 * NW * UB * NB exactly.
 struct StreamShape {
     int NW, UB, NI;

@@ -78,6 +78,8 @@ int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f1
 int gemm_w4a16_stream_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K, int ch0,
                                    int nch, hipStream_t st);
 
+int prefetch_l2(const void* p, size_t bytes, int workgroups, hipStream_t st);
+
 // attention.hip
 int rope_kv_write(const int64_t* positions, f16* qkv, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
                   const int64_t* slot_mapping, int T, int nq, int nkv, int d, int rot_dim, hipStream_t st);

@@ -182,6 +182,11 @@ def gate_up_silu_linear(x, x_scale, wq, w_scale, act):
     return act
 
 
+def prefetch(t, workgroups: int = 128):
+    """Cache hint (qspec_prefetch): pull tensor `t` into the Infinity Cache on the current stream."""
+    _call("qspec_prefetch", t.data_ptr(), t.numel() * t.element_size(), workgroups, _stream())
+
+
 def ln_linear_s4s4_supported(M: int, N: int, K: int) -> bool:
     return bool(_lib.load().qspec_ln_linear_s4s4_supported(M, N, K))
 
