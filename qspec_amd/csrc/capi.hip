@@ -170,6 +170,8 @@ int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, 
     if (M == 0 || N == 0) return 0;
     NONNULL(op, x); NONNULL(op, w); NONNULL(op, out);
     if (K % 32 || K <= 0) return fail("%s: need K %% 32 == 0 (K=%d)", op, K);
+    if (use_stream() && qspec::gemm_f16_stream_supported(M, N, K))
+        return finish(op, qspec::gemm_f16_stream(CH(x), CH(w), H(out), M, N, K, ST));
     return finish(op, qspec::gemm_f16(CH(x), CH(w), H(out), M, N, K, ST));
 }
 int qspec_dequant_w4(const int8_t* wq, const qspec_half* ws, qspec_half* out, int N, int K, void* stream) {

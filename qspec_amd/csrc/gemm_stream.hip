@@ -761,6 +761,101 @@ int prefetch_l2(const void* p, size_t bytes, int workgroups, hipStream_t st) {
     return 0;
 }
 
+// ------------------------------------------------------------------ fp16 x fp16^T (lm_head), same skeleton
+// out[m,n] = h( sum_k f(x[m,k]) f(w[n,k]) ), fp32 accumulate  (nn.Linear lm_head, logits_processor.py:92-97).
+// K = 32 * NW * UB: a wave keeps UB loads (UB KiB) of the 1 GB vocabulary matrix in flight and its activation
+// fragments in registers; a workgroup walks over its tiles with the refill-behind-use pipeline of the kernels above.
+template <int NW, int UB>
+__global__ __launch_bounds__(NW * 64) void gemm_f16_stream_kernel(const f16* __restrict__ x, const f16* __restrict__ wt,
+                                                                  f16* __restrict__ out, int M, int N, int K,
+                                                                  int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = reinterpret_cast<float*>(smem);   // [2][NW][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int el = tid & 63, reg = (tid >> 6) & 3;
+    const int c = el & 15, m = 4 * (el >> 4) + reg;
+    const bool ethread = tid < 256 && m < M;
+    // step u of this wave = bytes [step_off(wave, u) + 16 g, +16) of a weight row = k (halves) offset / 2
+    f16x8 af[UB];
+    {
+        const f16* xrow = x + (size_t)(r < M ? r : 0) * K + g * 8;
+#pragma unroll
+        for (int u = 0; u < UB; u++) af[u] = *reinterpret_cast<const f16x8*>(xrow + step_off<NW, UB>(wave, u) / 2);
+    }
+    int tile = blockIdx.x, par = 0;
+    const int my_tiles = (ntiles - tile + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto wptr = [&](int t) -> const unsigned char* {
+        return reinterpret_cast<const unsigned char*>(wt + (size_t)(t * 16 + r) * K) + g * 16;
+    };
+    f16x8 w[UB];
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const unsigned char* wp0 = wptr(tile);
+#pragma unroll
+        for (int u = 0; u < UB; u++) w[u] = *reinterpret_cast<const f16x8*>(wp0 + step_off<NW, UB>(wave, u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto finish = [&](int t, int par) {
+        float* rb = red + par * NW * 256;
+#pragma unroll
+        for (int i = 0; i < 4; i++) rb[wave * 256 + i * 64 + lane] = acc[i];
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        if (ethread) {
+            float sum = rb[tid];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[w2 * 256 + tid];
+            out[(size_t)m * N + t * 16 + c] = f2h(sum);
+        }
+    };
+    for (int q = 0; q < my_tiles - 1; q++) {
+        const int nt = tile + gridDim.x;
+        const unsigned char* wp = wptr(nt);
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u], w[u], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            w[u] = *reinterpret_cast<const f16x8*>(wp + step_off<NW, UB>(wave, u));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        finish(tile, par);
+        par ^= 1;
+        tile = nt;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; u++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u], w[u], acc, 0, 0, 0);
+    finish(tile, par);
+}
+
+bool gemm_f16_stream_supported(int M, int N, int K) {
+    return M >= 1 && M <= 16 && N % 16 == 0 && (K == 1024 || K == 2048 || K == 4096 || K == 5120);
+}
+int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st) {
+    if (!gemm_f16_stream_supported(M, N, K)) return -1;
+    const int ntiles = N / 16;
+    static int cap = 0;
+    if (cap == 0) {
+        const char* e = getenv("QSPEC_HEAD_CAP");
+        cap = e ? atoi(e) : 256;   // one workgroup per CU: 6.3 TB/s measured (512: 6.1, 1024: 5.9)
+        if (cap < 1) cap = 256;
+    }
+    int grid = ntiles;
+    if (grid > cap) {
+        const int per = (ntiles + cap - 1) / cap;
+        grid = (ntiles + per - 1) / per;
+    }
+#define QS_F16S(NWV, UBV) hipLaunchKernelGGL((gemm_f16_stream_kernel<NWV, UBV>), dim3(grid), dim3(NWV * 64), (size_t)2 * NWV * 1024, st, x, w, out, M, N, K, ntiles)
+    if (K == 4096) QS_F16S(8, 16);
+    else if (K == 2048) QS_F16S(8, 8);
+    else if (K == 1024) QS_F16S(4, 8);
+    else QS_F16S(8, 20);
+#undef QS_F16S
+    return 0;
+}
+
 // Shape classes: K/2 bytes of a weight row = 64 * NW * UB * NB exactly.
 struct StreamShape {
     int NW, UB, NI;
