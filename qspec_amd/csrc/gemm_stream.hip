@@ -308,9 +308,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
     const int NB = Kb / (64 * NW * UB);                              // batches per tile (exact: checked on the host)
 
     // epilogue thread (tid < 256) owns accumulator element (token m, tile column c)
-    const int el = tid & 63, reg = (tid >> 6) & 3;
-    const int c = el & 15, m = 4 * (el >> 4) + reg;
-    const bool ethread = tid < 256 && m < a.M;
+    // epilogue thread t owns output (token m = t / 16, tile column c = t % 16): for M <= 4 that is wave 0 alone, the
+    // other waves go straight back to streaming.  ridx = where the MFMA left that element in a wave's accumulators.
+    const int c = tid & 15, m = tid >> 4;
+    const bool ethread = m < a.M;
+    const int ridx = (m & 3) * 64 + ((m >> 2) & 3) * 16 + c;
     const int mc = m < a.M ? m : 0;
 
     // No load in this kernel sits behind a branch: hipcc resolves control flow around vector-memory operations
@@ -335,14 +337,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
     auto wptr = [&](int tile, int b) -> const uint8_t* {
         return a.wq + (size_t)stile_row<EPI>(tile, r, a.I) * Kb + (size_t)(b * UB * NW) * 64 + g * 16;
     };
+    // A wave owns the same K steps of every tile (one batch per tile: NB == 1, checked on the host), so its
+    // activation fragments are widened ONCE and stay in registers: no per-step LDS read, and with (xq, xs) given
+    // (PRO_Q) no LDS staging and no barrier in front of the first MFMA at all.
     const unsigned char* arow = xq_lds + (size_t)(r & (MP - 1)) * RS + g * 16;
+    i32x4 af0[UB], af1[UB];
+    float xs_m = 0.0f;   // activation scale of this epilogue thread's token
     i32x4 acc = {0, 0, 0, 0};
     auto use = [&](const u32x4& w, int b, int u) {
-        const u32x4 av = *reinterpret_cast<const u32x4*>(arow + (size_t)b * (UB * NW * 64) + step_off<NW, UB>(wave, u));
         const i32x4 b0 = widen16(w[0], w[1]), b1 = widen16(w[2], w[3]);
-        const i32x4 a0 = widen16(av[0], av[1]), a1 = widen16(av[2], av[3]);
-        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af0[u], b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1[u], b1, acc, 0, 0, 0);
     };
     auto finish = [&](int tile, int par, const Pre& pre) {
         int* rb = red + par * NW * 256;
@@ -354,8 +359,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
         if (ethread) {
             int sum = 0;
 #pragma unroll
-            for (int w2 = 0; w2 < NW; w2++) sum += rb[w2 * 256 + tid];
-            const float v = ((float)(sum >> 8) * xs_lds[m]) * h2f(pre.swn);  // both operands carried a factor 16
+            for (int w2 = 0; w2 < NW; w2++) sum += rb[w2 * 256 + ridx];
+            const float v = ((float)(sum >> 8) * xs_m) * h2f(pre.swn);  // both operands carried a factor 16
             hv = f2h(v);
         }
         if (EPI == SEPI_PLAIN) {
@@ -363,10 +368,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
             return;
         }
         f16* e = ex + par * 256;
-        if (tid < 256) e[m * 16 + c] = hv;
+        if (tid < 256) e[tid] = hv;
         __syncthreads();
         if (!ethread) return;
-        const f16 partner = e[(m * 16 + c) ^ 8];
+        const f16 partner = e[tid ^ 8];
         if (EPI == SEPI_GATEUP) {
             if (c < 8) {  // hv = up, partner = gate
                 const float gt = h2f(partner);
@@ -497,33 +502,31 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
             ln_compute<NI, NG, RB>(a, base, rg, xq_lds, RS, xs_lds, lnred, wh);
         }
     } else {
-        const int chunks_per_row = Kb >> 4;
-        const int total = a.M * chunks_per_row;
-        constexpr int XA = 4;
-        u32x4 xa[XA];
-        int xoff[XA];
+        u32x4 araw[UB];
+        const unsigned char* xrow = reinterpret_cast<const unsigned char*>(a.xq) + (size_t)(r < a.M ? r : 0) * Kb + g * 16;
 #pragma unroll
-        for (int q2 = 0; q2 < XA; q2++) {
-            const int i = min(tid + q2 * NW * 64, total - 1);
-            const int row = i / chunks_per_row, q = i - row * chunks_per_row;
-            xoff[q2] = row * RS + q * 16;
-            xa[q2] = *reinterpret_cast<const u32x4*>(a.xq + (size_t)row * Kb + q * 16);
-        }
-        const float xsv = h2f(a.xs[tid < a.M ? tid : 0]);
+        for (int u = 0; u < UB; u++) araw[u] = *reinterpret_cast<const u32x4*>(xrow + step_off<NW, UB>(wave, u));
+        const f16 xsh = a.xs[mc];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < UB; u++) w[u] = *reinterpret_cast<const u32x4*>(wp0 + step_off<NW, UB>(wave, u));
         load_pre(pre, tile);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q2 = 0; q2 < XA; q2++) *reinterpret_cast<u32x4*>(xq_lds + xoff[q2]) = xa[q2];  // duplicates rewrite the same bytes
-        for (int i = tid + XA * NW * 64; i < total; i += NW * 64) {  // M * K beyond XA chunks per thread (M > 4)
-            const int row = i / chunks_per_row, q = i - row * chunks_per_row;
-            *reinterpret_cast<u32x4*>(xq_lds + (size_t)row * RS + q * 16) =
-                *reinterpret_cast<const u32x4*>(a.xq + (size_t)row * Kb + q * 16);
+        for (int u = 0; u < UB; u++) {
+            af0[u] = widen16(araw[u][0], araw[u][1]);
+            af1[u] = widen16(araw[u][2], araw[u][3]);
         }
-        if (tid < a.M) xs_lds[tid] = xsv;
-        __syncthreads();
+        xs_m = h2f(xsh);
+    }
+    if (PRO != PRO_Q) {   // the norm left the packed rows in LDS: take this wave's fragments out once
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const u32x4 av = *reinterpret_cast<const u32x4*>(arow + step_off<NW, UB>(wave, u));
+            af0[u] = widen16(av[0], av[1]);
+            af1[u] = widen16(av[2], av[3]);
+        }
+        xs_m = xs_lds[mc];
     }
 
     // ---- main loop: one unit = UB steps of every wave.  Each step's register is refilled with the same step of
@@ -608,9 +611,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
     const size_t ldw = a.ldw ? (size_t)a.ldw : (size_t)Kb, ldx = a.ldx ? (size_t)a.ldx : (size_t)a.K;
     float* red = reinterpret_cast<float*>(smem);                     // [2][NW][256]
     f16* ex = reinterpret_cast<f16*>(red + 2 * NW * 256);            // [2][256]
-    const int el = tid & 63, reg = (tid >> 6) & 3;
-    const int c = el & 15, m = 4 * (el >> 4) + reg;
-    const bool ethread = tid < 256 && m < a.M;
+    // epilogue thread t owns output (token m = t / 16, tile column c = t % 16): for M <= 4 that is wave 0 alone, the
+    // other waves go straight back to streaming.  ridx = where the MFMA left that element in a wave's accumulators.
+    const int c = tid & 15, m = tid >> 4;
+    const bool ethread = m < a.M;
+    const int ridx = (m & 3) * 64 + ((m >> 2) & 3) * 16 + c;
     const int mc = m < a.M ? m : 0;
     int64_t pos_m = 0, slot_m = -1;
     if (EPI == SEPI_QKV) {
@@ -675,9 +680,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
         __syncthreads();
         f16 hv = (f16)0.0f;
         if (ethread) {
-            float sum = rb[tid];
+            float sum = rb[ridx];
 #pragma unroll
-            for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[w2 * 256 + tid];   // wave order: deterministic
+            for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[w2 * 256 + ridx];   // wave order: deterministic
             hv = f2h(sum * h2f(pre.swn));
         }
         if (EPI == SEPI_PLAIN) {
@@ -685,10 +690,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
             return;
         }
         f16* e = ex + par * 256;
-        if (tid < 256) e[m * 16 + c] = hv;
+        if (tid < 256) e[tid] = hv;
         __syncthreads();
         if (!ethread) return;
-        const f16 partner = e[(m * 16 + c) ^ 8];
+        const f16 partner = e[tid ^ 8];
         if (EPI == SEPI_GATEUP) {
             if (c < 8) {
                 const float gt = h2f(partner);
@@ -774,9 +779,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_f16_stream_kernel(const f16* __r
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int el = tid & 63, reg = (tid >> 6) & 3;
-    const int c = el & 15, m = 4 * (el >> 4) + reg;
-    const bool ethread = tid < 256 && m < M;
+    const int c = tid & 15, m = tid >> 4;   // epilogue thread -> (token, tile column), as in the kernels above
+    const bool ethread = m < M;
+    const int ridx = (m & 3) * 64 + ((m >> 2) & 3) * 16 + c;
     // step u of this wave = bytes [step_off(wave, u) + 16 g, +16) of a weight row = k (halves) offset / 2
     f16x8 af[UB];
     {
@@ -805,9 +810,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_f16_stream_kernel(const f16* __r
         acc = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
         if (ethread) {
-            float sum = rb[tid];
+            float sum = rb[ridx];
 #pragma unroll
-            for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[w2 * 256 + tid];
+            for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[w2 * 256 + ridx];
             out[(size_t)m * N + t * 16 + c] = f2h(sum);
         }
     };
@@ -864,16 +869,13 @@ static bool stream_shape(int K, StreamShape* sh) {
     const int nsteps = K / 128;
     if (K % 128) return false;
     static const StreamShape cand[] = {{8, 4, 0}, {16, 7, 0}, {8, 8, 0}, {8, 5, 0}, {4, 4, 0}, {4, 2, 0}};
-    // preferred order: one batch per tile first
-    for (int pass = 0; pass < 2; pass++)
-        for (const StreamShape& c : cand) {
-            const int per = c.NW * c.UB;
-            if (nsteps % per) continue;
-            if (pass == 0 && nsteps != per) continue;
-            *sh = c;
-            sh->NI = (K % 1024 == 0 && K / 1024 <= 8) ? K / 1024 : 0;
-            return true;
-        }
+    // one batch per tile (the activation fragments of a wave's K slice live in registers)
+    for (const StreamShape& c : cand) {
+        if (nsteps != c.NW * c.UB) continue;
+        *sh = c;
+        sh->NI = (K % 1024 == 0 && K / 1024 <= 8) ? K / 1024 : 0;
+        return true;
+    }
     return false;
 }
 
