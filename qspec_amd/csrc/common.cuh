@@ -66,9 +66,30 @@ __device__ __forceinline__ int rni_sat(float v, int lo, int hi) {
 __device__ __forceinline__ float shfl_xor_f(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask, 64); }
 
+// lane ^ M for M in {1, 2, 4, 8} as DPP moves (no LDS round trip, ~8 cycles instead of a ~100-cycle ds_bpermute):
+// quad_perm for 1 and 2, row_ror:8 for 8, and for 4 a row_shl:4 into the even 4-lane banks + row_shr:4 into the odd.
+template <int M>
+__device__ __forceinline__ float dpp_xor(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    int r;
+    if (M == 1) r = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, false);        // quad_perm:[1,0,3,2]
+    else if (M == 2) r = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, false);   // quad_perm:[2,3,0,1]
+    else if (M == 8) r = __builtin_amdgcn_update_dpp(0, xi, 0x128, 0xF, 0xF, false);  // row_ror:8
+    else {
+        r = __builtin_amdgcn_update_dpp(0, xi, 0x104, 0xF, 0x5, false);               // row_shl:4 -> banks 0,2
+        r = __builtin_amdgcn_update_dpp(r, xi, 0x114, 0xF, 0xA, false);               // row_shr:4 -> banks 1,3
+    }
+    return __builtin_bit_cast(float, r);
+}
+
+// max over the 64 lanes of a wave (order independent): xor 1, 2, 4, 8 as DPP moves, 16 and 32 through ds_bpermute
 __device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, shfl_xor_f(v, m));
+    v = fmaxf(v, dpp_xor<1>(v));
+    v = fmaxf(v, dpp_xor<2>(v));
+    v = fmaxf(v, dpp_xor<4>(v));
+    v = fmaxf(v, dpp_xor<8>(v));
+    v = fmaxf(v, shfl_xor_f(v, 16));
+    v = fmaxf(v, shfl_xor_f(v, 32));
     return v;
 }
 

@@ -74,22 +74,6 @@ __device__ __forceinline__ int stile_row(int tb, int r, int I) {
     return tb * 16 + r;
 }
 
-// lane ^ M for M in {1, 2, 4, 8} as DPP moves (no LDS round trip, ~8 cycles instead of a ~100-cycle ds_bpermute):
-// quad_perm for 1 and 2, row_ror:8 for 8, and for 4 a row_shl:4 into the even 4-lane banks + row_shr:4 into the odd.
-template <int M>
-__device__ __forceinline__ float dpp_xor(float x) {
-    const int xi = __builtin_bit_cast(int, x);
-    int r;
-    if (M == 1) r = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, false);        // quad_perm:[1,0,3,2]
-    else if (M == 2) r = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, false);   // quad_perm:[2,3,0,1]
-    else if (M == 8) r = __builtin_amdgcn_update_dpp(0, xi, 0x128, 0xF, 0xF, false);  // row_ror:8
-    else {
-        r = __builtin_amdgcn_update_dpp(0, xi, 0x104, 0xF, 0x5, false);               // row_shl:4 -> banks 0,2
-        r = __builtin_amdgcn_update_dpp(r, xi, 0x114, 0xF, 0xA, false);               // row_shr:4 -> banks 1,3
-    }
-    return __builtin_bit_cast(float, r);
-}
-
 // Reference summation tree over 1024 virtual-thread partials held 4 per lane (norm_quant.hip:ref_tree_sum_1024),
 // for RB rows at once.  j = index inside the 256-thread group; red = [RB][32] floats of this group, written once.
 // Same pairings, same order as the reference's two xor butterflies (so the same bits); the second butterfly is
@@ -125,16 +109,6 @@ __device__ __forceinline__ void tree_sum_rows(float (&p)[RB][4], float* red, int
             for (int k = 0; k < m; k++) v[k] = v[k] + v[k + m];
         out[i] = v[0];
     }
-}
-
-__device__ __forceinline__ float wave_max_dpp(float v) {
-    v = fmaxf(v, dpp_xor<1>(v));
-    v = fmaxf(v, dpp_xor<2>(v));
-    v = fmaxf(v, dpp_xor<4>(v));
-    v = fmaxf(v, dpp_xor<8>(v));
-    v = fmaxf(v, shfl_xor_f(v, 16));
-    v = fmaxf(v, shfl_xor_f(v, 32));
-    return v;
 }
 
 // Residual add + LN-no-gamma + int4 quant of all M rows into LDS (xq_lds [MP][RS] bytes, xs_lds [16] floats).
@@ -247,7 +221,7 @@ __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs
                 am2[1] = a2[1] > am2[1] ? a2[1] : am2[1];
             }
         float am = fmaxf(h2f(am2[0]), h2f(am2[1]));
-        am = wave_max_dpp(am);
+        am = wave_max_f(am);
         if ((j & 63) == 0) red_max[i * 32 + (j >> 6)] = am;
     }
     __syncthreads();

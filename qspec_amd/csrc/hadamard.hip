@@ -553,15 +553,22 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
                     v[i + stride] = a - b;
                 }
         }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const bool hi = lane & m;
-#pragma unroll
-            for (int i = 0; i < EPL; i++) {
-                float o = shfl_xor_f(v[i], m);
-                v[i] = hi ? (o - v[i]) : (v[i] + o);
-            }
+        // lane-exchange stages: xor 1, 2, 4, 8 as DPP moves (no LDS round trip), 16 and 32 through ds_bpermute
+#define QS_FWHT_STAGE(M, EXCH)                                  \
+        {                                                       \
+            const bool hi = lane & M;                           \
+            _Pragma("unroll") for (int i = 0; i < EPL; i++) {   \
+                const float o = EXCH;                           \
+                v[i] = hi ? (o - v[i]) : (v[i] + o);            \
+            }                                                   \
         }
+        QS_FWHT_STAGE(1, dpp_xor<1>(v[i]))
+        QS_FWHT_STAGE(2, dpp_xor<2>(v[i]))
+        QS_FWHT_STAGE(4, dpp_xor<4>(v[i]))
+        QS_FWHT_STAGE(8, dpp_xor<8>(v[i]))
+        QS_FWHT_STAGE(16, shfl_xor_f(v[i], 16))
+        QS_FWHT_STAGE(32, shfl_xor_f(v[i], 32))
+#undef QS_FWHT_STAGE
         if (EPL >= 8) {  // one 16-byte LDS store per 8 values (2-byte stores at a 16-byte lane stride are 8-way conflicted)
 #pragma unroll
             for (int b = 0; b < EPL / 8; b++) {
