@@ -281,8 +281,11 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
         float mx = s8[0];
 #pragma unroll
         for (int i = 1; i < 8; i++) mx = fmaxf(mx, s8[i]);
-#pragma unroll
-        for (int m = 8; m > 0; m >>= 1) mx = fmaxf(mx, shfl_xor_f(mx, m));
+        // the 16 lanes of a row exchange through DPP (max: order independent)
+        mx = fmaxf(mx, dpp_xor<8>(mx));
+        mx = fmaxf(mx, dpp_xor<4>(mx));
+        mx = fmaxf(mx, dpp_xor<2>(mx));
+        mx = fmaxf(mx, dpp_xor<1>(mx));
         float sum = 0.0f;
         f16x8 p8, p8lo;
 #pragma unroll
@@ -295,8 +298,10 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
             p8lo[i] = f2h(pv - h2f(ph));
             sum += pv;
         }
-#pragma unroll
-        for (int m = 8; m > 0; m >>= 1) sum += shfl_xor_f(sum, m);
+        sum += dpp_xor<8>(sum);   // same pairing order as the xor butterfly it replaces (8, 4, 2, 1)
+        sum += dpp_xor<4>(sum);
+        sum += dpp_xor<2>(sum);
+        sum += dpp_xor<1>(sum);
         *reinterpret_cast<f16x8*>(pl + r * QS_ATT_CHUNK + ks * 8) = p8;
         *reinterpret_cast<f16x8*>(pl2 + r * QS_ATT_CHUNK + ks * 8) = p8lo;
         if (ks == 0) {
