@@ -66,32 +66,53 @@ def barrier(world):
 
 
 def measure_dominant_kernel(model, engine, reps=5):
-    """The dominant kernel = the W4A4 weight-streaming GEMM (qspec::gemm_w4a4_kernel, all decoder shapes at
-    M = batch; 3 of the 4 forwards of a cycle).  Every decoder GEMM of one draft forward is enqueued in model order on
-    the real weights into one hipGraph (so launches are back to back as in the timed region, and each weight byte is
+    """The dominant kernel = the weight-streaming W4A4 GEMM of the draft pass (qspec::gemm_w4a4_stream_kernel: the
+    four decoder GEMM launches of a draft forward at M = batch, 3 of the 4 forwards of a cycle), in exactly the
+    forms the cycle launches: residual add + LN + int4 quant prologue -> qkv (+ RoPE + KV write) / gate_up (+ silu*up),
+    and the plain (xq, xs) form for o_proj / down_proj.  Every decoder GEMM of one draft forward is enqueued in model
+    order on the real weights into one hipGraph (launches back to back as in the timed region; each weight byte is
     cold again by the time it is re-read: 3.5 GB > the 256 MiB infinity cache), bracketed by HIP events recorded on
     the launching stream.  Returns algorithmic bytes and seconds per launch, overall and per shape."""
     from qspec_amd import ops
     B = engine.B
     s, md, cfg = engine.scratch_draft, engine.md_draft, model.config
     xq, sc = s.quantized_buffer_qkv[:B], s.scale_buffer[:B]
+    hid, hid2, o = s.hidden[:B], s.hidden2[:B], s.act_buffer_output[:B]
+    eps = cfg.rms_norm_eps
     kinds = ("qkv", "o", "gate_up", "down")
+    ln_fused = ops.ln_linear_s4s4_supported(B, cfg.q_size + 2 * cfg.kv_size, cfg.hidden_size)
 
     def launch(layer, kc, vc, kind):
         if kind == "qkv":
-            ops.qkv_rope_linear(xq, sc, layer.qkv_proj.weight, layer.qkv_proj._scales(), s.act_buffer_qkv[:B],
-                                engine.d_pos, model.cos_sin_cache, kc, vc, md.slot_mapping, cfg.num_attention_heads,
-                                cfg.num_key_value_heads, cfg.head_dim)
+            if ln_fused:
+                ops.ln_qkv_rope_linear(hid, o, hid2, eps, layer.qkv_proj.weight, layer.qkv_proj._scales(),
+                                       s.act_buffer_qkv[:B], engine.d_pos, model.cos_sin_cache, kc, vc, md.slot_mapping,
+                                       cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim)
+            else:
+                ops.qkv_rope_linear(xq, sc, layer.qkv_proj.weight, layer.qkv_proj._scales(), s.act_buffer_qkv[:B],
+                                    engine.d_pos, model.cos_sin_cache, kc, vc, md.slot_mapping, cfg.num_attention_heads,
+                                    cfg.num_key_value_heads, cfg.head_dim)
         elif kind == "o":
-            ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq, sc, layer.o_proj.weight, layer.o_proj._scales(), None, s.act_buffer_output[:B])
+            ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq, sc, layer.o_proj.weight, layer.o_proj._scales(), None, o)
         elif kind == "gate_up":
-            ops.gate_up_silu_linear(xq, sc, layer.gate_up.weight, layer.gate_up._scales(), s.act_buffer_had_mlp[:B])
+            if ln_fused:
+                ops.ln_gate_up_silu_linear(hid2, o, hid, eps, layer.gate_up.weight, layer.gate_up._scales(),
+                                           s.act_buffer_had_mlp[:B])
+            else:
+                ops.gate_up_silu_linear(xq, sc, layer.gate_up.weight, layer.gate_up._scales(), s.act_buffer_had_mlp[:B])
         else:
-            ops.rowwise_scaled_linear_cutlass_s4s4_unified(s.quantized_buffer_mlp[:B], sc, layer.down_proj.weight, layer.down_proj._scales(), None, s.act_buffer_output[:B])
+            ops.rowwise_scaled_linear_cutlass_s4s4_unified(s.quantized_buffer_mlp[:B], sc, layer.down_proj.weight, layer.down_proj._scales(), None, o)
 
-    def nbytes(lin, out_cols):
+    def nbytes(kd, lin):
         n, kb = lin.weight.shape
-        return n * kb + 2 * n + B * kb + 2 * B + 2 * B * out_cols   # packed weights + scales + activations in/out
+        out_cols = n // 2 if kd == "gate_up" else n
+        w = n * kb + 2 * n                                     # packed weights + channel scales
+        if ln_fused and kd in ("qkv", "gate_up"):
+            act_in = 2 * B * (2 * kb) * 2                      # residual stream + previous projection, fp16
+            act_out = B * (2 * kb) * 2                         # updated residual stream (written once)
+        else:
+            act_in, act_out = B * kb + 2 * B, 0                # packed int4 activations + scales
+        return w + act_in + act_out + 2 * B * out_cols
 
     res, tot_b, tot_t, launches = {}, 0.0, 0.0, 0
     for kind in kinds + ("all",):
@@ -120,13 +141,31 @@ def measure_dominant_kernel(model, engine, reps=5):
         for layer in model.layers:
             for kd in sel:
                 lin = {"qkv": layer.qkv_proj, "o": layer.o_proj, "gate_up": layer.gate_up, "down": layer.down_proj}[kd]
-                by += nbytes(lin, lin.weight.shape[0] // 2 if kd == "gate_up" else lin.weight.shape[0])
+                by += nbytes(kd, lin)
         by *= reps
         if kind == "all":
             tot_b, tot_t, launches = by, t, n
         else:
             res[kind] = {"GB/s": round(by / t / 1e9, 1), "us": round(t / n * 1e6, 2)}
     return tot_b, tot_t, launches, res
+
+
+def pmc_traffic_per_launch():
+    """HBM read bytes per launch of the dominant kernel from the PMC pass committed under profiles/ (a separate
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` run of scripts/profile_cycle.py, same workload; FETCH_SIZE KiB x 1024
+    x 2 = the gfx950 correction for wide streaming reads, MI355X_MICROARCH.md).  Average over the kernel's launches
+    in a cycle (the four decoder shapes in equal numbers).  None if the summary is not there."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")
+    try:
+        d = json.load(open(path))
+    except OSError:
+        return None
+    tot = n = 0
+    for name, v in d.items():
+        if "gemm_w4a4_stream_kernel" in name:
+            tot += v["hbm_read_bytes_per_launch_corrected"] * v["launches"]
+            n += v["launches"]
+    return int(tot / n) if n else None
 
 
 def cpu_baseline(model, args):
@@ -241,9 +280,9 @@ def main():
         tot_b, tot_t, n, per_shape = measure_dominant_kernel(model, eng)
         achieved = tot_b / tot_t / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(achieved / 8000.0, 4), "traffic": None,
-                           "kernel": "qspec::gemm_w4a4_kernel<1,*> (the four decoder GEMMs of a draft forward, M = batch, "
-                                     "incl. the fused rope/kv-write and silu epilogues)",
+                           "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic_per_launch(),
+                           "kernel": "qspec::gemm_w4a4_stream_kernel (the four decoder GEMM launches of a draft forward, M = batch: "
+                                     "LN+int4-quant prologue -> qkv+RoPE+KV-write / gate_up+silu*up; o_proj; down_proj)",
                            "launches": n, "avg_launch_us": round(tot_t / n * 1e6, 2),
                            "bytes_per_launch_avg": int(tot_b / n), "per_shape": per_shape}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
