@@ -382,6 +382,38 @@ def test_ln_prologue_gemms_equal_ln_then_gemm(ops, oracle, M, K, with_delta, han
     assert torch.equal(act.view(torch.int16), act_ref.view(torch.int16))
 
 
+@pytest.mark.parametrize("M", [4, 3, 16])
+def test_ln_prologue_full_layer_shapes_with_lds_prefetch(ops, oracle, M, monkeypatch):
+    """Llama-3-8B layer shapes: several tiles per workgroup, so the tiles behind the first one are brought into LDS
+    by LDS-DMA underneath the norm (gemm_stream.hip).  Against the separate LN kernel + the plain GEMM entries."""
+    monkeypatch.setattr(ops, "LN_HANDOFF", False)
+    rng = np.random.default_rng(M)
+    K, nq, nkv, d, bs, I = 4096, 32, 8, 128, 16, 14336
+    N = (nq + 2 * nkv) * d
+    hidden = dev(rand_hidden(rng, M, K)); delta = dev(rand_hidden(rng, M, K, 0.3))
+    wq = dev(rng.integers(-128, 128, (N, K // 2)).astype(np.int8)); ws = dev((rng.random(N) * 0.01 + 0.001).astype(np.float16))
+    wg = dev(rng.integers(-128, 128, (2 * I, K // 2)).astype(np.int8)); wgs = dev((rng.random(2 * I) * 0.01 + 0.001).astype(np.float16))
+    cs = dev(oracle.make_cos_sin_cache(d, 2048, 500000.0))
+    pos = dev(rng.integers(0, 2048, M).astype(np.int64))
+    slots = dev(rng.permutation(64 * bs)[:M].astype(np.int64))
+    q = torch.empty(M, K // 2, dtype=torch.int8, device=DEV); sc = torch.empty(M, dtype=torch.float16, device=DEV)
+    h_ref = torch.empty_like(hidden)
+    ops.add_rms_norm_i4(q, sc, h_ref, hidden, delta, 1e-5)
+    qkv_ref = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    kc0 = torch.zeros(64, bs, nkv, d, dtype=torch.float16, device=DEV); vc0 = torch.zeros_like(kc0)
+    ops.qkv_rope_linear(q, sc, wq, ws, qkv_ref, pos, cs, kc0, vc0, slots, nq, nkv, d)
+    act_ref = ops.gate_up_silu_linear(q, sc, wg, wgs, torch.empty(M, I, dtype=torch.float16, device=DEV))
+    h1 = torch.empty_like(hidden); qkv = torch.empty_like(qkv_ref)
+    kc1 = torch.zeros_like(kc0); vc1 = torch.zeros_like(kc0)
+    ops.ln_qkv_rope_linear(hidden, delta, h1, 1e-5, wq, ws, qkv, pos, cs, kc1, vc1, slots, nq, nkv, d)
+    act = ops.ln_gate_up_silu_linear(hidden, delta, h1, 1e-5, wg, wgs, torch.empty(M, I, dtype=torch.float16, device=DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(h1.view(torch.int16), h_ref.view(torch.int16))
+    assert torch.equal(qkv.view(torch.int16), qkv_ref.view(torch.int16))
+    assert torch.equal(kc1, kc0) and torch.equal(vc1, vc0)
+    assert torch.equal(act.view(torch.int16), act_ref.view(torch.int16))
+
+
 def test_ln_handoff_stress_back_to_back(ops, oracle, monkeypatch):
     """The fence-free producer -> consumer hand-off of the LN-prologue GEMMs under back-to-back launches with
     different inputs each time (a stale flag or a stale row would reuse the previous launch's activations), at the
