@@ -142,7 +142,12 @@ int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const
  *   h = fp16(hidden_in + delta) (delta NULL: h = hidden_in);  hidden_out = h;  (xq, xs) = ln_i4(h);  then the fused
  *   GEMM of qspec_qkv_rope_linear_s4s4 / qspec_gate_up_silu_linear_s4s4.
  * hidden_out must not alias hidden_in (every workgroup re-reads hidden_in; workgroup 0 writes hidden_out).
- * Bit-identical to qspec_add_rms_norm_i4 followed by the GEMM entry.  K = hidden size in {2048, 4096, 5120, 8192}. */
+ * Bit-identical to qspec_add_rms_norm_i4 followed by the GEMM entry.  K = hidden size in {1024, 2048, 4096, 5120, 8192}. 
+ * sync_workspace: NULL -> every workgroup recomputes the norm; else qspec_ln_linear_workspace_bytes() bytes,
+ * ZERO-FILLED once before first use (every call leaves it zeroed): a few producer workgroups compute the norm and
+ * hand the packed rows to the others through L2 (write-through stores + flags, no fences) while all of them already
+ * stream weights (faster from 8 tokens).  One workspace serves all calls of a stream; not for concurrent streams. */
+size_t qspec_ln_linear_workspace_bytes(void);
 int qspec_ln_qkv_rope_linear_s4s4(const qspec_half* hidden_in, const qspec_half* delta, qspec_half* hidden_out,
                                   float eps, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M, int N,
                                   int K, const int64_t* positions, const qspec_half* cos_sin_cache,
