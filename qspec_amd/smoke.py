@@ -24,4 +24,19 @@ def run():
     torch.cuda.synchronize()
     assert np.array_equal(q.cpu().numpy(), q0), "LN+int4 quant mismatch"
     assert np.array_equal(out.cpu().numpy().view(np.uint16), ref.view(np.uint16)), "W4A4 GEMM mismatch"
-    print("smoke ok: LN+int4 quant and W4A4 GEMM bit-exact vs oracle")
+    # the draft pass's fused launch: residual add + LN + int4 quant + gate_up GEMM + silu(gate)*up, vs the oracle's ops
+    I = 128
+    d = (rng.standard_normal((T, H)) * 0.3).astype(np.float16)
+    wg = O.pack_i4(rng.integers(-8, 8, (2 * I, H)).astype(np.int8))
+    wgs = (rng.random(2 * I) * 0.01 + 0.001).astype(np.float16)
+    h0 = O.add_f16(x, d)
+    q1, s1, _ = O.ln_quant_i4(h0, 1e-5)
+    act0 = O.silu_mul(O.gemm_w4a4(q1, s1, wg, wgs), I)
+    hout = torch.empty(T, H, dtype=torch.float16, device=dev)
+    act = torch.empty(T, I, dtype=torch.float16, device=dev)
+    ops.ln_gate_up_silu_linear(xd, torch.from_numpy(d).to(dev), hout, 1e-5, torch.from_numpy(wg).to(dev),
+                               torch.from_numpy(wgs).to(dev), act)
+    torch.cuda.synchronize()
+    assert np.array_equal(hout.cpu().numpy().view(np.uint16), h0.view(np.uint16)), "residual add mismatch"
+    assert np.array_equal(act.cpu().numpy().view(np.uint16), act0.view(np.uint16)), "fused LN + gate_up + silu mismatch"
+    print("smoke ok: LN+int4 quant, W4A4 GEMM and the fused LN->gate_up->silu launch bit-exact vs oracle")

@@ -18,7 +18,8 @@ for q_len in (1, 4):
     qs = (torch.arange(B + 1, dtype=torch.int32, device=dev) * q_len).contiguous()
     ws = torch.zeros(ops.paged_attention_workspace_bytes(T, nq, d, n_splits), dtype=torch.uint8, device=dev)
     out = torch.empty(T, nq * d, dtype=torch.float16, device=dev)
-    f = lambda: ops.paged_attention(qkv, row, kc, vc, bt, ctx, qs, T, q_len, nq, d ** -0.5, n_splits, ws, out)
+    PART = os.environ.get('PARTIAL', '0') == '1'
+    f = lambda: ops.paged_attention(qkv, row, kc, vc, bt, ctx, qs, T, q_len, nq, d ** -0.5, n_splits, ws, None if PART else out)
     f(); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
