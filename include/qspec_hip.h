@@ -104,6 +104,15 @@ int qspec_mlp_hadamard(const qspec_half* act, const qspec_half* hadK, qspec_half
 int qspec_rowwise_scaled_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
                                      const qspec_half* bias, qspec_half* out, int M, int N, int K, void* stream);
 
+/* The s4s4 linear above followed by the residual add of QuarotDecoderLayer (quarot_llama.py:380 `hidden = residual +
+ * o_proj(...)`, :390 `residual + down_proj(...)`): resid_out = h(f(resid_in) + f(h(linear))), an fp16 add of the
+ * fp16 GEMM result, in the GEMM's epilogue.  resid_out may alias resid_in.  M <= 16.  The norm that follows then
+ * reads one tensor (qspec_ln_*_linear_s4s4 with delta = NULL, hidden_out = NULL). */
+int qspec_rowwise_scaled_linear_s4s4_residual(const int8_t* xq, const qspec_half* xs, const int8_t* wq,
+                                              const qspec_half* ws, const qspec_half* resid_in, qspec_half* resid_out,
+                                              int M, int N, int K, void* stream);
+int qspec_rowwise_scaled_linear_s4s4_residual_supported(int M, int N, int K);
+
 /* bitblas.Matmul.__call__(x, w ^ 0x88, output=C, scale=ws, bias=bias)  (quarot_nn/linear.py:102-124,156-211).
  *   Takes the SAME wq buffer as the s4s4 op (no XOR copy).  x [M,K] fp16.
  *   workspace: NULL, or qspec_w4a16_workspace_bytes() bytes ZERO-FILLED once before first use: lets narrow layers
@@ -141,7 +150,8 @@ int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const
  * kernel third-party/kernels/csrc/layernorm_kernels.cu:569-716) runs as the PROLOGUE of the GEMM launch:
  *   h = fp16(hidden_in + delta) (delta NULL: h = hidden_in);  hidden_out = h;  (xq, xs) = ln_i4(h);  then the fused
  *   GEMM of qspec_qkv_rope_linear_s4s4 / qspec_gate_up_silu_linear_s4s4.
- * hidden_out must not alias hidden_in (every workgroup re-reads hidden_in; workgroup 0 writes hidden_out).
+ * hidden_out must not alias hidden_in (every workgroup re-reads hidden_in; workgroup 0 writes hidden_out);
+ * hidden_out may be NULL (nothing written): with delta NULL too this is the plain norm of hidden_in.
  * Bit-identical to qspec_add_rms_norm_i4 followed by the GEMM entry.  K = hidden size in {1024, 2048, 4096, 5120, 8192}. 
  * sync_workspace: NULL -> every workgroup recomputes the norm; else qspec_ln_linear_workspace_bytes() bytes,
  * ZERO-FILLED once before first use (every call leaves it zeroed): a few producer workgroups compute the norm and

@@ -152,6 +152,22 @@ int qspec_rowwise_scaled_linear_s4s4(const int8_t* xq, const qspec_half* xs, con
     }
     return finish(op, qspec::gemm_w4a4(xq, CH(xs), wq, CH(ws), CH(bias), H(out), M, N, K, ST));
 }
+int qspec_rowwise_scaled_linear_s4s4_residual(const int8_t* xq, const qspec_half* xs, const int8_t* wq,
+                                              const qspec_half* ws, const qspec_half* resid_in, qspec_half* resid_out,
+                                              int M, int N, int K, void* stream) {
+    const char* op = "qspec_rowwise_scaled_linear_s4s4_residual";
+    if (M < 0 || N < 0) return fail("%s: negative size", op);
+    if (M == 0 || N == 0) return 0;
+    NONNULL(op, xq); NONNULL(op, xs); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, resid_in); NONNULL(op, resid_out);
+    if (!qspec::gemm_w4a4_stream_supported(M, N, K, false))
+        return fail("%s: need M <= 16, N %% 16 == 0 and a built K (M=%d N=%d K=%d)", op, M, N, K);
+    qspec::StreamActs x;
+    x.xq = xq; x.xs = CH(xs);
+    return finish(op, qspec::gemm_w4a4_stream_residual(x, wq, CH(ws), CH(resid_in), H(resid_out), M, N, K, ST));
+}
+int qspec_rowwise_scaled_linear_s4s4_residual_supported(int M, int N, int K) {
+    return qspec::gemm_w4a4_stream_supported(M, N, K, false) ? 1 : 0;
+}
 size_t qspec_w4a16_workspace_bytes(void) { return qspec::gemm_w4a16_ws_bytes(); }
 int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* ws, const qspec_half* bias,
                        qspec_half* out, int M, int N, int K, void* workspace, void* stream) {

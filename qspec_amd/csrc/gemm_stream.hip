@@ -26,8 +26,8 @@
 
 namespace qspec {
 
-enum { SEPI_PLAIN = 0, SEPI_QKV = 1, SEPI_GATEUP = 2 };
-enum { PRO_Q = 0, PRO_LN = 1, PRO_LNH = 2 };  // LNH: LN by a few producer workgroups, handed to the rest through L2
+enum { SEPI_PLAIN = 0, SEPI_QKV = 1, SEPI_GATEUP = 2, SEPI_RESID = 3 };   // RESID: plain + fp16 residual add
+enum { PRO_Q = 0, PRO_LN = 1, PRO_LNH = 2, PRO_LN1 = 3 };   // LN1: norm of hidden_in alone (no delta, no write-back)  // LNH: LN by a few producer workgroups, handed to the rest through L2
 
 struct StreamArgs {
     const int8_t* xq;       // PRO_Q : [M, K/2] packed int4 activations
@@ -37,6 +37,8 @@ struct StreamArgs {
     f16* hidden_out;        // PRO_LN: [M, K] updated residual stream (written by workgroup 0) or nullptr
     float eps;
     int* sync;              // PRO_LNH: hand-off workspace (gemm_w4a4_stream_sync_bytes(), zero-filled once)
+    const f16* resid_in;    // SEPI_RESID: [M, N] residual stream; resid_out = h(f(resid_in) + f(h(gemm)))
+    f16* resid_out;         // SEPI_RESID: [M, N] (may alias resid_in: each element is read and written by one thread)
     const f16* x;           // W4A16: [M, K] fp16 activations, row stride ldx halves
     int64_t ldx, ldw;       // W4A16: activation row stride (halves) / packed weight row stride (bytes); 0 = dense
     int tile0;              // W4A16: first tile of the launch (column-parallel shards)
@@ -122,7 +124,7 @@ struct LnRegs {
     f16x4 x[RB][NI], d[RB][NI];
 };
 
-template <int NI, int NG, int RB>
+template <int NI, int NG, int RB, bool HASD = true>
 __device__ __forceinline__ void ln_load(const StreamArgs& a, int base, LnRegs<NI, RB>& rg) {
     const int tid = threadIdx.x, j = tid & 255, grp = tid >> 8;
     const int H = a.K;
@@ -136,12 +138,12 @@ __device__ __forceinline__ void ln_load(const StreamArgs& a, int base, LnRegs<NI
             // no branch around a load: hipcc answers control flow with s_waitcnt vmcnt(0), which would serialise
             // every load of the prologue (delta == nullptr re-reads hidden_in and the value is discarded)
             rg.x[i][it] = *reinterpret_cast<const f16x4*>(a.hidden_in + (size_t)rr * H + it * 1024 + 4 * j);
-            rg.d[i][it] = *reinterpret_cast<const f16x4*>(dptr + (size_t)rr * H + it * 1024 + 4 * j);
+            if (HASD) rg.d[i][it] = *reinterpret_cast<const f16x4*>(dptr + (size_t)rr * H + it * 1024 + 4 * j);
         }
     }
 }
 
-template <int NI, int NG, int RB>
+template <int NI, int NG, int RB, bool HASD = true>
 __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs<NI, RB>& rg,
                                            unsigned char* xq_lds, int RS, float* xs_lds,
                                            float* lnred /* [3][NG][RB][32] */, bool write_hidden) {
@@ -153,7 +155,7 @@ __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs
     float v[RB][NI][4];
     int row[RB];
     bool act[RB];
-    if (a.delta) {  // uniform; no load inside
+    if (HASD && a.delta) {  // uniform; no load inside
 #pragma unroll
         for (int i = 0; i < RB; i++)
 #pragma unroll
@@ -168,7 +170,7 @@ __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs
         const int rr = act[i] ? row[i] : 0;
 #pragma unroll
         for (int it = 0; it < NI; it++) {
-            if (write_hidden && act[i])
+            if (HASD && write_hidden && act[i])
                 *reinterpret_cast<f16x4*>(a.hidden_out + (size_t)rr * H + it * 1024 + 4 * j) = rg.x[i][it];
 #pragma unroll
             for (int c = 0; c < 4; c++) v[i][it][c] = h2f(rg.x[i][it][c]);
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
     };
     auto load_pre = [&](Pre& pre, int tile) {  // epilogue operands of (token m, column c) of `tile`
         pre.swn = a.ws[stile_row<EPI>(tile, c, a.I)];
+        if (EPI == SEPI_RESID) pre.cf = a.resid_in[(size_t)mc * a.N + tile * 16 + c];   // the residual element
         if (EPI == SEPI_QKV) {
             const int o = (tile & 7) * 8 + (c & 7);
             const f16* cs = a.cos_sin_cache + pos_m * 128;
@@ -339,6 +342,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
         }
         if (EPI == SEPI_PLAIN) {
             if (ethread) a.out[(size_t)m * a.N + tile * 16 + c] = hv;
+            return;
+        }
+        if (EPI == SEPI_RESID) {   // hidden = residual + proj_out, an fp16 add of two fp16 tensors (quarot_llama.py:380,390)
+            if (ethread) a.resid_out[(size_t)m * a.N + tile * 16 + c] = f2h(h2f(pre.cf) + h2f(hv));
             return;
         }
         f16* e = ex + par * 256;
@@ -460,9 +467,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
                 __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-    } else if (PRO == PRO_LN) {
+    } else if (PRO == PRO_LN || PRO == PRO_LN1) {
+        constexpr bool HASD = PRO == PRO_LN;
         LnRegs<NI, RB> rg;
-        ln_load<NI, NG, RB>(a, 0, rg);
+        ln_load<NI, NG, RB, HASD>(a, 0, rg);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < UB; u++) w[u] = *reinterpret_cast<const u32x4*>(wp0 + step_off<NW, UB>(wave, u));
@@ -470,10 +478,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
         __builtin_amdgcn_sched_barrier(0);
         const bool wh = blockIdx.x == 0 && a.hidden_out != nullptr;
         QS_SSTAMP(1);
-        ln_compute<NI, NG, RB>(a, 0, rg, xq_lds, RS, xs_lds, lnred, wh);
+        ln_compute<NI, NG, RB, HASD>(a, 0, rg, xq_lds, RS, xs_lds, lnred, wh);
         for (int base = NG * RB; base < a.M; base += NG * RB) {
-            ln_load<NI, NG, RB>(a, base, rg);
-            ln_compute<NI, NG, RB>(a, base, rg, xq_lds, RS, xs_lds, lnred, wh);
+            ln_load<NI, NG, RB, HASD>(a, base, rg);
+            ln_compute<NI, NG, RB, HASD>(a, base, rg, xq_lds, RS, xs_lds, lnred, wh);
         }
     } else {
         u32x4 araw[UB];
@@ -842,7 +850,7 @@ struct StreamShape {
 static bool stream_shape(int K, StreamShape* sh) {
     const int nsteps = K / 128;
     if (K % 128) return false;
-    static const StreamShape cand[] = {{8, 4, 0}, {16, 7, 0}, {8, 8, 0}, {8, 5, 0}, {4, 4, 0}, {4, 2, 0}};
+    static const StreamShape cand[] = {{8, 4, 0}, {16, 7, 0}, {8, 8, 0}, {8, 5, 0}, {4, 4, 0}, {4, 2, 0}, {4, 7, 0}};
     // one batch per tile (the activation fragments of a wave's K slice live in registers)
     for (const StreamShape& c : cand) {
         if (nsteps != c.NW * c.UB) continue;
@@ -902,6 +910,7 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
         if (sh.NW == 8 && sh.UB == 5) return launch_stream_inst<EPI, PRO_Q, 8, 5, 0>(a, st);
         if (sh.NW == 4 && sh.UB == 4) return launch_stream_inst<EPI, PRO_Q, 4, 4, 0>(a, st);
         if (sh.NW == 4 && sh.UB == 2) return launch_stream_inst<EPI, PRO_Q, 4, 2, 0>(a, st);
+        if (sh.NW == 4 && sh.UB == 7) return launch_stream_inst<EPI, PRO_Q, 4, 7, 0>(a, st);
         return -1;
     }
     // LN prologue: the reference's 1024 virtual threads -> K a multiple of 1024; one batch per tile
@@ -911,6 +920,14 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
         if (a.K == 5120) return launch_stream_inst<EPI, PRO_LNH, 8, 5, 5>(a, st);
         if (a.K == 2048) return launch_stream_inst<EPI, PRO_LNH, 4, 4, 2>(a, st);
         if (a.K == 1024) return launch_stream_inst<EPI, PRO_LNH, 4, 2, 1>(a, st);
+        return -1;
+    }
+    if (!a.delta && !a.hidden_out) {   // pure norm of hidden_in: half the prologue loads
+        if (a.K == 4096) return launch_stream_inst<EPI, PRO_LN1, 8, 4, 4>(a, st);
+        if (a.K == 8192) return launch_stream_inst<EPI, PRO_LN1, 8, 8, 8>(a, st);
+        if (a.K == 5120) return launch_stream_inst<EPI, PRO_LN1, 8, 5, 5>(a, st);
+        if (a.K == 2048) return launch_stream_inst<EPI, PRO_LN1, 4, 4, 2>(a, st);
+        if (a.K == 1024) return launch_stream_inst<EPI, PRO_LN1, 4, 2, 1>(a, st);
         return -1;
     }
     if (a.K == 4096) return launch_stream_inst<EPI, PRO_LN, 8, 4, 4>(a, st);
@@ -1010,6 +1027,17 @@ int gemm_w4a4_stream(const StreamActs& x, const int8_t* wq, const f16* ws, f16* 
     a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps; a.sync = x.sync;
     a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = out; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
     return launch_stream<SEPI_PLAIN>(a, x.hidden_in != nullptr, st);
+}
+
+// resid_out = h(f(resid_in) + f(h(x W^T scales)))  -- the projection and the residual add that follows it
+int gemm_w4a4_stream_residual(const StreamActs& x, const int8_t* wq, const f16* ws, const f16* resid_in, f16* resid_out,
+                              int M, int N, int K, hipStream_t st) {
+    if (!gemm_w4a4_stream_supported(M, N, K, x.hidden_in != nullptr)) return -1;
+    StreamArgs a{};
+    a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps; a.sync = x.sync;
+    a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
+    a.resid_in = resid_in; a.resid_out = resid_out;
+    return launch_stream<SEPI_RESID>(a, x.hidden_in != nullptr, st);
 }
 
 int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,

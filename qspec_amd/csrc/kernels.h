@@ -62,6 +62,8 @@ size_t gemm_w4a4_stream_sync_bytes();
 bool gemm_w4a4_stream_supported(int M, int N, int K, bool ln);
 int gemm_w4a4_stream(const StreamActs& x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K,
                      hipStream_t st);
+int gemm_w4a4_stream_residual(const StreamActs& x, const int8_t* wq, const f16* ws, const f16* resid_in, f16* resid_out,
+                              int M, int N, int K, hipStream_t st);
 int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                               const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
                               const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st);

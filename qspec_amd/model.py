@@ -212,23 +212,24 @@ class QuarotLlamaForCausalLM:
         # draft pass at decode-sized M: residual add + LN + int4 quant run in the prologue of the qkv / gate_up GEMM
         # launches (gemm_stream.hip); the residual stream ping-pongs between two buffers
         ln_fused = (w4a4 and fuse and self.FUSE_LN and ops.ln_linear_s4s4_supported(T, row, cfg.hidden_size)
-                    and ops.ln_linear_s4s4_supported(T, 2 * cfg.intermediate_size, cfg.hidden_size))
-        hidden2 = s.hidden2[:T]
+                    and ops.ln_linear_s4s4_supported(T, 2 * cfg.intermediate_size, cfg.hidden_size)
+                    and ops.rowwise_scaled_linear_s4s4_residual_supported(T, cfg.hidden_size, cfg.hidden_size)
+                    and ops.rowwise_scaled_linear_s4s4_residual_supported(T, cfg.hidden_size, cfg.intermediate_size))
         for li, layer in enumerate(self.layers):
             kc, vc = kv_caches[li]
             qkv_w, qkv_s = layer.qkv_proj.weight, layer.qkv_proj._scales()
             gu_w, gu_s = layer.gate_up.weight, layer.gate_up._scales()
             if ln_fused:
-                # hidden2 = hidden + delta; LN+quant; qkv_proj; rope; kv write                       :373-374,183-226
-                ops.ln_qkv_rope_linear(hidden, delta, hidden2, eps, qkv_w, qkv_s, qkv, positions, self.cos_sin_cache,
-                                       kc, vc, md.slot_mapping, nh, nkv, hd)
-                self._attention_hadamard(qkv, row, kc, vc, md, T, s, attn, q1, sc, None)
-                ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, layer.o_proj.weight, layer.o_proj._scales(), None, o)
-                # hidden = hidden2 + o; LN+quant; gate_up; silu*up                                   :380-388,266-284
-                ops.ln_gate_up_silu_linear(hidden2, o, hidden, eps, gu_w, gu_s, act)
+                # 7 launches per layer; the residual stream is updated in the o_proj / down_proj epilogues
+                # (hidden = residual + proj_out, :380,390), the norms read it in the qkv / gate_up prologues
+                ops.ln_qkv_rope_linear(hidden, None, None, eps, qkv_w, qkv_s, qkv, positions, self.cos_sin_cache,
+                                       kc, vc, md.slot_mapping, nh, nkv, hd)                       # :373-374,183-226
+                self._attention_hadamard(qkv, row, kc, vc, md, T, s, attn, q1, sc, None)            # :213-238
+                ops.rowwise_scaled_linear_s4s4_residual(q1, sc, layer.o_proj.weight, layer.o_proj._scales(), hidden, hidden)
+                ops.ln_gate_up_silu_linear(hidden, None, None, eps, gu_w, gu_s, act)                # :380-388,266-284
                 ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, q=q3, scale=sc)
-                ops.rowwise_scaled_linear_cutlass_s4s4_unified(q3, sc, layer.down_proj.weight, layer.down_proj._scales(), None, o)
-                delta = o
+                ops.rowwise_scaled_linear_s4s4_residual(q3, sc, layer.down_proj.weight, layer.down_proj._scales(), hidden, hidden)
+                delta = None
                 continue
             # input_layernorm (+ residual add of the previous MLP) -> qkv_proj -> rope -> kv write    :373-374,183-226
             if w4a4:

@@ -215,7 +215,7 @@ def ln_qkv_rope_linear(hidden_in, delta, hidden_out, eps, wq, w_scale, qkv, posi
     M, K = hidden_in.shape
     N = wq.shape[0]
     _call("qspec_ln_qkv_rope_linear_s4s4", _chk(hidden_in, "hidden_in", _F16), _opt(delta, "delta", _F16),
-          _chk(hidden_out, "hidden_out", _F16), float(eps), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
+          _opt(hidden_out, "hidden_out", _F16), float(eps), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
           _chk(qkv, "qkv", _F16), M, N, K, _chk(positions, "positions", _I64), _chk(cos_sin_cache, "cos_sin_cache", _F16),
           _chk(key_cache, "key_cache", _F16), _chk(value_cache, "value_cache", _F16),
           _chk(slot_mapping, "slot_mapping", _I64), num_heads, num_kv_heads, head_size, cos_sin_cache.shape[-1],
@@ -229,7 +229,7 @@ def ln_gate_up_silu_linear(hidden_in, delta, hidden_out, eps, wq, w_scale, act):
     M, K = hidden_in.shape
     I = wq.shape[0] // 2
     _call("qspec_ln_gate_up_silu_linear_s4s4", _chk(hidden_in, "hidden_in", _F16), _opt(delta, "delta", _F16),
-          _chk(hidden_out, "hidden_out", _F16), float(eps), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
+          _opt(hidden_out, "hidden_out", _F16), float(eps), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
           _chk(act, "act", _F16), M, I, K, _opt(ln_linear_workspace(hidden_in.device, M), "sync_workspace"), _stream())
     return act
 
@@ -246,6 +246,20 @@ def rowwise_scaled_linear_cutlass_s4s4_unified(xq, x_scale, wq, w_scale, bias, o
           _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16), _opt(bias, "bias", _F16),
           _chk(out, "out", _F16), M, N, Kb * 2, _stream())
     return out
+
+
+def rowwise_scaled_linear_s4s4_residual(xq, x_scale, wq, w_scale, resid_in, resid_out):
+    """resid_out = resid_in + linear_s4s4(xq) (fp16 add of the fp16 GEMM result) in one launch (quarot_llama.py:380,390)."""
+    M, Kb = xq.shape
+    N = wq.shape[0]
+    _call("qspec_rowwise_scaled_linear_s4s4_residual", _chk(xq, "xq", (_I8, _U8)), _chk(x_scale, "x_scale", _F16),
+          _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16), _chk(resid_in, "resid_in", _F16),
+          _chk(resid_out, "resid_out", _F16), M, N, Kb * 2, _stream())
+    return resid_out
+
+
+def rowwise_scaled_linear_s4s4_residual_supported(M: int, N: int, K: int) -> bool:
+    return bool(_lib.load().qspec_rowwise_scaled_linear_s4s4_residual_supported(M, N, K))
 
 
 _w16_ws = {}

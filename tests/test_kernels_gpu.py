@@ -414,6 +414,36 @@ def test_ln_prologue_full_layer_shapes_with_lds_prefetch(ops, oracle, M, monkeyp
     assert torch.equal(act.view(torch.int16), act_ref.view(torch.int16))
 
 
+@pytest.mark.parametrize("M,N,K", [(4, 4096, 4096), (4, 4096, 14336), (16, 1024, 2048), (3, 512, 1024)])
+def test_s4s4_residual_epilogue_equals_linear_then_add(ops, oracle, M, N, K):
+    """hidden = residual + proj_out in the GEMM epilogue == the GEMM entry followed by an fp16 tensor add; also in
+    place (resid_out aliasing resid_in), and the delta-less norm prologue == the plain LN kernel + GEMM."""
+    rng = np.random.default_rng(M + N + K)
+    xq = dev(oracle.pack_i4(rand_w4(rng, M, K))); xs = dev((rng.random(M) * 0.1 + 0.01).astype(np.float16))
+    wq = dev(rng.integers(-128, 128, (N, K // 2)).astype(np.int8)); ws = dev((rng.random(N) * 0.01 + 0.001).astype(np.float16))
+    resid = dev(rand_hidden(rng, M, N))
+    lin = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq, xs, wq, ws, None, lin)
+    ref = resid + lin                                   # fp16 tensor add: one rounding per element
+    out = torch.empty_like(resid)
+    ops.rowwise_scaled_linear_s4s4_residual(xq, xs, wq, ws, resid, out)
+    inplace = resid.clone()
+    ops.rowwise_scaled_linear_s4s4_residual(xq, xs, wq, ws, inplace, inplace)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    assert torch.equal(inplace.view(torch.int16), ref.view(torch.int16))
+    if K in (1024, 2048, 4096):   # norm-only prologue (delta = None, nothing written back)
+        I = 256
+        hid = dev(rand_hidden(rng, M, K))
+        wg = dev(rng.integers(-128, 128, (2 * I, K // 2)).astype(np.int8)); wgs = dev((rng.random(2 * I) * 0.01 + 0.001).astype(np.float16))
+        q = torch.empty(M, K // 2, dtype=torch.int8, device=DEV); sc = torch.empty(M, dtype=torch.float16, device=DEV)
+        ops.rms_norm_general_fuse_sum_i4(q, hid, None, sc, 1e-5)
+        a0 = ops.gate_up_silu_linear(q, sc, wg, wgs, torch.empty(M, I, dtype=torch.float16, device=DEV))
+        a1 = ops.ln_gate_up_silu_linear(hid, None, None, 1e-5, wg, wgs, torch.empty(M, I, dtype=torch.float16, device=DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(a0.view(torch.int16), a1.view(torch.int16))
+
+
 def test_ln_handoff_stress_back_to_back(ops, oracle, monkeypatch):
     """The fence-free producer -> consumer hand-off of the LN-prologue GEMMs under back-to-back launches with
     different inputs each time (a stale flag or a stale row would reuse the previous launch's activations), at the
