@@ -68,8 +68,8 @@ def barrier(world):
 def measure_dominant_kernel(model, engine, reps=5):
     """The dominant kernel = the weight-streaming W4A4 GEMM of the draft pass (qspec::gemm_w4a4_stream_kernel: the
     four decoder GEMM launches of a draft forward at M = batch, 3 of the 4 forwards of a cycle), in exactly the
-    forms the cycle launches: residual add + LN + int4 quant prologue -> qkv (+ RoPE + KV write) / gate_up (+ silu*up),
-    and the plain (xq, xs) form for o_proj / down_proj.  Every decoder GEMM of one draft forward is enqueued in model
+    forms the cycle launches: LN + int4 quant prologue -> qkv (+ RoPE + KV write) / gate_up (+ silu*up), and the
+    (xq, xs) form with the residual add in the epilogue for o_proj / down_proj.  Every decoder GEMM of one draft forward is enqueued in model
     order on the real weights into one hipGraph (launches back to back as in the timed region; each weight byte is
     cold again by the time it is re-read: 3.5 GB > the 256 MiB infinity cache), bracketed by HIP events recorded on
     the launching stream.  Returns algorithmic bytes and seconds per launch, overall and per shape."""
@@ -77,7 +77,7 @@ def measure_dominant_kernel(model, engine, reps=5):
     B = engine.B
     s, md, cfg = engine.scratch_draft, engine.md_draft, model.config
     xq, sc = s.quantized_buffer_qkv[:B], s.scale_buffer[:B]
-    hid, hid2, o = s.hidden[:B], s.hidden2[:B], s.act_buffer_output[:B]
+    hid, o = s.hidden[:B], s.act_buffer_output[:B]
     eps = cfg.rms_norm_eps
     kinds = ("qkv", "o", "gate_up", "down")
     ln_fused = ops.ln_linear_s4s4_supported(B, cfg.q_size + 2 * cfg.kv_size, cfg.hidden_size)
@@ -85,7 +85,7 @@ def measure_dominant_kernel(model, engine, reps=5):
     def launch(layer, kc, vc, kind):
         if kind == "qkv":
             if ln_fused:
-                ops.ln_qkv_rope_linear(hid, o, hid2, eps, layer.qkv_proj.weight, layer.qkv_proj._scales(),
+                ops.ln_qkv_rope_linear(hid, None, None, eps, layer.qkv_proj.weight, layer.qkv_proj._scales(),
                                        s.act_buffer_qkv[:B], engine.d_pos, model.cos_sin_cache, kc, vc, md.slot_mapping,
                                        cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim)
             else:
@@ -93,13 +93,18 @@ def measure_dominant_kernel(model, engine, reps=5):
                                     engine.d_pos, model.cos_sin_cache, kc, vc, md.slot_mapping, cfg.num_attention_heads,
                                     cfg.num_key_value_heads, cfg.head_dim)
         elif kind == "o":
-            ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq, sc, layer.o_proj.weight, layer.o_proj._scales(), None, o)
+            if ln_fused:
+                ops.rowwise_scaled_linear_s4s4_residual(xq, sc, layer.o_proj.weight, layer.o_proj._scales(), hid, hid)
+            else:
+                ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq, sc, layer.o_proj.weight, layer.o_proj._scales(), None, o)
         elif kind == "gate_up":
             if ln_fused:
-                ops.ln_gate_up_silu_linear(hid2, o, hid, eps, layer.gate_up.weight, layer.gate_up._scales(),
+                ops.ln_gate_up_silu_linear(hid, None, None, eps, layer.gate_up.weight, layer.gate_up._scales(),
                                            s.act_buffer_had_mlp[:B])
             else:
                 ops.gate_up_silu_linear(xq, sc, layer.gate_up.weight, layer.gate_up._scales(), s.act_buffer_had_mlp[:B])
+        elif ln_fused:
+            ops.rowwise_scaled_linear_s4s4_residual(s.quantized_buffer_mlp[:B], sc, layer.down_proj.weight, layer.down_proj._scales(), hid, hid)
         else:
             ops.rowwise_scaled_linear_cutlass_s4s4_unified(s.quantized_buffer_mlp[:B], sc, layer.down_proj.weight, layer.down_proj._scales(), None, o)
 
@@ -108,11 +113,12 @@ def measure_dominant_kernel(model, engine, reps=5):
         out_cols = n // 2 if kd == "gate_up" else n
         w = n * kb + 2 * n                                     # packed weights + channel scales
         if ln_fused and kd in ("qkv", "gate_up"):
-            act_in = 2 * B * (2 * kb) * 2                      # residual stream + previous projection, fp16
-            act_out = B * (2 * kb) * 2                         # updated residual stream (written once)
+            act_in = B * (2 * kb) * 2                          # the residual stream, fp16 (normed in the prologue)
         else:
-            act_in, act_out = B * kb + 2 * B, 0                # packed int4 activations + scales
-        return w + act_in + act_out + 2 * B * out_cols
+            act_in = B * kb + 2 * B                            # packed int4 activations + scales
+        if ln_fused and kd in ("o", "down"):
+            act_in += 2 * B * out_cols                         # residual read by the epilogue (written back below)
+        return w + act_in + 2 * B * out_cols
 
     res, tot_b, tot_t, launches = {}, 0.0, 0.0, 0
     for kind in kinds + ("all",):
@@ -282,7 +288,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                            "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic_per_launch(),
                            "kernel": "qspec::gemm_w4a4_stream_kernel (the four decoder GEMM launches of a draft forward, M = batch: "
-                                     "LN+int4-quant prologue -> qkv+RoPE+KV-write / gate_up+silu*up; o_proj; down_proj)",
+                                     "LN+int4-quant prologue -> qkv+RoPE+KV-write / gate_up+silu*up; o_proj / down_proj + residual add)",
                            "launches": n, "avg_launch_us": round(tot_t / n * 1e6, 2),
                            "bytes_per_launch_avg": int(tot_b / n), "per_shape": per_shape}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

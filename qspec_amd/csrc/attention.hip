@@ -451,6 +451,65 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------- generic head size (plumbing path)
+// Any head_size <= 256 (TinyLlama: 64).  One 128-thread workgroup per (query token, head): scores of all visible keys
+// into LDS (fp32 dot products), one softmax over them, then thread j accumulates output dimension j over the keys in
+// order (fp32, deterministic).  No context split, no matrix cores: correctness path for configurations the MFMA
+// kernel (head_size 128) does not cover, not a tuned one.
+__global__ __launch_bounds__(128) void paged_attention_generic_kernel(
+    const f16* __restrict__ q, int64_t q_stride, const f16* __restrict__ key_cache, const f16* __restrict__ value_cache,
+    const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
+    const int32_t* __restrict__ q_start, int n_seqs, int nq, int nkv, int d, int block_size, float sm_scale,
+    f16* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sc = reinterpret_cast<float*>(smem_raw);   // [ctx]
+    __shared__ float red[4];
+    const int t = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    int seq = 0;
+    while (seq + 1 < n_seqs && q_start[seq + 1] <= t) seq++;
+    const int qs = q_start[seq], qlen = q_start[seq + 1] - qs, ctx = ctx_lens[seq];
+    if (t - qs >= qlen) return;
+    const int pos = ctx - qlen + (t - qs);            // absolute position of this query token
+    const int nvis = pos + 1;                          // causal: keys 0..pos
+    const int kvh = h / (nq / nkv);
+    const f16* qp = q + (size_t)t * q_stride + (size_t)h * d;
+    const int32_t* bt = block_tables + (size_t)seq * max_blocks;
+    float mx = -__builtin_inff();
+    for (int k = tid; k < nvis; k += 128) {
+        const int64_t slot = (int64_t)bt[k / block_size] * block_size + k % block_size;
+        const f16* kp = key_cache + (slot * nkv + kvh) * d;
+        float acc = 0.0f;
+        for (int e = 0; e < d; e++) acc = __builtin_fmaf(h2f(qp[e]), h2f(kp[e]), acc);
+        acc *= sm_scale;
+        sc[k] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max_f(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(red[0], red[1]);
+    __syncthreads();
+    float sum = 0.0f;
+    for (int k = tid; k < nvis; k += 128) {
+        const float p = qexpf(sc[k] - mx);
+        sc[k] = p;
+        sum += p;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) sum += shfl_xor_f(sum, m);
+    if ((tid & 63) == 0) red[2 + (tid >> 6)] = sum;
+    __syncthreads();
+    const float den = red[2] + red[3];
+    for (int e = tid; e < d; e += 128) {
+        float acc = 0.0f;
+        for (int k = 0; k < nvis; k++) {
+            const int64_t slot = (int64_t)bt[k / block_size] * block_size + k % block_size;
+            acc = __builtin_fmaf(sc[k], h2f(value_cache[(slot * nkv + kvh) * d + e]), acc);
+        }
+        out[((size_t)t * nq + h) * d + e] = f2h(acc / den);
+    }
+}
+
 // float offsets of the partials inside the workspace (shared with hadamard.hip:heads_hadamard_merge)
 size_t paged_attention_ws_o_offset() { return QS_ATT_CNT_SLOTS; }
 size_t paged_attention_ws_ml_offset(int Tmax, int nq, int d, int n_splits) {
@@ -473,7 +532,15 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
                     float* ws, f16* out, hipStream_t st) {
     // out == nullptr: leave the per-split partials (o, m, l) in the workspace for heads_hadamard_merge
     if (n_seqs == 0) return 0;
-    if (d != 128 || nq % nkv) return -1;
+    if (nq % nkv) return -1;
+    if (d != 128) {   // plumbing path (e.g. TinyLlama's 64): no split, no partials -> needs `out`
+        if (!out || d > 256 || d % 2) return -1;
+        int max_ctx_bytes = 64 * 1024;   // scores of one row in LDS: contexts up to 16 K keys
+        hipLaunchKernelGGL(paged_attention_generic_kernel, dim3(n_seqs * max_q_len, nq), dim3(128), max_ctx_bytes, st, q,
+                           q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, n_seqs, nq, nkv,
+                           d, block_size, sm_scale, out);
+        return 0;
+    }
     if (n_splits < 1 || n_splits > QS_ATT_MAXSPLIT) return -3;
     const int bs_log2 = ilog2_exact(block_size), group_log2 = ilog2_exact(nq / nkv);
     if (bs_log2 < 0 || group_log2 < 0) return -5;  // block size and GQA group must be powers of two

@@ -232,7 +232,8 @@ int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_hal
     if (n_seqs == 0 || tokens == 0) return 0;
     NONNULL(op, q); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, block_tables); NONNULL(op, ctx_lens);
     NONNULL(op, q_start); NONNULL(op, workspace);   /* out == NULL: partials only, see qspec_heads_hadamard_merged */
-    if (head_size != 128) return fail("%s: head_size=%d (only 128 is built)", op, head_size);
+    if (head_size != 128 && (!out || head_size > 256 || head_size % 2))
+        return fail("%s: head_size=%d: the matrix-core kernel is built for 128; other sizes <= 256 run the generic kernel, which needs `out`", op, head_size);
     if (tokens > n_seqs * max_q_len) return fail("%s: tokens=%d > n_seqs*max_q_len=%d", op, tokens, n_seqs * max_q_len);
     int rc = qspec::paged_attention(CH(q), q_stride, CH(key_cache), CH(value_cache), block_tables, max_blocks_per_seq, ctx_lens, q_start, n_seqs, max_q_len, num_heads, num_kv_heads, head_size, block_size, sm_scale, n_splits, (float*)workspace, H(out), ST);
     return finish(op, rc);

@@ -584,6 +584,26 @@ def test_paged_attention_within_1e3(ops, oracle, ctx_lens, q_len):
 
 # ------------------------------------------------------------------ token side
 
+@pytest.mark.parametrize("ctx_lens,q_len,d,nq,nkv", [([37, 200], 1, 64, 32, 4), ([70, 9, 300], 4, 64, 8, 8), ([50], 3, 96, 4, 2)])
+def test_paged_attention_generic_head_size_within_1e3(ops, oracle, ctx_lens, q_len, d, nq, nkv):
+    """Head sizes other than 128 (TinyLlama: 64) take the generic kernel (no context split, no matrix cores)."""
+    rng = np.random.default_rng(sum(ctx_lens) + d)
+    bs = 16
+    n_seqs = len(ctx_lens)
+    bt, kc, vc = make_paged(rng, n_seqs, ctx_lens, nkv, d, bs)
+    T = n_seqs * q_len
+    row = (nq + 2 * nkv) * d
+    qkv = (rng.standard_normal((T, row)) * 0.5).astype(np.float16)
+    q_start = (np.arange(n_seqs + 1) * q_len).astype(np.int32)
+    ctx = np.array(ctx_lens, np.int32)
+    scale = d ** -0.5
+    ref = oracle.paged_attention(qkv[:, : nq * d], kc, vc, bt, ctx, q_start, scale)
+    ws = torch.zeros(ops.paged_attention_workspace_bytes(T, nq, d, 1), dtype=torch.uint8, device=DEV)
+    out = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
+    ops.paged_attention(dev(qkv), row, dev(kc), dev(vc), dev(bt), dev(ctx), dev(q_start), T, q_len, nq, scale, 1, ws, out)
+    assert_close_1e3(host(out), ref)
+
+
 @pytest.mark.parametrize("ctx_lens,q_len,n_splits", [([37, 128, 129, 500], 1, 8), ([37, 130, 260, 515], 4, 5),
                                                      ([1500], 2, 12), ([5, 9], 4, 3)])
 def test_heads_hadamard_merged_equals_attention_merge_then_hadamard(ops, oracle, ctx_lens, q_len, n_splits):
