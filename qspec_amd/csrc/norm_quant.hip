@@ -17,32 +17,37 @@
 namespace qspec {
 
 // Reference summation tree over 1024 virtual-thread partials held 4 per lane.
-// red must hold 32 floats; all 256 threads return the same bits.
+// red must hold 32 floats and is written once per call site (callers pass distinct regions, so no barrier is needed
+// in front); all 256 threads return the same bits.  First butterfly (virtual lane bits 4,3,2 <-> j ^ 4, 2, 1) by DPP
+// moves, second butterfly (32 warp sums) evaluated directly from LDS by every thread: every lane of an xor butterfly
+// ends with the same value, so lane 0's expression tree is the result -- same pairings, same order, same bits as the
+// shuffle form, without five dependent cross-lane exchanges.
 __device__ __forceinline__ float ref_tree_sum_1024(float p0, float p1, float p2, float p3, float* red) {
-    // virtual lane bits 4,3,2 of (4*(j&7)+c)  <->  j ^ 4, 2, 1
-#pragma unroll
-    for (int m = 4; m > 0; m >>= 1) {
-        p0 = p0 + shfl_xor_f(p0, m);
-        p1 = p1 + shfl_xor_f(p1, m);
-        p2 = p2 + shfl_xor_f(p2, m);
-        p3 = p3 + shfl_xor_f(p3, m);
-    }
+    p0 = p0 + dpp_xor<4>(p0); p1 = p1 + dpp_xor<4>(p1); p2 = p2 + dpp_xor<4>(p2); p3 = p3 + dpp_xor<4>(p3);
+    p0 = p0 + dpp_xor<2>(p0); p1 = p1 + dpp_xor<2>(p1); p2 = p2 + dpp_xor<2>(p2); p3 = p3 + dpp_xor<2>(p3);
+    p0 = p0 + dpp_xor<1>(p0); p1 = p1 + dpp_xor<1>(p1); p2 = p2 + dpp_xor<1>(p2); p3 = p3 + dpp_xor<1>(p3);
     // virtual lane bits 1, 0 are in-thread
-    float r0 = p0 + p2, r1 = p1 + p3;
-    float s = r0 + r1;
+    const float r0 = p0 + p2, r1 = p1 + p3;
+    const float s = r0 + r1;
     const int j = threadIdx.x;
-    __syncthreads();  // red may still be read by a previous call
     if ((j & 7) == 0) red[j >> 3] = s;
     __syncthreads();
-    float v = red[j & 31];
+    float v[32];
 #pragma unroll
-    for (int m = 16; m > 0; m >>= 1) v = v + shfl_xor_f(v, m);
-    return v;
+    for (int q = 0; q < 8; q++) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(red + 4 * q);
+        v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+    }
+#pragma unroll
+    for (int m = 16; m > 0; m >>= 1)
+#pragma unroll
+        for (int k = 0; k < m; k++) v[k] = v[k] + v[k + m];
+    return v[0];
 }
 
+// red: 4 floats of its own (written once per call site)
 __device__ __forceinline__ float block_max_256(float v, float* red) {
     v = wave_max_f(v);
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -56,7 +61,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
                                                  f16* hidden_out /* may alias x */, f16* __restrict__ out,
                                                  int8_t* __restrict__ q, f16* __restrict__ scale,
                                                  f16* __restrict__ input_sum, float eps, int H) {
-    __shared__ float red[32];
+    __shared__ __attribute__((aligned(16))) float red_all[4][32];   // one region per reduction: no barrier in front
+    float* red = red_all[0];
     const int row = blockIdx.x, j = threadIdx.x;
     const f16* xr = x + (size_t)row * H;
     float v[NI][4];
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
         }
         p[c] = s;
     }
-    const float var = ref_tree_sum_1024(p[0], p[1], p[2], p[3], red);
+    const float var = ref_tree_sum_1024(p[0], p[1], p[2], p[3], red_all[1]);
     const float rstd = 1.0f / __builtin_sqrtf(var / (float)H + eps);
 
     if (MODE == 1) {
@@ -117,8 +123,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
         }
         p[c] = h2f(s16);
     }
-    const float sum_f = ref_tree_sum_1024(p[0], p[1], p[2], p[3], red);
-    amax = block_max_256(amax, red);
+    const float sum_f = input_sum ? ref_tree_sum_1024(p[0], p[1], p[2], p[3], red_all[2]) : 0.0f;   // write-only output
+    amax = block_max_256(amax, red_all[3]);
     const float s = 7.0f / amax;
 #pragma unroll
     for (int it = 0; it < NI; it++) {
