@@ -382,6 +382,37 @@ def test_ln_prologue_gemms_equal_ln_then_gemm(ops, oracle, M, K, with_delta, han
     assert torch.equal(act.view(torch.int16), act_ref.view(torch.int16))
 
 
+@pytest.mark.parametrize("handoff", [False, True])
+def test_ln_prologue_edge_rows(ops, oracle, handoff, monkeypatch):
+    """Edge rows through the fused norm prologue: all-zero (amax floor 1e-6), constant, tiny, near-overflow, exact
+    .5 ties, -0.0 -- same bytes as the standalone LN kernel (itself oracle-checked on such rows) + GEMM."""
+    monkeypatch.setattr(ops, "LN_HANDOFF", handoff)
+    monkeypatch.setattr(ops, "LN_HANDOFF_MIN_M", 1)
+    K, I = 4096, 256
+    rng = np.random.default_rng(5)
+    x = np.zeros((8, K), np.float16)
+    x[1] = 3.0
+    x[2] = (rng.standard_normal(K) * 1e-4).astype(np.float16)
+    x[3] = (rng.standard_normal(K) * 3e4).clip(-6e4, 6e4).astype(np.float16)
+    x[4] = np.tile(np.array([0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 3.5, -3.5], np.float16), K // 8)
+    x[5] = -0.0
+    x[6] = rand_hidden(rng, 1, K)[0]
+    x[7, ::2] = 1.0
+    for delta in (None, dev((rng.standard_normal((8, K)) * 0.01).astype(np.float16))):
+        hid = dev(x)
+        wg = dev(rng.integers(-128, 128, (2 * I, K // 2)).astype(np.int8)); wgs = dev((rng.random(2 * I) * 0.01 + 0.001).astype(np.float16))
+        q = torch.empty(8, K // 2, dtype=torch.int8, device=DEV); sc = torch.empty(8, dtype=torch.float16, device=DEV)
+        h0 = torch.empty_like(hid)
+        ops.add_rms_norm_i4(q, sc, h0, hid, delta, 1e-5)
+        a0 = ops.gate_up_silu_linear(q, sc, wg, wgs, torch.empty(8, I, dtype=torch.float16, device=DEV))
+        h1 = torch.empty_like(hid) if delta is not None else None
+        a1 = ops.ln_gate_up_silu_linear(hid, delta, h1, 1e-5, wg, wgs, torch.empty(8, I, dtype=torch.float16, device=DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(a0.view(torch.int16), a1.view(torch.int16))
+        if delta is not None:
+            assert torch.equal(h0.view(torch.int16), h1.view(torch.int16))
+
+
 @pytest.mark.parametrize("M", [4, 3, 16])
 def test_ln_prologue_full_layer_shapes_with_lds_prefetch(ops, oracle, M, monkeypatch):
     """Llama-3-8B layer shapes: several tiles per workgroup, so the tiles behind the first one are brought into LDS
