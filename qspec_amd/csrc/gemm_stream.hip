@@ -619,16 +619,42 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
     auto wptr = [&](int tile) -> const uint8_t* {
         return a.wq + (size_t)stile_row<EPI>(tile, r, a.I) * ldw + g * 16;
     };
-    // activation fragments of this wave's K slice (rows >= M repeat row 0: their outputs are never stored)
-    u32x4 araw[UB][4];
-    {
-        const f16* xrow = a.x + (size_t)(r < a.M ? r : 0) * ldx + g * 32;
+    // Activation fragments of this wave's K slice (rows >= M repeat row 0: their outputs are never stored).
+    // As MFMA fragments they are 16 rows x 64-byte pieces per load instruction (measured: the 128 KB per workgroup cost
+    // ~3 us that way), so the workgroup copies the [16 x K] tile through LDS instead: fully coalesced global loads
+    // (1 KiB of one row per wave instruction), 16-byte chunks XOR-swizzled by the row so the ds_read_b128 fragment
+    // reads are conflict-free, one stage = the K range of a pair of steps (NW * 256 k), double buffered.
+    constexpr int UE = UB & ~1, NST = (UB + 1) / 2;            // paired steps / stages
+    constexpr int CPT = 8;                                      // 16-byte chunks per thread and (full) stage
+    unsigned char* abuf = smem + (size_t)2 * NW * 1024 + 1024;  // [2][16 rows][NW * 512 B]
+    constexpr int SBMAX = NW * 512;
+    u32x4 areg[2][CPT];
+    auto stage_load = [&](u32x4(&dst)[CPT], int st_) {
+        const bool paired = 2 * st_ < UE;
+        const int cpr = paired ? NW * 32 : NW * 16;             // chunks per row in this stage
+        const size_t kbase = paired ? (size_t)st_ * NW * 256 : (size_t)UE * NW * 128;
 #pragma unroll
-        for (int u = 0; u < UB; u++)
+        for (int i = 0; i < CPT; i++) {
+            const int cidx = tid + i * NW * 64;
+            const int row = paired ? cidx / (NW * 32) : (cidx / (NW * 16)) & 15;   // unpaired: CPT covers the rows twice
+            const int q = cidx % cpr;
+            dst[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)(row < a.M ? row : 0) * ldx + kbase + (size_t)q * 8);
+        }
+    };
+    auto stage_store = [&](const u32x4(&src)[CPT], int st_) {
+        const bool paired = 2 * st_ < UE;
+        const int cpr = paired ? NW * 32 : NW * 16;
+        unsigned char* buf = abuf + (size_t)(st_ & 1) * 16 * SBMAX;
 #pragma unroll
-            for (int dd = 0; dd < 4; dd++)
-                araw[u][dd] = *reinterpret_cast<const u32x4*>(xrow + 2 * step_off<NW, UB>(wave, u) + dd * 8);
-    }
+        for (int i = 0; i < CPT; i++) {
+            const int cidx = tid + i * NW * 64;
+            const int row = paired ? cidx / (NW * 32) : (cidx / (NW * 16)) & 15;
+            const int q = cidx % cpr;
+            *reinterpret_cast<u32x4*>(buf + (size_t)row * SBMAX + ((q ^ row) << 4)) = src[i];
+        }
+    };
+    stage_load(areg[0], 0);
+    if (NST > 1) stage_load(areg[1], 1);
     int tile = a.tile0 + blockIdx.x, par = 0;
     const int tile_end = a.tile0 + a.ntiles;
     const int my_tiles = (tile_end - tile + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -644,9 +670,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
     __builtin_amdgcn_sched_barrier(0);
     f16x8 af[UB][4];
 #pragma unroll
-    for (int u = 0; u < UB; u++)
+    for (int st_ = 0; st_ < NST; st_++) {
+        stage_store(areg[st_ & 1], st_);
+        __syncthreads();
+        if (st_ + 2 < NST) stage_load(areg[st_ & 1], st_ + 2);   // compile-time condition (unrolled)
+        const bool paired = 2 * st_ < UE;
+        const unsigned char* buf = abuf + (size_t)(st_ & 1) * 16 * SBMAX + (size_t)r * SBMAX;
 #pragma unroll
-        for (int dd = 0; dd < 4; dd++) af[u][dd] = sshuffle_act8(araw[u][dd]);
+        for (int j = 0; j < 2; j++) {
+            const int u = 2 * st_ + j;
+            if (u < UB) {
+#pragma unroll
+                for (int dd = 0; dd < 4; dd++) {
+                    const int qq = paired ? wave * 32 + j * 16 + g * 4 + dd : wave * 16 + g * 4 + dd;
+                    af[u][dd] = sshuffle_act8(*reinterpret_cast<const u32x4*>(buf + ((qq ^ r) << 4)));
+                }
+            }
+        }
+    }
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     auto use = [&](const u32x4& wv, int u) {
@@ -942,7 +983,14 @@ size_t gemm_w4a4_stream_sync_bytes() { return 32 * sizeof(int) + (size_t)16 * (8
 
 template <int EPI, int NW, int UB>
 static int launch_stream16_inst(const StreamArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)2 * NW * 1024 + 1024;
+    const size_t lds = (size_t)2 * NW * 1024 + 1024 + (size_t)2 * 16 * NW * 512;   // reduction + activation staging
+    static size_t attr_set = 0;
+    if (lds > 64 * 1024 && lds > attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4a16_stream_kernel<EPI, NW, UB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -8;
+        attr_set = lds;
+    }
     const int cap = stream_cap();
     int grid = a.ntiles;
     if (grid > cap) {
