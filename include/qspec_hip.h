@@ -122,6 +122,17 @@ size_t qspec_w4a16_workspace_bytes(void);
 int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* ws, const qspec_half* bias,
                        qspec_half* out, int M, int N, int K, void* workspace, void* stream);
 
+/* Long-K W4A16 layers at M <= 16 (down_proj, K = 14336: 16 rows x K of fp16 activations do not fit a CU's registers):
+ * K is cut into `slices` = qspec_w4a16_linear_partial_slices(M, N, K) slices (0: not needed / not built) and the raw
+ * fp32 sums of each slice go to part [slices][M][N].  Whoever consumes them forms h((p_0 + p_1 + ...) * f(ws[n])):
+ * qspec_w4a16_linear does it with a finishing launch, the verify pass inside the norm that follows
+ * (qspec_add_rms_norm_fp16_partial: hidden_out = x + that, out = LN(hidden_out)); same expression, same bits. */
+int qspec_w4a16_linear_partial_slices(int M, int N, int K);
+int qspec_w4a16_linear_partial(const qspec_half* x, const int8_t* wq, float* part, int M, int N, int K, int slices,
+                               void* stream);
+int qspec_add_rms_norm_fp16_partial(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const float* part,
+                                    const qspec_half* ws, int slices, float eps, int tokens, int hidden, void* stream);
+
 /* qkv_proj fused with what follows it in QuarotLlamaAttention.forward (quarot_llama.py:183-226): the GEMM
  * (s4s4: linear.py:82 / w4a16: linear.py:122) -> ops.rotary_embedding on q,k (csrc/pos_encoding_kernels.cu:71-122)
  * -> reshape_and_cache_flash of k,v (csrc/cache_kernels.cu:207-303).  wq rows are [q; k; v] (fuse_qkv,

@@ -48,6 +48,9 @@ SIGNATURES = {
     "qspec_rowwise_scaled_linear_s4s4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_w4a16_workspace_bytes": (_sz, []),
     "qspec_w4a16_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "qspec_w4a16_linear_partial_slices": (_i, [_i, _i, _i]),
+    "qspec_w4a16_linear_partial": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "qspec_add_rms_norm_fp16_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _vp]),
     "qspec_w4a16_linear_ksliced": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "qspec_gate_up_silu_linear_w4a16_shard": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "qspec_linear_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

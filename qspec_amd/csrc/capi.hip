@@ -178,6 +178,14 @@ int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* 
     if (N % 16 || K % 128 || K <= 0) return fail("%s: need N %% 16 == 0 and K %% 128 == 0 (N=%d K=%d)", op, N, K);
     if (!bias && use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K))
         return finish(op, qspec::gemm_w4a16_stream(CH(x), 0, wq, 0, CH(ws), H(out), M, N, K, ST));
+    // long K (down_proj): K slices of a built length, raw sums in the workspace (behind its ticket counters), finish
+    const int S = (!bias && use_stream() && workspace) ? qspec::gemm_w4a16_stream_partial_slices(M, N, K) : 0;
+    if (S > 0 && (size_t)S * M * N * sizeof(float) + 8192 <= qspec::gemm_w4a16_ws_bytes()) {
+        float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 8192);
+        int rc = qspec::gemm_w4a16_stream_partial(CH(x), 0, wq, 0, part, M, N, K, S, ST);
+        if (rc == 0) rc = qspec::gemm_w4a16_partial_finish(part, CH(ws), H(out), M, N, S, ST);
+        return finish(op, rc);
+    }
     return finish(op, qspec::gemm_w4a16(CH(x), wq, CH(ws), CH(bias), H(out), M, N, K, workspace, ST));
 }
 int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, int M, int N, int K, void* stream) {
@@ -403,6 +411,15 @@ int qspec_w4a16_linear_ksliced(const qspec_half* x, int64_t ldx, const int8_t* w
     if (N % 16 || K % 128 || ldw_bytes % 16 || ldx % 8) return fail("%s: need N%%16, K%%128, ldw%%16, ldx%%8 == 0", op);
     if (use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K))
         return finish(op, qspec::gemm_w4a16_stream(CH(x), ldx, wq, ldw_bytes, CH(ws), H(out), M, N, K, ST));
+    {
+        const int S = (use_stream() && workspace) ? qspec::gemm_w4a16_stream_partial_slices(M, N, K) : 0;
+        if (S > 0 && (size_t)S * M * N * sizeof(float) + 8192 <= qspec::gemm_w4a16_ws_bytes()) {
+            float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 8192);
+            int rc = qspec::gemm_w4a16_stream_partial(CH(x), ldx, wq, ldw_bytes, part, M, N, K, S, ST);
+            if (rc == 0) rc = qspec::gemm_w4a16_partial_finish(part, CH(ws), H(out), M, N, S, ST);
+            return finish(op, rc);
+        }
+    }
     return finish(op, qspec::gemm_w4a16_strided(CH(x), ldx, wq, ldw_bytes, CH(ws), H(out), M, N, K, workspace, ST));
 }
 int qspec_gate_up_silu_linear_w4a16_shard(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act,
@@ -450,6 +467,27 @@ int qspec_ln_gate_up_silu_linear_s4s4(const qspec_half* hidden_in, const qspec_h
     return finish(op, qspec::gemm_w4a4_stream_gate_up_silu(x, wq, CH(ws), H(act), M, intermediate, K, ST));
 }
 size_t qspec_ln_linear_workspace_bytes(void) { return qspec::gemm_w4a4_stream_sync_bytes(); }
+int qspec_w4a16_linear_partial_slices(int M, int N, int K) { return use_stream() ? qspec::gemm_w4a16_stream_partial_slices(M, N, K) : 0; }
+int qspec_w4a16_linear_partial(const qspec_half* x, const int8_t* wq, float* part, int M, int N, int K, int slices,
+                               void* stream) {
+    const char* op = "qspec_w4a16_linear_partial";
+    if (M == 0 || N == 0) return 0;
+    NONNULL(op, x); NONNULL(op, wq); NONNULL(op, part);
+    if (slices < 2 || slices != qspec::gemm_w4a16_stream_partial_slices(M, N, K))
+        return fail("%s: (M=%d N=%d K=%d) takes %d slices (qspec_w4a16_linear_partial_slices), got %d", op, M, N, K,
+                    qspec::gemm_w4a16_stream_partial_slices(M, N, K), slices);
+    return finish(op, qspec::gemm_w4a16_stream_partial(CH(x), 0, wq, 0, part, M, N, K, slices, ST));
+}
+int qspec_add_rms_norm_fp16_partial(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const float* part,
+                                    const qspec_half* ws, int slices, float eps, int tokens, int hidden, void* stream) {
+    const char* op = "qspec_add_rms_norm_fp16_partial";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, out); NONNULL(op, x); NONNULL(op, part); NONNULL(op, ws); NONNULL(op, hidden_out);
+    if (slices < 1) return fail("%s: slices < 1", op);
+    if (hidden % 1024 || hidden > 8192 || hidden <= 0) return fail("%s: hidden=%d must be a multiple of 1024, <= 8192", op, hidden);
+    return finish(op, qspec::ln_fp16_partial(CH(x), part, CH(ws), slices, H(hidden_out), H(out), eps, tokens, hidden, ST));
+}
 int qspec_prefetch(const void* p, size_t bytes, int workgroups, void* stream) {
     const char* op = "qspec_prefetch";
     if (bytes == 0) return 0;

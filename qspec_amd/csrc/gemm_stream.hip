@@ -26,7 +26,7 @@
 
 namespace qspec {
 
-enum { SEPI_PLAIN = 0, SEPI_QKV = 1, SEPI_GATEUP = 2, SEPI_RESID = 3 };   // RESID: plain + fp16 residual add
+enum { SEPI_PLAIN = 0, SEPI_QKV = 1, SEPI_GATEUP = 2, SEPI_RESID = 3, SEPI_PARTIAL = 4 };   // RESID: plain + fp16 residual add
 enum { PRO_Q = 0, PRO_LN = 1, PRO_LNH = 2, PRO_LN1 = 3 };   // LN1: norm of hidden_in alone (no delta, no write-back)  // LNH: LN by a few producer workgroups, handed to the rest through L2
 
 struct StreamArgs {
@@ -42,6 +42,7 @@ struct StreamArgs {
     const f16* x;           // W4A16: [M, K] fp16 activations, row stride ldx halves
     int64_t ldx, ldw;       // W4A16: activation row stride (halves) / packed weight row stride (bytes); 0 = dense
     int tile0;              // W4A16: first tile of the launch (column-parallel shards)
+    float* part;            // W4A16 SEPI_PARTIAL: [gridDim.y][M][N] raw fp32 sums of K slice blockIdx.y (K = slice length)
     const uint8_t* wq;      // [N, K/2]
     const f16* ws;          // [N]
     f16* out;
@@ -591,6 +592,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
     const int r = lane & 15, g = lane >> 4;
     const int Kb = a.K >> 1;
     const size_t ldw = a.ldw ? (size_t)a.ldw : (size_t)Kb, ldx = a.ldx ? (size_t)a.ldx : (size_t)a.K;
+    // SEPI_PARTIAL: blockIdx.y picks one of gridDim.y K slices of length K (x row stride ldx, weight row stride ldw);
+    // the raw fp32 sums go to part[blockIdx.y] and are combined in slice order by whoever consumes them
+    const size_t kofs = EPI == SEPI_PARTIAL ? (size_t)blockIdx.y * a.K : 0;
     float* red = reinterpret_cast<float*>(smem);                     // [2][NW][256]
     f16* ex = reinterpret_cast<f16*>(red + 2 * NW * 256);            // [2][256]
     // epilogue thread t owns output (token m = t / 16, tile column c = t % 16): for M <= 4 that is wave 0 alone, the
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
         }
     };
     auto wptr = [&](int tile) -> const uint8_t* {
-        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I) * ldw + g * 16;
+        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I) * ldw + (kofs >> 1) + g * 16;
     };
     // Activation fragments of this wave's K slice (rows >= M repeat row 0: their outputs are never stored).
     // As MFMA fragments they are 16 rows x 64-byte pieces per load instruction (measured: the 128 KB per workgroup cost
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
             const int cidx = tid + i * NW * 64;
             const int row = paired ? cidx / (NW * 32) : (cidx / (NW * 16)) & 15;   // unpaired: CPT covers the rows twice
             const int q = cidx % cpr;
-            dst[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)(row < a.M ? row : 0) * ldx + kbase + (size_t)q * 8);
+            dst[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)(row < a.M ? row : 0) * ldx + kofs + kbase + (size_t)q * 8);
         }
     };
     auto stage_store = [&](const u32x4(&src)[CPT], int st_) {
@@ -707,7 +711,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
 #pragma unroll
             for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[w2 * 256 + ridx];   // wave order: deterministic
             hv = f2h(sum * h2f(pre.swn));
+            if (EPI == SEPI_PARTIAL) a.part[((size_t)blockIdx.y * a.M + m) * a.N + tile * 16 + c] = sum;
         }
+        if (EPI == SEPI_PARTIAL) return;
         if (EPI == SEPI_PLAIN) {
             if (ethread) a.out[(size_t)m * a.N + tile * 16 + c] = hv;
             return;
@@ -981,6 +987,17 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
 
 size_t gemm_w4a4_stream_sync_bytes() { return 32 * sizeof(int) + (size_t)16 * (8192 / 2) + 16 * sizeof(float) + 64; }
 
+// out[m,n] = h( (p_0 + p_1 + ...)[m,n] * f(sw[n]) ): K slices combined in slice order (deterministic).  The verify
+// pass does this inside the next norm kernel instead (norm_quant.hip, ln_kernel with `part`); same expression.
+__global__ __launch_bounds__(256) void w4a16_partial_finish_kernel(const float* __restrict__ part, const f16* __restrict__ ws,
+                                                                     f16* __restrict__ out, int MN, int N, int S) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= MN) return;
+    float sum = part[i];
+    for (int s2 = 1; s2 < S; s2++) sum = sum + part[(size_t)s2 * MN + i];
+    out[i] = f2h(sum * h2f(ws[i % N]));
+}
+
 template <int EPI, int NW, int UB>
 static int launch_stream16_inst(const StreamArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * NW * 1024 + 1024 + (size_t)2 * 16 * NW * 512;   // reduction + activation staging
@@ -997,7 +1014,15 @@ static int launch_stream16_inst(const StreamArgs& a, hipStream_t st) {
         const int per = (a.ntiles + cap - 1) / cap;
         grid = (a.ntiles + per - 1) / per;
     }
-    hipLaunchKernelGGL((gemm_w4a16_stream_kernel<EPI, NW, UB>), dim3(grid), dim3(NW * 64), lds, st, a);
+    const int slices = EPI == SEPI_PARTIAL ? a.nq : 1;   // (nq carries the slice count for SEPI_PARTIAL)
+    if (slices > 1) {   // one workgroup per CU in total: the tile groups share the grid with the slices
+        const int per_slice = cap / slices > 0 ? cap / slices : 1;
+        if (grid > per_slice) {
+            const int per = (a.ntiles + per_slice - 1) / per_slice;
+            grid = (a.ntiles + per - 1) / per;
+        }
+    }
+    hipLaunchKernelGGL((gemm_w4a16_stream_kernel<EPI, NW, UB>), dim3(grid, slices), dim3(NW * 64), lds, st, a);
     return 0;
 }
 
@@ -1038,6 +1063,29 @@ int gemm_w4a16_stream(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, 
     a.x = x; a.ldx = ldx; a.ldw = ldw; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = out;
     a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
     return launch_stream16<SEPI_PLAIN>(a, st);
+}
+
+// Long-K layers (down_proj, K = 14336): 16 rows x K of fp16 activations do not fit one CU's registers, so K is cut
+// into S slices of a built length (14336 = 2 x 7168), slice s on workgroups (tile group, s); raw fp32 sums per slice
+// go to part [S][M][N].  Returns the slice count to use for (M, N, K), 0 if the shape is not covered.
+int gemm_w4a16_stream_partial_slices(int M, int N, int K) {
+    if (gemm_w4a16_stream_supported(M, N, K)) return 0;   // fits unsliced: use the plain entry
+    for (int S = 2; S <= 4; S++)
+        if (K % S == 0 && gemm_w4a16_stream_supported(M, N, K / S)) return S;
+    return 0;
+}
+int gemm_w4a16_stream_partial(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, float* part, int M, int N, int K,
+                              int S, hipStream_t st) {
+    if (S < 2 || K % S || !gemm_w4a16_stream_supported(M, N, K / S) || !part) return -1;
+    StreamArgs a{};
+    a.x = x; a.ldx = ldx ? ldx : K; a.ldw = ldw ? ldw : K / 2; a.wq = reinterpret_cast<const uint8_t*>(wq);
+    a.M = M; a.N = N; a.K = K / S; a.ntiles = N / 16; a.part = part; a.nq = S;
+    return launch_stream16<SEPI_PARTIAL>(a, st);
+}
+int gemm_w4a16_partial_finish(const float* part, const f16* ws, f16* out, int M, int N, int S, hipStream_t st) {
+    const int MN = M * N;
+    hipLaunchKernelGGL(w4a16_partial_finish_kernel, dim3((MN + 255) / 256), dim3(256), 0, st, part, ws, out, MN, N, S);
+    return 0;
 }
 
 int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,

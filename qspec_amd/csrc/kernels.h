@@ -12,6 +12,9 @@ typedef _Float16 f16;
 int ln_quant_i4(const f16* x, const f16* delta, f16* hidden_out, int8_t* q, f16* scale, f16* isum, float eps, int T,
                 int H, hipStream_t st);
 int ln_fp16(const f16* x, const f16* delta, f16* hidden_out, f16* out, float eps, int T, int H, hipStream_t st);
+// delta = h((part[0] + ... + part[S-1])[t, :] * f(ws[:])): the K-sliced W4A16 projection finished inside the norm
+int ln_fp16_partial(const f16* x, const float* part, const f16* ws, int S, f16* hidden_out, f16* out, float eps, int T,
+                    int H, hipStream_t st);
 int rowabsmax_quant(const f16* x, f16* scale, int8_t* q, float clip, int T, int K, hipStream_t st);
 
 // hadamard.hip
@@ -74,6 +77,10 @@ int gemm_w4a4_stream_gate_up_silu(const StreamActs& x, const int8_t* wq, const f
 bool gemm_w4a16_stream_supported(int M, int N, int K);
 int gemm_w4a16_stream(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, const f16* ws, f16* out, int M, int N,
                       int K, hipStream_t st);
+int gemm_w4a16_stream_partial_slices(int M, int N, int K);
+int gemm_w4a16_stream_partial(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, float* part, int M, int N, int K,
+                              int S, hipStream_t st);
+int gemm_w4a16_partial_finish(const float* part, const f16* ws, f16* out, int M, int N, int S, hipStream_t st);
 int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                                const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
                                const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st);

@@ -60,7 +60,9 @@ template <int NI, int MODE>
 __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __restrict__ delta,
                                                  f16* hidden_out /* may alias x */, f16* __restrict__ out,
                                                  int8_t* __restrict__ q, f16* __restrict__ scale,
-                                                 f16* __restrict__ input_sum, float eps, int H) {
+                                                 f16* __restrict__ input_sum, float eps, int H,
+                                                 const float* __restrict__ part = nullptr,
+                                                 const f16* __restrict__ pws = nullptr, int S = 0, size_t pstride = 0) {
     __shared__ __attribute__((aligned(16))) float red_all[4][32];   // one region per reduction: no barrier in front
     float* red = red_all[0];
     const int row = blockIdx.x, j = threadIdx.x;
@@ -69,7 +71,21 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
 #pragma unroll
     for (int it = 0; it < NI; it++) {
         f16x4 a = *reinterpret_cast<const f16x4*>(xr + it * 1024 + 4 * j);
-        if (delta) {
+        if (part) {
+            // delta arrives as S raw fp32 K-slice sums of a W4A16 projection (gemm_stream.hip, SEPI_PARTIAL):
+            // delta = h((p_0 + p_1 + ...) * f(sw)), the expression of w4a16_partial_finish_kernel
+            const size_t col = (size_t)it * 1024 + 4 * j;
+            f32x4 sum = *reinterpret_cast<const f32x4*>(part + (size_t)row * H + col);
+            for (int s2 = 1; s2 < S; s2++) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(part + (size_t)s2 * pstride + (size_t)row * H + col);
+#pragma unroll
+                for (int c = 0; c < 4; c++) sum[c] = sum[c] + t[c];
+            }
+            const f16x4 w4 = *reinterpret_cast<const f16x4*>(pws + col);
+#pragma unroll
+            for (int c = 0; c < 4; c++) a[c] = f2h(h2f(a[c]) + h2f(f2h(sum[c] * h2f(w4[c]))));
+            if (hidden_out) *reinterpret_cast<f16x4*>(hidden_out + (size_t)row * H + it * 1024 + 4 * j) = a;
+        } else if (delta) {
             f16x4 b = *reinterpret_cast<const f16x4*>(delta + (size_t)row * H + it * 1024 + 4 * j);
 #pragma unroll
             for (int c = 0; c < 4; c++) a[c] = f2h(h2f(a[c]) + h2f(b[c]));
@@ -167,6 +183,22 @@ int ln_quant_i4(const f16* x, const f16* delta, f16* hidden_out, int8_t* q, f16*
 }
 int ln_fp16(const f16* x, const f16* delta, f16* hidden_out, f16* out, float eps, int T, int H, hipStream_t st) {
     return launch_ln<1>(x, delta, hidden_out, out, nullptr, nullptr, nullptr, eps, T, H, st);
+}
+int ln_fp16_partial(const f16* x, const float* part, const f16* ws, int S, f16* hidden_out, f16* out, float eps, int T,
+                    int H, hipStream_t st) {
+    if (T == 0) return 0;
+    if (S < 1 || !part || !ws) return -1;
+#define QS_LNP_CASE(NI)                                                                                              \
+    case NI:                                                                                                         \
+        hipLaunchKernelGGL((ln_kernel<NI, 1>), dim3(T), dim3(256), 0, st, x, (const f16*)nullptr, hidden_out, out,   \
+                           (int8_t*)nullptr, (f16*)nullptr, (f16*)nullptr, eps, H, part, ws, S, (size_t)T * H);     \
+        break;
+    switch (H / 1024) {
+        QS_LNP_CASE(1) QS_LNP_CASE(2) QS_LNP_CASE(3) QS_LNP_CASE(4) QS_LNP_CASE(5) QS_LNP_CASE(6) QS_LNP_CASE(7) QS_LNP_CASE(8)
+        default: return -1;
+    }
+#undef QS_LNP_CASE
+    return 0;
 }
 
 // ----------------------------------------------------------------- row absmax

@@ -99,6 +99,8 @@ class Scratch:
         self.act_buffer_gate_up = e(T, 2 * I)
         self.act_buffer_had_mlp = e(T, I)
         self.logits = e(T if logits_rows is None else logits_rows, cfg.vocab_size)
+        # verify pass: raw fp32 K-slice sums of down_proj, finished inside the next norm (ops.w4a16_linear_partial)
+        self.down_part = e(4, T, H, dtype=torch.float32) if T <= 16 else None
         ws = ops.paged_attention_workspace_bytes(n_seqs * max_q_len, cfg.num_attention_heads, cfg.head_dim, n_splits)
         self.attn_ws = torch.zeros(ws, dtype=torch.uint8, device=device)   # ticket counters start at zero
 
@@ -166,6 +168,15 @@ class QuarotLlamaForCausalLM:
             self._dq[key] = torch.empty(key[0], key[1] * 2, dtype=torch.float16, device=self.device)
         wd = ops.dequant_w4(lin.weight, lin._scales(), self._dq[key])
         return torch.matmul(x, wd.t(), out=out)
+
+    def _add_norm_fp16(self, normed, hidden, delta, eps):
+        """hidden += delta; normed = LN(hidden).  delta: fp16 tensor, None, or ("partial", part, w_scale, S) = the raw
+        K-slice sums of a long-K W4A16 down_proj, finished inside the norm kernel."""
+        if isinstance(delta, tuple):
+            _, part, w_scale, S = delta
+            ops.add_rms_norm_fp16_partial(normed, hidden, hidden, part, w_scale, S, eps)
+        else:
+            ops.add_rms_norm_fp16(normed, hidden, hidden, delta, eps)
 
     MERGE_IN_HADAMARD = True   # False: the attention kernel merges its context splits itself (ticket + fences)
 
@@ -236,7 +247,7 @@ class QuarotLlamaForCausalLM:
                 ops.add_rms_norm_i4(q1, sc, hidden, hidden, delta, eps)
                 x, xs = q1, sc
             else:
-                ops.add_rms_norm_fp16(normed, hidden, hidden, delta, eps)
+                self._add_norm_fp16(normed, hidden, delta, eps)
                 x, xs = normed, None
             if fuse:
                 ops.qkv_rope_linear(x, xs, qkv_w, qkv_s, qkv, positions, self.cos_sin_cache, kc, vc, md.slot_mapping,
@@ -292,10 +303,18 @@ class QuarotLlamaForCausalLM:
                 ops.w4a16_linear_ksliced(had_mlp_in, layer.down_proj.weight, layer.down_proj._scales(), o, k0, k1)
                 self.tp.all_reduce(o)
             else:
+                S = 0
+                if fuse and s.down_part is not None:   # long K at decode-sized M: K slices, finished by the next norm
+                    S = ops.w4a16_linear_partial_slices(T, cfg.hidden_size, cfg.intermediate_size)
+                if 0 < S <= 4:
+                    part = s.down_part.view(-1)[:S * T * cfg.hidden_size].view(S, T, cfg.hidden_size)
+                    ops.w4a16_linear_partial(had_mlp_in, layer.down_proj.weight, part, S)
+                    delta = ("partial", part, layer.down_proj._scales(), S)
+                    continue
                 self._w4a16(had_mlp_in, layer.down_proj, o)
             delta = o
         # final norm is always fp16, in both passes (self.norm(hidden_states) without kwargs, :533)
-        ops.add_rms_norm_fp16(normed, hidden, hidden, delta, eps)
+        self._add_norm_fp16(normed, hidden, delta, eps)
         return normed
 
     def compute_logits(self, hidden_states, scratch: Scratch, shard_vocab: bool = False):

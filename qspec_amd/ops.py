@@ -286,6 +286,28 @@ def w4a16_linear(x, wq, w_scale, out, bias=None):
     return out
 
 
+def w4a16_linear_partial_slices(M: int, N: int, K: int) -> int:
+    """Slices the long-K W4A16 path cuts K into for this shape (0: use w4a16_linear)."""
+    return int(_lib.load().qspec_w4a16_linear_partial_slices(M, N, K))
+
+
+def w4a16_linear_partial(x, wq, part, slices: int):
+    """Raw fp32 K-slice sums of x @ dequant(wq)^T into part [slices, M, N] (finished by add_rms_norm_fp16_partial)."""
+    M, K = x.shape
+    N = wq.shape[0]
+    _call("qspec_w4a16_linear_partial", _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)), _chk(part, "part", _F32), M, N, K,
+          slices, _stream())
+    return part
+
+
+def add_rms_norm_fp16_partial(out, hidden_out, x, part, w_scale, slices: int, eps: float):
+    """hidden_out = x + h(sum_s part[s] * w_scale); out = LN(hidden_out) -- the finish of w4a16_linear_partial fused in."""
+    H = x.shape[-1]
+    T = x.numel() // H
+    _call("qspec_add_rms_norm_fp16_partial", _chk(out, "out", _F16), _chk(hidden_out, "hidden_out", _F16),
+          _chk(x, "x", _F16), _chk(part, "part", _F32), _chk(w_scale, "w_scale", _F16), slices, float(eps), T, H, _stream())
+
+
 def w4a16_linear_ksliced(x, wq, w_scale, out, k0: int, k1: int):
     """Row-parallel shard: out = x[:, k0:k1] @ dequant(wq)[:, k0:k1]^T * w_scale (partial sum; caller all-reduces).
     x [M,K] and wq [N,K/2] are the FULL tensors; only the K range is read."""

@@ -770,6 +770,33 @@ def test_advance_step(ops, oracle):
 
 # ------------------------------------------------------------------ tensor-parallel views
 
+@pytest.mark.parametrize("M,N,K", [(16, 4096, 14336), (5, 4096, 14336), (16, 1024, 14336)])
+def test_w4a16_long_k_slices_and_norm_finish(ops, oracle, M, N, K):
+    """Long-K W4A16 (down_proj): K slices -> raw fp32 sums; w4a16_linear finishes them with a small launch, the verify
+    pass inside the next norm.  Both against the oracle (1e-3) and against each other (bit for bit)."""
+    rng = np.random.default_rng(M + N)
+    x = rand_hidden(rng, M, K)
+    w = rand_w4(rng, N, K)
+    wq = oracle.pack_i4(w)
+    ws = (rng.random(N) * 0.002 + 0.0005).astype(np.float16)
+    S = ops.w4a16_linear_partial_slices(M, N, K)
+    assert S == 2
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.w4a16_linear(dev(x), dev(wq), dev(ws), out)
+    assert_close_1e3(host(out), oracle.gemm_w4a16(x, wq, ws))
+    if N % 1024 == 0:   # the norm-side finish needs a hidden size the norm kernel is built for
+        part = torch.empty(S, M, N, dtype=torch.float32, device=DEV)
+        ops.w4a16_linear_partial(dev(x), dev(wq), part, S)
+        hidden = dev(rand_hidden(rng, M, N))
+        n0 = torch.empty_like(hidden); h0 = torch.empty_like(hidden)
+        ops.add_rms_norm_fp16(n0, h0, hidden, out, 1e-5)
+        n1 = torch.empty_like(hidden); h1 = torch.empty_like(hidden)
+        ops.add_rms_norm_fp16_partial(n1, h1, hidden, part, dev(ws), S, 1e-5)
+        torch.cuda.synchronize()
+        assert torch.equal(h0.view(torch.int16), h1.view(torch.int16))
+        assert torch.equal(n0.view(torch.int16), n1.view(torch.int16))
+
+
 @pytest.mark.parametrize("M,N,K,world", [(16, 4096, 4096, 8), (16, 4096, 14336, 8), (4, 1024, 3584, 2)])
 def test_w4a16_ksliced_partials_sum_to_full(ops, oracle, M, N, K, world):
     from qspec_amd.parallel import shard_range
