@@ -254,29 +254,33 @@ __global__ __launch_bounds__(NH * 8) void heads_hadamard_wide_kernel(const f16* 
 // Thread (head = tid / 8, 16 columns) merges with 16-byte loads, all issued up front; the merged row goes through
 // LDS to the Hadamard thread mapping.
 template <int NH, bool QUANT>
-__global__ __launch_bounds__(NH * 8) void heads_hadamard_merge_kernel(const float* __restrict__ ws_o,
-                                                                       const float* __restrict__ ws_ml, int S,
-                                                                       f16* __restrict__ out16, int8_t* __restrict__ q,
-                                                                       f16* __restrict__ scale, float had_scale,
-                                                                       float clip) {
+__global__ __launch_bounds__(1024) void heads_hadamard_merge_kernel(const float* __restrict__ ws_o,
+                                                                        const float* __restrict__ ws_ml, int S,
+                                                                        f16* __restrict__ out16, int8_t* __restrict__ q,
+                                                                        f16* __restrict__ scale, float had_scale,
+                                                                        float clip) {
+    // 1024 threads merge (CP = 4 or 8 columns each: 4x / 2x fewer loads and instructions per wave than with NH * 8
+    // threads, and 4 waves per SIMD to hide them); the first NH * 8 threads then run the head transform, the others
+    // retire.
     constexpr int HG = NH / 8, D = 128, SMAX = 8;
+    constexpr int CP = NH * D / 1024, TPH = D / CP;   // columns per merge thread, merge threads per head
     __shared__ float xl[NH][D];
     __shared__ __attribute__((aligned(16))) f16 al[NH][D];
     __shared__ float red[HG];
-    const int t = blockIdx.x, tid = threadIdx.x, dc = tid & 63, hg = tid >> 6;
+    const int t = blockIdx.x, tid = threadIdx.x, dc = tid & 63, hg = (tid >> 6) & (HG - 1);
     {   // ---- merge
-        const int head = tid >> 3, c0 = (tid & 7) * 16;
+        const int head = tid / TPH, c0 = (tid % TPH) * CP;
         const size_t th = (size_t)t * NH + head;
         const float* ob = ws_o + th * S * D + c0;
         const float* mlb = ws_ml + th * S * 2;
-        float num[16];
+        f32x4 num[CP / 4];
 #pragma unroll
-        for (int e = 0; e < 16; e++) num[e] = 0.0f;
+        for (int v4 = 0; v4 < CP / 4; v4++) num[v4] = f32x4{0.f, 0.f, 0.f, 0.f};
         float den = 0.0f;
         float M = -__builtin_inff();
         for (int s0 = 0; s0 < S; s0 += SMAX) {   // S <= 8 in one trip: every load in flight before the first use
             float2 ml[SMAX];
-            f32x4 o[SMAX][4];
+            f32x4 o[SMAX][CP / 4];
 #pragma unroll
             for (int s2 = 0; s2 < SMAX; s2++) {
                 const int sc = min(s0 + s2, S - 1);
@@ -286,10 +290,13 @@ __global__ __launch_bounds__(NH * 8) void heads_hadamard_merge_kernel(const floa
             for (int s2 = 0; s2 < SMAX; s2++) {
                 const int sc = min(s0 + s2, S - 1);
 #pragma unroll
-                for (int v4 = 0; v4 < 4; v4++) o[s2][v4] = *reinterpret_cast<const f32x4*>(ob + (size_t)sc * D + v4 * 4);
+                for (int v4 = 0; v4 < CP / 4; v4++) o[s2][v4] = *reinterpret_cast<const f32x4*>(ob + (size_t)sc * D + v4 * 4);
             }
-            if (s0 == 0) {   // M over ALL splits first (as attention.hip does), the (m, l) of later trips re-read
-                for (int s2 = 0; s2 < S; s2++) M = fmaxf(M, mlb[s2 * 2]);
+            if (s0 == 0) {   // M over ALL splits first (as attention.hip does): from the registers just loaded;
+                             // only splits beyond the first trip (S > 8, long contexts) are re-read
+#pragma unroll
+                for (int s2 = 0; s2 < SMAX; s2++) M = fmaxf(M, s2 < S ? ml[s2].x : -__builtin_inff());
+                for (int s2 = SMAX; s2 < S; s2++) M = fmaxf(M, mlb[s2 * 2]);
             }
 #pragma unroll
             for (int s2 = 0; s2 < SMAX; s2++) {
@@ -298,22 +305,22 @@ __global__ __launch_bounds__(NH * 8) void heads_hadamard_merge_kernel(const floa
                     const float w = m == -__builtin_inff() ? 0.0f : qexpf(m - M);
                     den = __builtin_fmaf(w, ml[s2].y, den);
 #pragma unroll
-                    for (int v4 = 0; v4 < 4; v4++)
+                    for (int v4 = 0; v4 < CP / 4; v4++)
 #pragma unroll
-                        for (int e = 0; e < 4; e++) num[v4 * 4 + e] = __builtin_fmaf(w, o[s2][v4][e], num[v4 * 4 + e]);
+                        for (int e = 0; e < 4; e++) num[v4][e] = __builtin_fmaf(w, o[s2][v4][e], num[v4][e]);
                 }
             }
         }
-        f16x8 h0, h1;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            h0[e] = f2h(num[e] / den);
-            h1[e] = f2h(num[8 + e] / den);
+        for (int v4 = 0; v4 < CP / 4; v4++) {
+            f16x4 h0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) h0[e] = f2h(num[v4][e] / den);
+            *reinterpret_cast<f16x4*>(&al[head][c0 + v4 * 4]) = h0;
         }
-        *reinterpret_cast<f16x8*>(&al[head][c0]) = h0;
-        *reinterpret_cast<f16x8*>(&al[head][c0 + 8]) = h1;
     }
     __syncthreads();
+    if (tid >= NH * 8) return;   // retired waves no longer take part in the barriers below
     float v0[8], v1[8];
 #pragma unroll
     for (int h = 0; h < 8; h++) {
@@ -411,10 +418,10 @@ int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out
 #define QS_HHM(NHV)                                                                                                \
     if (heads == NHV) {                                                                                             \
         if (quant)                                                                                                  \
-            hipLaunchKernelGGL((heads_hadamard_merge_kernel<NHV, true>), dim3(T), dim3(NHV * 8), 0, st, ws_o, ws_ml, \
+            hipLaunchKernelGGL((heads_hadamard_merge_kernel<NHV, true>), dim3(T), dim3(1024), 0, st, ws_o, ws_ml, \
                                n_splits, out_f16, q, scale, had_scale, clip);                                       \
         else                                                                                                        \
-            hipLaunchKernelGGL((heads_hadamard_merge_kernel<NHV, false>), dim3(T), dim3(NHV * 8), 0, st, ws_o, ws_ml, \
+            hipLaunchKernelGGL((heads_hadamard_merge_kernel<NHV, false>), dim3(T), dim3(1024), 0, st, ws_o, ws_ml, \
                                n_splits, out_f16, q, scale, had_scale, clip);                                       \
         return 0;                                                                                                   \
     }
