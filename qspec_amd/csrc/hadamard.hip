@@ -510,8 +510,8 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
     // pre_activated: the input is already g = silu(gate)*up, [T, I] (fused into the gate_up GEMM epilogue)
     const f16* up = gate_up + (size_t)t * (pre_activated ? I : 2 * I);
     const f16* gate = up + I;
-    if (K > 1)
-        for (int i = tid; i < K * K; i += NT) had[i] = h2f(hadK[i]);
+    // hadK -> LDS AFTER phase A (it is only read in phase B): staged here it would put an L2 round trip in front of
+    // the first activation load (results return in issue order).
 
     // phase A: one chunk of P elements per wave trip (a token's 14336 elements keep 16 waves = 4 per SIMD busy:
     // this kernel is VALU bound -- correctly rounded fp32 divisions in SiLU and in the quantiser)
@@ -595,6 +595,8 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
 #else
 #define QS_ST2(i)
 #endif
+    if (K > 1)
+        for (int i = tid; i < K * K; i += NT) had[i] = h2f(hadK[i]);
     QS_ST2(1);
     __syncthreads();
     QS_ST2(2);
