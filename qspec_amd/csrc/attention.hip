@@ -545,7 +545,7 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
     const int bs_log2 = ilog2_exact(block_size), group_log2 = ilog2_exact(nq / nkv);
     if (bs_log2 < 0 || group_log2 < 0) return -5;  // block size and GQA group must be powers of two
     const int n_rb = ((max_q_len << group_log2) + QS_ATT_MAXR - 1) / QS_ATT_MAXR;
-    if ((size_t)n_seqs * nkv * n_rb > QS_ATT_CNT_SLOTS) return -4;
+    if (out && (size_t)n_seqs * nkv * n_rb > QS_ATT_CNT_SLOTS) return -4;   // ticket counters: in-kernel merge only
     // workspace: [ticket counters | o partials | (m,l) partials]; sized by the host for n_seqs*max_q_len tokens.
     // It must be zero-filled once before its first use; every call leaves the counters zero again.
     const size_t Tmax = (size_t)n_seqs * max_q_len;
