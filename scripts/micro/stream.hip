@@ -2,6 +2,7 @@
 // (graph replay over > 256 MiB of rotating copies; results reduced to one store per wave so nothing is elided)
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -74,7 +75,7 @@ int main() {
                 auto run = [&](auto kern) {
                     return time_graph([&](int i) { hipLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), 0, st, pool + (size_t)(i % L) * bytes, Kb, spw, ntiles, out); }, L * 2, st);
                 };
-                if (spw % 8 == 0) { t[0] = run(rd<0, 8>); t[1] = run(rd<1, 8>); t[2] = run(rd<2, 8>); }
+                if (spw % 8 == 0 && getenv("UB4") == nullptr) { t[0] = run(rd<0, 8>); t[1] = run(rd<1, 8>); t[2] = run(rd<2, 8>); }
                 else if (spw % 7 == 0) { t[0] = run(rd<0, 7>); t[1] = run(rd<1, 7>); t[2] = -1; }
                 else if (spw % 4 == 0) { t[0] = run(rd<0, 4>); t[1] = run(rd<1, 4>); t[2] = run(rd<2, 4>); }
                 else if (spw % 2 == 0) { t[0] = run(rd<0, 2>); t[1] = run(rd<1, 2>); t[2] = run(rd<2, 2>); }
