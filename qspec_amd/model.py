@@ -6,7 +6,7 @@ QuarotDecoderLayer :319, LlamaModel :436, QuarotLlamaForCausalLM :597): same wei
 One set of packed int4 weights and one paged KV cache serve both passes.
 
 Two implementations of the layer body:
-  * `forward`            -- the product path: 10 fused HIP kernels per layer, no transposes / copies;
+  * `forward`            -- the product path: 7 (draft) / 9 (verify) fused HIP launches per layer, no transposes / copies;
   * `forward_modulewise` -- module by module through qspec_amd.quarot_nn exactly in the reference's order
                             (one reference op per call); kept for parity tests of the fusion.
 """
@@ -86,7 +86,6 @@ class Scratch:
         e = lambda *s, dtype=f16: torch.empty(*s, dtype=dtype, device=device)  # noqa: E731
         self.T = T
         self.hidden = e(T, H)
-        self.hidden2 = e(T, H)                                 # draft pass: ping-pong partner of `hidden` (LN-prologue GEMMs)
         self.normed = e(T, H)                                  # verify: fp16 LN output
         self.quantized_buffer_qkv = e(T, H // 2, dtype=i8)     # draft: int4 activations of width H
         self.quantized_buffer_mlp = e(T, I // 2, dtype=i8)

@@ -50,7 +50,7 @@ def make_inputs(model, rng, ctx_lens, q_len, block_size=16):
 
 @pytest.mark.parametrize("w4a4,ctx_lens,q_len", [(True, [40, 130, 7, 260], 1), (False, [40, 130, 9, 260], 4)])
 def test_fused_forward_equals_modulewise(tiny, w4a4, ctx_lens, q_len):
-    """The 10-kernel fused layer must reproduce the reference-order, one-op-per-module path bit for bit."""
+    """The fused layer (7 / 9 launches) must reproduce the reference-order, one-op-per-module path bit for bit."""
     from qspec_amd.model import Scratch
     rng = np.random.default_rng(0)
     inp = make_inputs(tiny, rng, ctx_lens, q_len)
