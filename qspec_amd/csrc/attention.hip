@@ -189,11 +189,15 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
     const int r0 = rb * QS_ATT_MAXR;
     const int R = min(QS_ATT_MAXR, (qlen << group_log2) - r0);
     if (R <= 0) return;  // uniform for the whole workgroup
-    // keys per split adapt to the sequence: ceil(ctx / n_splits) rounded up to a 16-key tile (<= 128), so that a
-    // short context still spreads over all n_splits workgroups (each CU only draws ~25 GB/s)
-    const int chunk = min(QS_ATT_CHUNK, (((ctx + n_splits - 1) / n_splits) + 15) & ~15);
-    const int k_begin = split * chunk;
-    const int nkeys = max(0, min(ctx, k_begin + chunk) - k_begin);
+    // Keys per split adapt to the sequence: ceil(ctx / n_splits) rounded up to a 16-key tile, so that a short context
+    // still spreads over all n_splits workgroups (each CU only draws ~25 GB/s).  A split longer than 128 keys is walked
+    // in 128-key chunks with a running (max, sum, output) -- flash-decoding with an inner loop -- so the number of
+    // splits (and of partials to merge) stays put while the context grows; the loads of chunk i+1 are issued before
+    // chunk i is consumed.  One chunk per split is the same arithmetic as before the loop existed.
+    const int kps = (((ctx + n_splits - 1) / n_splits) + 15) & ~15;
+    const int k_begin = split * kps;
+    const int k_end = min(ctx, k_begin + kps);
+    const int n_it = max(1, (min(kps, max(k_end - k_begin, 0)) + QS_ATT_CHUNK - 1) / QS_ATT_CHUNK);
     const int c16 = lane & 15, g4 = lane >> 4;
     const int32_t* bt = block_tables + (size_t)seq * max_blocks;
 #ifdef QS_ATT_STAMPS
@@ -204,142 +208,173 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
 #endif
     QS_STAMP(0);
 
-    // ---- every global load up front, in two waves of requests: vmcnt retires in order, so a block-table read
-    // placed between data loads would make its dependent address wait for ALL earlier data loads.
-    // (1) all block-table entries (index clamped, so they do not wait for ctx_lens)
-    int64_t ksl[2], vsl[8];
+    // No load below sits behind a branch (hipcc answers control flow around a load with s_waitcnt vmcnt(0), which
+    // would serialise the prefetch): block-table indices and key rows are clamped, out-of-range keys are masked
+    // after the load (scores -> -inf, V rows -> 0).
+    struct Slots {
+        int64_t k[2], v[8];
+    };
+    struct KV {
+        u32x4 kfrag[2][4], vraw[8];
+    };
+    auto lookup = [&](Slots& sl, int kb) {   // block-table entries of the chunk starting at key kb
 #pragma unroll
-    for (int t2 = 0; t2 < 2; t2++) {
-        const int p = k_begin + (wave * 2 + t2) * 16 + c16;
-        ksl[t2] = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
-    }
+        for (int t2 = 0; t2 < 2; t2++) {
+            const int p = kb + (wave * 2 + t2) * 16 + c16;
+            sl.k[t2] = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
+        }
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int p = k_begin + wave * 4 + g4 + 16 * i;
-        vsl[i] = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
-    }
-    // (2) Q fragments (independent of the table), then K fragments and V rows
-    u32x4 kfrag[2][4], qfrag[4], vraw[8];
-    {  // lane (row c16, d slice 8*g4 + 32j); rows >= R are zero
+        for (int i = 0; i < 8; i++) {
+            const int p = kb + wave * 4 + g4 + 16 * i;
+            sl.v[i] = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
+        }
+    };
+    auto fetch = [&](KV& kv, const Slots& sl) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {  // lane (key c16 of tile 2w+t2, d slice 8*g4 + 32j)
+            const f16* kp = key_cache + (sl.k[t2] * nkv + kvh) * D + g4 * 8;
+#pragma unroll
+            for (int j = 0; j < 4; j++) kv.kfrag[t2][j] = *reinterpret_cast<const u32x4*>(kp + 32 * j);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)  // 16 lanes cover one 256-byte V row; wave w, group g4 -> keys 4w+g4 + 16i
+            kv.vraw[i] = *reinterpret_cast<const u32x4*>(value_cache + (sl.v[i] * nkv + kvh) * D + c16 * 8);
+    };
+    Slots sl_cur, sl_nxt;
+    lookup(sl_cur, k_begin);
+    lookup(sl_nxt, k_begin + (n_it > 1 ? QS_ATT_CHUNK : 0));
+    u32x4 qfrag[4];
+    {  // lane (row c16, d slice 8*g4 + 32j); rows >= R repeat row 0 (their outputs are never stored)
         const int r = r0 + (c16 < R ? c16 : 0);
         const int tok = qs + (r >> group_log2), head = (kvh << group_log2) + (r & gmask);
         const f16* qp = q + (size_t)tok * q_stride + (size_t)head * D + g4 * 8;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            qfrag[j] = u32x4{0, 0, 0, 0};
-            if (c16 < R) qfrag[j] = *reinterpret_cast<const u32x4*>(qp + 32 * j);
-        }
+        for (int j = 0; j < 4; j++) qfrag[j] = *reinterpret_cast<const u32x4*>(qp + 32 * j);
     }
-#pragma unroll
-    for (int t2 = 0; t2 < 2; t2++) {  // lane (key c16 of tile 2w+t2, d slice 8*g4 + 32j)
-        const int kk = (wave * 2 + t2) * 16 + c16;
-        const f16* kp = key_cache + (ksl[t2] * nkv + kvh) * D + g4 * 8;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            kfrag[t2][j] = u32x4{0, 0, 0, 0};
-            if (kk < nkeys) kfrag[t2][j] = *reinterpret_cast<const u32x4*>(kp + 32 * j);
-        }
+    KV cur, nxt;
+    fetch(cur, sl_cur);
+    if (tid < QS_ATT_MAXR) {
+        row_m[tid] = -__builtin_inff();
+        row_l[tid] = 0.0f;
     }
-#pragma unroll
-    for (int i = 0; i < 8; i++) {  // 16 lanes cover one 256-byte V row; wave w, group g4 -> keys 4w+g4 + 16i
-        const int kk = wave * 4 + g4 + 16 * i;
-        vraw[i] = u32x4{0, 0, 0, 0};
-        if (kk < nkeys) vraw[i] = *reinterpret_cast<const u32x4*>(value_cache + (vsl[i] * nkv + kvh) * D + c16 * 8);
-    }
-
+    float* row_a = wgt;   // [16] rescale factors of the running output (wgt is free until the merge)
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
     QS_STAMP(1);
-    // ---- S = Q K^T (fp32 accumulate) -> sc[row][key], masked and scaled
-#pragma unroll
-    for (int t2 = 0; t2 < 2; t2++) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, qfrag[j]),
-                                                         __builtin_bit_cast(f16x8, kfrag[t2][j]), acc, 0, 0, 0);
-        const int kk = (wave * 2 + t2) * 16 + c16;  // lane holds rows 4*g4 + reg of key column kk
-        const int p = k_begin + kk;
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int r = 4 * g4 + reg;
-            const int pos = ctx - qlen + ((r0 + r) >> group_log2);  // absolute position of this query token
-            sc[r * QS_ATT_CHUNK + kk] = (kk < nkeys && p <= pos) ? acc[reg] * sm_scale : -__builtin_inff();
-        }
-    }
-    // V rows -> LDS (zeros beyond nkeys keep the MFMA clean)
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        *reinterpret_cast<u32x4*>(vl + (wave * 4 + g4 + 16 * i) * QS_ATT_VSTRIDE + c16 * 8) = vraw[i];
-    __syncthreads();
 
-    QS_STAMP(2);
-    // ---- softmax over the 128 keys of a row: thread (row = tid>>4, 8 keys = tid&15)
-    {
-        const int r = tid >> 4, ks = tid & 15;
-        const float4 a = *reinterpret_cast<const float4*>(sc + r * QS_ATT_CHUNK + ks * 8);
-        const float4 b = *reinterpret_cast<const float4*>(sc + r * QS_ATT_CHUNK + ks * 8 + 4);
-        float s8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        float mx = s8[0];
+    auto process = [&](const KV& kv, int kb, bool last) {
+        const int nkeys = max(0, min(k_end - kb, QS_ATT_CHUNK));
+        // ---- S = Q K^T (fp32 accumulate) -> sc[row][key], masked and scaled
 #pragma unroll
-        for (int i = 1; i < 8; i++) mx = fmaxf(mx, s8[i]);
-        // the 16 lanes of a row exchange through DPP (max: order independent)
-        mx = fmaxf(mx, dpp_xor<8>(mx));
-        mx = fmaxf(mx, dpp_xor<4>(mx));
-        mx = fmaxf(mx, dpp_xor<2>(mx));
-        mx = fmaxf(mx, dpp_xor<1>(mx));
-        float sum = 0.0f;
-        f16x8 p8, p8lo;
+        for (int t2 = 0; t2 < 2; t2++) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, qfrag[j]),
+                                                             __builtin_bit_cast(f16x8, kv.kfrag[t2][j]), acc, 0, 0, 0);
+            const int kk = (wave * 2 + t2) * 16 + c16;  // lane holds rows 4*g4 + reg of key column kk
+            const int p = kb + kk;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int r = 4 * g4 + reg;
+                const int pos = ctx - qlen + ((r0 + r) >> group_log2);  // absolute position of this query token
+                sc[r * QS_ATT_CHUNK + kk] = (kk < nkeys && p <= pos) ? acc[reg] * sm_scale : -__builtin_inff();
+            }
+        }
+        // V rows -> LDS (zeros beyond nkeys keep the MFMA clean)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float pv = mx == -__builtin_inff() ? 0.0f : qexpf(s8[i] - mx);
-            // the matrix core takes fp16 operands: carry the fp32 probability as hi + lo so that P.V keeps
-            // fp32-class accuracy (22 bits) for two MFMAs instead of one
-            const f16 ph = f2h(pv);
-            p8[i] = ph;
-            p8lo[i] = f2h(pv - h2f(ph));
-            sum += pv;
+            const int kk = wave * 4 + g4 + 16 * i;
+            const u32x4 vz = kk < nkeys ? kv.vraw[i] : u32x4{0, 0, 0, 0};
+            *reinterpret_cast<u32x4*>(vl + kk * QS_ATT_VSTRIDE + c16 * 8) = vz;
         }
-        sum += dpp_xor<8>(sum);   // same pairing order as the xor butterfly it replaces (8, 4, 2, 1)
-        sum += dpp_xor<4>(sum);
-        sum += dpp_xor<2>(sum);
-        sum += dpp_xor<1>(sum);
-        *reinterpret_cast<f16x8*>(pl + r * QS_ATT_CHUNK + ks * 8) = p8;
-        *reinterpret_cast<f16x8*>(pl2 + r * QS_ATT_CHUNK + ks * 8) = p8lo;
-        if (ks == 0) {
-            row_m[r] = mx;
-            row_l[r] = sum;
+        __syncthreads();
+        // ---- softmax over the 128 keys of a row, folded into the running (max, sum): thread (row = tid>>4, 8 keys)
+        {
+            const int r = tid >> 4, ks = tid & 15;
+            const float4 a = *reinterpret_cast<const float4*>(sc + r * QS_ATT_CHUNK + ks * 8);
+            const float4 b = *reinterpret_cast<const float4*>(sc + r * QS_ATT_CHUNK + ks * 8 + 4);
+            float s8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            float mx = s8[0];
+#pragma unroll
+            for (int i = 1; i < 8; i++) mx = fmaxf(mx, s8[i]);
+            // the 16 lanes of a row exchange through DPP (max: order independent)
+            mx = fmaxf(mx, dpp_xor<8>(mx));
+            mx = fmaxf(mx, dpp_xor<4>(mx));
+            mx = fmaxf(mx, dpp_xor<2>(mx));
+            mx = fmaxf(mx, dpp_xor<1>(mx));
+            const float m_old = row_m[r];              // the row's 16 lanes sit in one wave: read before lane 0 writes
+            const float m_new = fmaxf(m_old, mx);
+            float sum = 0.0f;
+            f16x8 p8, p8lo;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float pv = m_new == -__builtin_inff() ? 0.0f : qexpf(s8[i] - m_new);
+                // the matrix core takes fp16 operands: carry the fp32 probability as hi + lo so that P.V keeps
+                // fp32-class accuracy (22 bits) for two MFMAs instead of one
+                const f16 ph = f2h(pv);
+                p8[i] = ph;
+                p8lo[i] = f2h(pv - h2f(ph));
+                sum += pv;
+            }
+            sum += dpp_xor<8>(sum);   // same pairing order as the xor butterfly it replaces (8, 4, 2, 1)
+            sum += dpp_xor<4>(sum);
+            sum += dpp_xor<2>(sum);
+            sum += dpp_xor<1>(sum);
+            *reinterpret_cast<f16x8*>(pl + r * QS_ATT_CHUNK + ks * 8) = p8;
+            *reinterpret_cast<f16x8*>(pl2 + r * QS_ATT_CHUNK + ks * 8) = p8lo;
+            if (ks == 0) {
+                const float alpha = m_old == -__builtin_inff() ? 0.0f : qexpf(m_old - m_new);   // e^0 = 1 exactly
+                row_a[r] = alpha;
+                row_m[r] = m_new;
+                row_l[r] = __builtin_fmaf(row_l[r], alpha, sum);   // first chunk: 0 * 0 + sum
+            }
         }
-    }
-    __syncthreads();
-
-    QS_STAMP(3);
-    // ---- O = P V: wave w owns d columns 32w..32w+31 (two 16-wide tiles), k over the 128 keys in 4 steps of 32
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-    {
-        const uint32_t vl_base = (uint32_t)(uintptr_t)vl;  // LDS byte address (low 32 bits of the shared pointer)
-        const int qd = c16 >> 2, pq = c16 & 3;              // lane 4q+p of its 16-lane group
+        __syncthreads();
+        // ---- O = O * alpha + P V: wave w owns d columns 32w..32w+31 (two 16-wide tiles), k over the 128 keys in 4 steps
+        {
 #pragma unroll
-        for (int st = 0; st < 4; st++) {
-            const f16x8 pa = *reinterpret_cast<const f16x8*>(pl + c16 * QS_ATT_CHUNK + st * 32 + g4 * 8);
-            const f16x8 pb = *reinterpret_cast<const f16x8*>(pl2 + c16 * QS_ATT_CHUNK + st * 32 + g4 * 8);
-            // B fragment of lane (col c16, group g4) = V[key st*32 + 8*g4 + j][d0 + c16], j = 0..7
-            const int krow = st * 32 + g4 * 8 + qd;
+            for (int reg = 0; reg < 4; reg++) {
+                const float al = row_a[4 * g4 + reg];
+                o0[reg] *= al;
+                o1[reg] *= al;
+            }
+            const uint32_t vl_base = (uint32_t)(uintptr_t)vl;  // LDS byte address (low 32 bits of the shared pointer)
+            const int qd = c16 >> 2, pq = c16 & 3;              // lane 4q+p of its 16-lane group
 #pragma unroll
-            for (int dt = 0; dt < 2; dt++) {
-                const int d0 = wave * 32 + dt * 16;
-                const uint32_t a0 = vl_base + (uint32_t)((krow * QS_ATT_VSTRIDE + d0 + 4 * pq) * 2);
-                const u32x2 lo = lds_read_tr_b16(a0);
-                const u32x2 hi = lds_read_tr_b16(a0 + 4 * QS_ATT_VSTRIDE * 2);
-                const u32x4 bw = {lo[0], lo[1], hi[0], hi[1]};
-                if (dt == 0) {
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o0, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o0, 0, 0, 0);
-                } else {
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o1, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o1, 0, 0, 0);
+            for (int st = 0; st < 4; st++) {
+                const f16x8 pa = *reinterpret_cast<const f16x8*>(pl + c16 * QS_ATT_CHUNK + st * 32 + g4 * 8);
+                const f16x8 pb = *reinterpret_cast<const f16x8*>(pl2 + c16 * QS_ATT_CHUNK + st * 32 + g4 * 8);
+                // B fragment of lane (col c16, group g4) = V[key st*32 + 8*g4 + j][d0 + c16], j = 0..7
+                const int krow = st * 32 + g4 * 8 + qd;
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++) {
+                    const int d0 = wave * 32 + dt * 16;
+                    const uint32_t a0 = vl_base + (uint32_t)((krow * QS_ATT_VSTRIDE + d0 + 4 * pq) * 2);
+                    const u32x2 lo = lds_read_tr_b16(a0);
+                    const u32x2 hi = lds_read_tr_b16(a0 + 4 * QS_ATT_VSTRIDE * 2);
+                    const u32x4 bw = {lo[0], lo[1], hi[0], hi[1]};
+                    if (dt == 0) {
+                        o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o0, 0, 0, 0);
+                        o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o0, 0, 0, 0);
+                    } else {
+                        o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o1, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o1, 0, 0, 0);
+                    }
                 }
             }
         }
+        if (!last) __syncthreads();   // sc / pl / vl / row_a are rewritten by the next chunk
+    };
+
+    int kb = k_begin;
+    for (int it = 0; it < n_it - 1; it++) {
+        fetch(nxt, sl_nxt);                                         // chunk it+1: in flight underneath chunk it
+        lookup(sl_nxt, kb + 2 * QS_ATT_CHUNK);                      // table entries of chunk it+2 (clamped)
+        process(cur, kb, false);
+        cur = nxt;
+        kb += QS_ATT_CHUNK;
     }
+    process(cur, kb, true);
     QS_STAMP(4);
     // ---- partial of this split -> workspace: ws_o [T, nq, n_splits, D], ws_ml [T, nq, n_splits, 2]
     // lane holds rows 4*g4 + reg, columns wave*32 + {0,16} + c16

@@ -29,13 +29,13 @@ ATTN_CHUNK = 128  # keys per context split of the attention kernel (QS_ATT_CHUNK
 
 
 def n_splits_for(ctx: int, n_groups: int = 0) -> int:
-    """Context splits of the attention kernel: enough 128-key chunks for the longest context, and at least enough
-    workgroups (n_groups = sequences x kv heads x row blocks) to occupy the 256 CUs; the kernel shrinks the chunk
-    to ceil(ctx / n_splits) for shorter contexts."""
-    need = max(1, (ctx + ATTN_CHUNK - 1) // ATTN_CHUNK)
+    """Context splits of the attention kernel.  Decode (n_groups = sequences x kv heads x row blocks > 0): enough
+    workgroups to occupy the 256 CUs (8 at batch 4 -- measured best: 6 and 12+ are slower), independent of the context
+    length: a split longer than 128 keys is walked in 128-key chunks inside the kernel, so the partials the next launch
+    merges do not grow with the context.  Prefill-sized queries (n_groups = 0) fill the chip with row blocks: 1."""
     if n_groups > 0:
-        need = max(need, min(16, (256 + n_groups - 1) // n_groups))
-    return need
+        return max(1, min(16, (256 + n_groups - 1) // n_groups))
+    return 1
 
 
 class QSpecEngine:

@@ -593,7 +593,8 @@ def test_rope_and_cache_write_bit_exact(ops, oracle):
 
 
 @pytest.mark.parametrize("ctx_lens,q_len", [([37, 128, 129, 500], 1), ([37, 130, 260, 515], 4), ([700], 6), ([5, 9], 4)])
-def test_paged_attention_within_1e3(ops, oracle, ctx_lens, q_len):
+@pytest.mark.parametrize("few_splits", [False, True])
+def test_paged_attention_within_1e3(ops, oracle, ctx_lens, q_len, few_splits):
     rng = np.random.default_rng(sum(ctx_lens) + q_len)
     nq, nkv, d, bs = 32, 8, 128, 16
     n_seqs = len(ctx_lens)
@@ -605,7 +606,8 @@ def test_paged_attention_within_1e3(ops, oracle, ctx_lens, q_len):
     ctx = np.array(ctx_lens, np.int32)
     scale = d ** -0.5
     ref = oracle.paged_attention(qkv[:, : nq * d], kc, vc, bt, ctx, q_start, scale)
-    n_splits = (max(ctx_lens) + 127) // 128 + 1
+    # few_splits: splits longer than 128 keys -> the kernel's inner chunk loop with the running softmax
+    n_splits = (1 if max(ctx_lens) < 600 else 2) if few_splits else (max(ctx_lens) + 127) // 128 + 1
     ws = torch.zeros(ops.paged_attention_workspace_bytes(T, nq, d, n_splits), dtype=torch.uint8, device=DEV)
     out = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
     ops.paged_attention(dev(qkv), row, dev(kc), dev(vc), dev(bt), dev(ctx), dev(q_start), T, q_len, nq, scale,
@@ -636,7 +638,7 @@ def test_paged_attention_generic_head_size_within_1e3(ops, oracle, ctx_lens, q_l
 
 
 @pytest.mark.parametrize("ctx_lens,q_len,n_splits", [([37, 128, 129, 500], 1, 8), ([37, 130, 260, 515], 4, 5),
-                                                     ([1500], 2, 12), ([5, 9], 4, 3)])
+                                                     ([1500], 2, 12), ([5, 9], 4, 3), ([1500, 3000], 1, 4)])
 def test_heads_hadamard_merged_equals_attention_merge_then_hadamard(ops, oracle, ctx_lens, q_len, n_splits):
     """Split merge moved from the attention kernel into the head-Hadamard launch: bit-identical outputs (int4 bytes,
     scales, fp16 rows) to the attention kernel merging its own splits followed by the plain head Hadamard."""
