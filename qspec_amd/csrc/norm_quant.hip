@@ -68,27 +68,49 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
     const int row = blockIdx.x, j = threadIdx.x;
     const f16* xr = x + (size_t)row * H;
     float v[NI][4];
+    // every load of the row first, unconditionally; the (uniform) choice between plain / delta / K-slice-partial
+    // input then selects among values, not among loads: a load behind a branch costs its own round trip (hipcc waits
+    // vmcnt(0) at the join), and with NI trips that was NI serialized round trips
+    f16x4 xa[NI], da[NI];
+    const f16* dsrc = delta ? delta : x;   // dummy re-read of x when there is no delta
 #pragma unroll
     for (int it = 0; it < NI; it++) {
-        f16x4 a = *reinterpret_cast<const f16x4*>(xr + it * 1024 + 4 * j);
-        if (part) {
-            // delta arrives as S raw fp32 K-slice sums of a W4A16 projection (gemm_stream.hip, SEPI_PARTIAL):
-            // delta = h((p_0 + p_1 + ...) * f(sw)), the expression of w4a16_partial_finish_kernel
+        xa[it] = *reinterpret_cast<const f16x4*>(xr + it * 1024 + 4 * j);
+        da[it] = *reinterpret_cast<const f16x4*>(dsrc + (size_t)row * H + it * 1024 + 4 * j);
+    }
+    if (part) {
+        // delta arrives as S raw fp32 K-slice sums of a W4A16 projection (gemm_stream.hip, SEPI_PARTIAL):
+        // delta = h((p_0 + p_1 + ...) * f(sw)), the expression of w4a16_partial_finish_kernel
+        f32x4 sum[NI];
+        f16x4 w4[NI];
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
             const size_t col = (size_t)it * 1024 + 4 * j;
-            f32x4 sum = *reinterpret_cast<const f32x4*>(part + (size_t)row * H + col);
-            for (int s2 = 1; s2 < S; s2++) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(part + (size_t)s2 * pstride + (size_t)row * H + col);
+            sum[it] = *reinterpret_cast<const f32x4*>(part + (size_t)row * H + col);
+            w4[it] = *reinterpret_cast<const f16x4*>(pws + col);
+        }
+        for (int s2 = 1; s2 < S; s2++) {
+            f32x4 t[NI];
 #pragma unroll
-                for (int c = 0; c < 4; c++) sum[c] = sum[c] + t[c];
-            }
-            const f16x4 w4 = *reinterpret_cast<const f16x4*>(pws + col);
+            for (int it = 0; it < NI; it++)
+                t[it] = *reinterpret_cast<const f32x4*>(part + (size_t)s2 * pstride + (size_t)row * H + (size_t)it * 1024 + 4 * j);
 #pragma unroll
-            for (int c = 0; c < 4; c++) a[c] = f2h(h2f(a[c]) + h2f(f2h(sum[c] * h2f(w4[c]))));
-            if (hidden_out) *reinterpret_cast<f16x4*>(hidden_out + (size_t)row * H + it * 1024 + 4 * j) = a;
-        } else if (delta) {
-            f16x4 b = *reinterpret_cast<const f16x4*>(delta + (size_t)row * H + it * 1024 + 4 * j);
+            for (int it = 0; it < NI; it++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) a[c] = f2h(h2f(a[c]) + h2f(b[c]));
+                for (int c = 0; c < 4; c++) sum[it][c] = sum[it][c] + t[it][c];
+        }
+#pragma unroll
+        for (int it = 0; it < NI; it++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) da[it][c] = f2h(sum[it][c] * h2f(w4[it][c]));
+    }
+    const bool has_delta = part != nullptr || delta != nullptr;
+#pragma unroll
+    for (int it = 0; it < NI; it++) {
+        f16x4 a = xa[it];
+        if (has_delta) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) a[c] = f2h(h2f(a[c]) + h2f(da[it][c]));
             if (hidden_out) *reinterpret_cast<f16x4*>(hidden_out + (size_t)row * H + it * 1024 + 4 * j) = a;
         }
 #pragma unroll
