@@ -490,14 +490,14 @@ int silu_mul(const f16* gate_up, f16* out, int T, int I, hipStream_t st) {
 //   draft: row-absmax int4 of z (index i*P + j); verify: fp16 z.
 // One 256-thread workgroup per token.  LDS: y fp16 [K][P], z fp16 [K][P], hadK fp32 [K][K].
 #define QS_SMH_THREADS 1024
-template <int EPL, int KH>  // EPL = elements per lane in the FWHT phase = P / 64; KH = K if specialised, else 0
+template <int EPL, int KH, bool PREACT>  // EPL = elements per lane in the FWHT phase = P / 64; KH = K if specialised, else 0
 __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const f16* __restrict__ gate_up,
                                                                             const f16* __restrict__ hadK,
                                                                             f16* __restrict__ out16,
                                                                             int8_t* __restrict__ q,
                                                                             f16* __restrict__ scale, float had_scale,
-                                                                            float clip, int I, int K,
-                                                                            int pre_activated) {
+                                                                            float clip, int I, int K) {
+    constexpr bool pre_activated = PREACT;   // the input is already g = silu(gate)*up, [T, I] (gate_up GEMM epilogue)
     constexpr int P = EPL * 64;
     constexpr int NT = QS_SMH_THREADS, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -515,10 +515,30 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
 
     // phase A: one chunk of P elements per wave trip (a token's 14336 elements keep 16 waves = 4 per SIMD busy:
     // this kernel is VALU bound -- correctly rounded fp32 divisions in SiLU and in the quantiser)
-    for (int c = wave; c < K; c += NW) {
+    // pre-activated input with 16-byte lanes (the engine's path): the loads of a wave's first two trips (all of them
+    // for K <= 32) are issued before the first transform -- one round trip to the cold activations instead of two
+    constexpr bool PF = PREACT && EPL >= 8;
+    constexpr int NB8 = EPL >= 8 ? EPL / 8 : 1;
+    f16x8 pre8[2][NB8];
+    if (PF) {
+#pragma unroll
+        for (int tr = 0; tr < 2; tr++)
+#pragma unroll
+            for (int b = 0; b < NB8; b++)
+                pre8[tr][b] = *reinterpret_cast<const f16x8*>(up + min(wave + tr * NW, K - 1) * P + lane * EPL + 8 * b);
+    }
+    int trip = 0;
+    for (int c = wave; c < K; c += NW, trip++) {
         float v[EPL];
         const int e0 = c * P + lane * EPL;
-        if (pre_activated) {
+        if (PF && trip < 2) {
+#pragma unroll
+            for (int b = 0; b < NB8; b++) {
+                const f16x8 u8 = trip == 0 ? pre8[0][b] : pre8[1][b];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[8 * b + i] = h2f(u8[i]);
+            }
+        } else if (pre_activated) {
             if (EPL >= 8) {
 #pragma unroll
                 for (int b = 0; b < EPL / 8; b++) {
@@ -709,11 +729,16 @@ int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t*
     if (lds > 160 * 1024 - 64) return -2;
 #define QS_SMH2(EPLV, KHV)                                                                                      \
     {                                                                                                            \
+        if (pre_activated) QS_SMH3(EPLV, KHV, true)                                                              \
+        QS_SMH3(EPLV, KHV, false)                                                                                \
+    }
+#define QS_SMH3(EPLV, KHV, PAV)                                                                                 \
+    {                                                                                                            \
         if (lds > 64 * 1024)                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&silu_mul_hadamard_kernel<EPLV, KHV>),       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&silu_mul_hadamard_kernel<EPLV, KHV, PAV>),  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-        hipLaunchKernelGGL((silu_mul_hadamard_kernel<EPLV, KHV>), dim3(T), dim3(QS_SMH_THREADS), lds, st, gate_up, hadK, \
-                           out_f16, q, scale, had_scale, clip, I, K, pre_activated);                             \
+        hipLaunchKernelGGL((silu_mul_hadamard_kernel<EPLV, KHV, PAV>), dim3(T), dim3(QS_SMH_THREADS), lds, st, gate_up, \
+                           hadK, out_f16, q, scale, had_scale, clip, I, K);                                      \
         return 0;                                                                                                \
     }
 #define QS_SMH(EPLV)                                                                                            \
@@ -726,6 +751,7 @@ int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t*
     QS_SMH(2) QS_SMH(4) QS_SMH(8) QS_SMH(16) QS_SMH(32)
 #undef QS_SMH
 #undef QS_SMH2
+#undef QS_SMH3
     return -1;
 }
 
