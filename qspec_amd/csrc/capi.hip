@@ -39,6 +39,16 @@ static bool use_stream() {
     }
     return v == 1;
 }
+// smallest M routed to the M-tiled W4A16 kernel (gemm_tiled.hip); QSPEC_TILED_MIN_M overrides (0 disables)
+static int tiled_min_m() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("QSPEC_TILED_MIN_M");
+        v = e ? atoi(e) : 33;
+        if (v <= 0) v = 1 << 30;
+    }
+    return v;
+}
 
 extern "C" {
 
@@ -186,6 +196,10 @@ int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* 
         if (rc == 0) rc = qspec::gemm_w4a16_partial_finish(part, CH(ws), H(out), M, N, S, ST);
         return finish(op, rc);
     }
+    if (!bias && M >= tiled_min_m() && qspec::gemm_w4a16_tiled_supported(M, N, K))   // prefill-sized M: M-tiled kernel
+        return finish(op, qspec::gemm_w4a16_tiled(CH(x), wq, CH(ws), H(out), M, N, K,
+                                                  workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 8192) : nullptr,
+                                                  workspace ? qspec::gemm_w4a16_ws_bytes() - 8192 : 0, ST));
     return finish(op, qspec::gemm_w4a16(CH(x), wq, CH(ws), CH(bias), H(out), M, N, K, workspace, ST));
 }
 int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, int M, int N, int K, void* stream) {

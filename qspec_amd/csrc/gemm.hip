@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void gemm_w4a16_kernel(const f16* __restrict__
 // K blocks are combined by the last workgroup to arrive: fp32 partial tiles in the workspace, summed in block
 // order (deterministic), agent-scope release/acquire around a ticket counter that every call leaves at zero.
 #define QS_W16_CNT_SLOTS 2048
-#define QS_W16_PART_BYTES (8u * 1024u * 1024u)
+#define QS_W16_PART_BYTES (32u * 1024u * 1024u)
 template <int MT, int EPI>
 __global__ __launch_bounds__(256) void gemm_w4a16_2d_kernel(const f16* __restrict__ x, const int8_t* __restrict__ wq,
                                                              const f16* __restrict__ ws, const f16* __restrict__ bias,

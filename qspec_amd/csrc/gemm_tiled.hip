@@ -1,0 +1,233 @@
+// W4A16 GEMM for prefill-sized M (prompt pass, verify pass of large batches): matrix-core bound, M-tiled.
+//
+//   out[m,n] = h( (sum_k f(x[m,k]) * w[n,k]) * f(sw[n]) ),  fp32 accumulate  (bitblas.Matmul, quarot_nn/linear.py:102-124)
+//
+// over the same packed int4 buffer as every other GEMM of the engine (no dequantised copy, no library GEMM).
+//   * Workgroup = 4 waves, tile = (32 * MT) tokens x 128 weight rows; wave w owns weight rows 32w..32w+31 against
+//     ALL the tile's tokens, so every packed dword is dequantised exactly once per token block
+//     (v_mfma_f32_32x32x16_f16: 4 MFMAs of MT token tiles per 16 packed bytes -> the 40 VALU of the dequantiser
+//     ride under 16 * MT matrix instructions).
+//   * Weights HBM -> VGPR, 16 B per lane (lane = weight row + 32 * k-group), 8 K steps (8 KiB per wave) in flight with
+//     the refill-behind-use pipeline of gemm_stream.hip; no load sits behind a branch.
+//   * Activations: [32 MT x 256 k] stages through LDS (coalesced 16-byte loads, chunks XOR-swizzled by the row), double
+//     buffered: the loads of stage p+1 are issued before stage p is consumed.
+//   * grid = (N / 128, ceil(M / (32 MT))); MT in {1, 2, 3, 4} chosen so that the token blocks cover M with little
+//     padding (192 = 2 x 96, 512 = 4 x 128).
+#include "common.cuh"
+#include "kernels.h"
+#include <stdlib.h>
+
+namespace qspec {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f16x8 tdequant_s4x8(u32 p) {   // = gemm.hip:dequant_s4x8 (k order 0,4,1,5,2,6,3,7)
+    p ^= 0x88888888u;
+    const u32 q = p >> 8;
+    const u32 r0 = (p & 0x000F000Fu) | 0x64006400u, r1 = (p & 0x00F000F0u) | 0x64006400u;
+    const u32 r2 = (q & 0x000F000Fu) | 0x64006400u, r3 = (q & 0x00F000F0u) | 0x64006400u;
+    const f16x2 c1032 = {(f16)1032.0f, (f16)1032.0f}, c16 = {(f16)0.0625f, (f16)0.0625f}, c72 = {(f16)72.0f, (f16)72.0f};
+    const f16x2 h0 = __builtin_bit_cast(f16x2, r0) - c1032;
+    const f16x2 h1 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, r1), c16, -c72);
+    const f16x2 h2 = __builtin_bit_cast(f16x2, r2) - c1032;
+    const f16x2 h3 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, r3), c16, -c72);
+    return f16x8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+}
+__device__ __forceinline__ f16x8 tshuffle_act8(u32x4 a) {  // 8 consecutive fp16 -> order 0,4,1,5,2,6,3,7
+    u32x4 o;
+    o[0] = __builtin_amdgcn_perm(a[2], a[0], 0x05040100u);
+    o[1] = __builtin_amdgcn_perm(a[2], a[0], 0x07060302u);
+    o[2] = __builtin_amdgcn_perm(a[3], a[1], 0x05040100u);
+    o[3] = __builtin_amdgcn_perm(a[3], a[1], 0x07060302u);
+    return __builtin_bit_cast(f16x8, o);
+}
+
+#define QS_T_STAGE_K 128                    // k per activation stage = 2 weight steps of 64 k
+
+// RING = weight steps (64 k each, 16 B per lane) in flight per wave: 8 (K % 512 == 0) or 4 (K % 256 == 0).
+template <int MT, int RING>
+__global__ __launch_bounds__(256) void gemm_w4a16_tiled_kernel(const f16* __restrict__ x, const uint8_t* __restrict__ wq,
+                                                                const f16* __restrict__ ws, f16* __restrict__ out,
+                                                                float* __restrict__ part, int M, int N, int K, int Ks) {
+    constexpr int BM = 32 * MT;
+    constexpr int ROWB = QS_T_STAGE_K * 2;                 // bytes of one token row in a stage (256)
+    constexpr int CPR = ROWB / 16;                          // 16-byte chunks per row (16)
+    constexpr int LPT = BM * CPR / 256;                     // activation chunks per thread and stage (2 * MT)
+    constexpr int NS = RING / 2;                            // stages per ring round
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][BM][256 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 31, kg = lane >> 5;
+    const int n0 = blockIdx.x * 128 + wave * 32, m0 = blockIdx.y * BM;
+    const int Kb = K >> 1;
+    const int nrounds = Ks / (64 * RING);                  // this workgroup's K slice: [blockIdx.z * Ks, + Ks)
+    const int k0 = blockIdx.z * Ks;
+    const uint8_t* wrow = wq + (size_t)(n0 + nl) * Kb + (k0 >> 1) + kg * 16;     // step s: + 32 * s bytes (64 k)
+    x += k0;
+
+    // activation stage: coalesced 16-byte loads, stored k-shuffled (order of the dequantiser) and chunk-swizzled
+    u32x4 areg[LPT];
+    auto a_load = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < LPT; i++) {
+            const int cidx = tid + i * 256, row = cidx / CPR, q = cidx % CPR;
+            const int m = min(m0 + row, M - 1);           // rows beyond M repeat the last row (never stored)
+            areg[i] = *reinterpret_cast<const u32x4*>(x + (size_t)m * K + (size_t)stage * QS_T_STAGE_K + q * 8);
+        }
+    };
+    auto a_store = [&](int buf) {
+        unsigned char* b = smem + (size_t)buf * BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < LPT; i++) {
+            const int cidx = tid + i * 256, row = cidx / CPR, q = cidx % CPR;
+            *reinterpret_cast<f16x8*>(b + (size_t)row * ROWB + ((q ^ (row & 15)) << 4)) = tshuffle_act8(areg[i]);
+        }
+    };
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[mt][i] = 0.0f;
+
+    a_load(0);
+    u32x4 w[RING];
+#pragma unroll
+    for (int u = 0; u < RING; u++) w[u] = *reinterpret_cast<const u32x4*>(wrow + (size_t)u * 32);
+    a_store(0);
+    __syncthreads();
+
+    // one stage = 2 weight steps; lane (weight row nl, k-group kg), step j, dword dd <-> k = 64 j + 32 kg + 8 dd
+    auto stage_compute = [&](int buf, const u32x4& w0, const u32x4& w1) {
+        const unsigned char* b = smem + (size_t)buf * BM * ROWB;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+#pragma unroll
+            for (int dd = 0; dd < 4; dd++) {
+                const f16x8 bf = tdequant_s4x8(j == 0 ? w0[dd] : w1[dd]);
+                const int q = j * 8 + kg * 4 + dd;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const int row = mt * 32 + nl;
+                    const f16x8 av = *reinterpret_cast<const f16x8*>(b + (size_t)row * ROWB + ((q ^ (row & 15)) << 4));
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bf, acc[mt], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // the last round is peeled so that no weight refill sits behind a branch
+    for (int r = 0; r < nrounds - 1; r++) {
+        const uint8_t* wnext = wrow + (size_t)(r + 1) * RING * 32;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            a_load(r * NS + s + 1);                       // next stage's activations fly under this stage's MFMAs
+            stage_compute(s & 1, w[2 * s], w[2 * s + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            w[2 * s] = *reinterpret_cast<const u32x4*>(wnext + (size_t)(2 * s) * 32);
+            w[2 * s + 1] = *reinterpret_cast<const u32x4*>(wnext + (size_t)(2 * s + 1) * 32);
+            __builtin_amdgcn_sched_barrier(0);
+            a_store((s & 1) ^ 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        if (s + 1 < NS) a_load((nrounds - 1) * NS + s + 1);
+        stage_compute(s & 1, w[2 * s], w[2 * s + 1]);
+        if (s + 1 < NS) {
+            a_store((s & 1) ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: 32x32 tile: lane holds column n = nl, rows (i / 4) * 8 + kg * 4 + (i % 4)
+    if (part) {   // K slices: raw fp32 sums, [slice][M][N]; scaled and rounded by the finish launch (or the next norm)
+        float* pz = part + (size_t)blockIdx.z * M * N;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int m = m0 + mt * 32 + (i >> 2) * 8 + kg * 4 + (i & 3);
+                if (m < M) pz[(size_t)m * N + n0 + nl] = acc[mt][i];
+            }
+        return;
+    }
+    const float swn = h2f(ws[n0 + nl]);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int m = m0 + mt * 32 + (i >> 2) * 8 + kg * 4 + (i & 3);
+            if (m < M) out[(size_t)m * N + n0 + nl] = f2h(acc[mt][i] * swn);
+        }
+}
+
+bool gemm_w4a16_tiled_supported(int M, int N, int K) { return M >= 1 && N % 128 == 0 && K % 256 == 0 && K >= 512; }
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Launch plan: token block 32 * MT and K slices S, by a small cost model fitted to a sweep on MI355X
+// (scripts/sweep_tiled.sh; within ~10 % of the best plan on every swept shape).  Wide layers fill the chip with
+// (N / 128) x token blocks; narrow ones (o_proj, down_proj at a few hundred tokens) would leave most CUs idle, so they
+// take smaller token blocks and/or K slices whose raw sums go through `part` ([S][M][N] fp32) and one finish launch.
+void gemm_w4a16_tiled_plan(int M, int N, int K, size_t part_bytes, int* MT_out, int* S_out) {
+    static const int force_mt = env_int("QSPEC_TILED_MT", 0), force_s = env_int("QSPEC_TILED_S", 0);
+    const int unit = K % 512 == 0 ? 512 : 256;            // one ring round
+    double best = 1e30;
+    int bmt = 1, bs = 1;
+    for (int mt = 1; mt <= 4; mt++) {
+        if (force_mt >= 1 && force_mt <= 4 && mt != force_mt) continue;
+        const int mb = (M + 32 * mt - 1) / (32 * mt);
+        for (int sl = 1; sl <= 8; sl++) {
+            if (K % (sl * unit)) continue;
+            if (sl > 1 && (size_t)sl * M * N * sizeof(float) > part_bytes) continue;
+            if (force_s >= 1 && sl != force_s && K % (force_s * unit) == 0 &&
+                (size_t)force_s * M * N * sizeof(float) <= part_bytes)
+                continue;
+            const double wgs = (double)(N / 128) * mb * sl;
+            const double steps = (double)(K / sl / 64);
+            const double rounds = (double)(((long long)wgs + 511) / 512);            // two workgroups per CU
+            const double share = wgs > 256 ? 1.0 : 0.62;                              // a lone workgroup runs faster
+            const double comp = rounds * steps * (0.06 + 0.265 * mt) * share;         // us
+            const double traffic = ((double)N * K / 2 * mb) / 5.5e6;                  // weight re-reads through L2
+            double t = (comp > traffic ? comp : traffic) + 4.0;
+            if (sl > 1) t += 1.5 + (double)sl * M * N * 8 / 5e6;                      // partial sums out and back in
+            if (t < best) { best = t; bmt = mt; bs = sl; }
+        }
+    }
+    *MT_out = bmt;
+    *S_out = bs;
+}
+
+int gemm_w4a16_tiled(const f16* x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K, float* part,
+                     size_t part_bytes, hipStream_t st) {
+    if (!gemm_w4a16_tiled_supported(M, N, K)) return -1;
+    int MT, S;
+    gemm_w4a16_tiled_plan(M, N, K, part ? part_bytes : 0, &MT, &S);
+    const dim3 grid(N / 128, (M + 32 * MT - 1) / (32 * MT), S);
+    const size_t lds = (size_t)2 * 32 * MT * (QS_T_STAGE_K * 2);   // <= 64 KiB
+    const uint8_t* w8 = reinterpret_cast<const uint8_t*>(wq);
+    const bool r8 = K % 512 == 0;
+    float* p = S > 1 ? part : nullptr;
+    const int Ks = K / S;
+#define QS_TILED(MTV)                                                                                                   \
+    case MTV:                                                                                                           \
+        if (r8)                                                                                                         \
+            hipLaunchKernelGGL((gemm_w4a16_tiled_kernel<MTV, 8>), grid, dim3(256), lds, st, x, w8, ws, out, p, M, N, K, \
+                               Ks);                                                                                     \
+        else                                                                                                            \
+            hipLaunchKernelGGL((gemm_w4a16_tiled_kernel<MTV, 4>), grid, dim3(256), lds, st, x, w8, ws, out, p, M, N, K, \
+                               Ks);                                                                                     \
+        break;
+    switch (MT) {
+        QS_TILED(1) QS_TILED(2) QS_TILED(3) QS_TILED(4)
+        default: return -1;
+    }
+#undef QS_TILED
+    if (S > 1) return gemm_w4a16_partial_finish(part, ws, out, M, N, S, st);
+    return 0;
+}
+
+}  // namespace qspec

@@ -153,20 +153,13 @@ class QuarotLlamaForCausalLM:
                            .to(torch.float16))
         return self
 
-    # prefill-sized M: dequantise the tile once and use the library GEMM (not the decode hot path)
+    # M above which the fused GEMM epilogues (QKV+RoPE+KV write, gate_up+SiLU) give way to plain GEMM + separate kernels
     BIG_M = 64
     FUSE_LN = True   # draft pass: LN in the GEMM prologue (False = separate LN kernel; the two are bit-identical)
 
     def _w4a16(self, x, lin, out):
-        if x.shape[0] <= self.BIG_M:
-            return ops.w4a16_linear(x, lin.weight, lin._scales(), out)
-        key = tuple(lin.weight.shape)
-        if not hasattr(self, "_dq"):
-            self._dq = {}
-        if key not in self._dq:
-            self._dq[key] = torch.empty(key[0], key[1] * 2, dtype=torch.float16, device=self.device)
-        wd = ops.dequant_w4(lin.weight, lin._scales(), self._dq[key])
-        return torch.matmul(x, wd.t(), out=out)
+        # every M reads the packed int4 buffer: streaming kernel (M <= 16), M-tiled kernel (prefill-sized M)
+        return ops.w4a16_linear(x, lin.weight, lin._scales(), out)
 
     def _add_norm_fp16(self, normed, hidden, delta, eps):
         """hidden += delta; normed = LN(hidden).  delta: fp16 tensor, None, or ("partial", part, w_scale, S) = the raw

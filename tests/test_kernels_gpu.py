@@ -851,3 +851,32 @@ def test_tensor_parallel_engine_two_ranks():
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "tp_check.py")],
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert "TP_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+# ------------------------------------------------------------------ W4A16, prefill-sized M (M-tiled kernel)
+
+@pytest.mark.parametrize("M,N,K", [(33, 256, 512), (64, 128, 768), (96, 384, 1024), (192, 6144, 4096),
+                                   (200, 4096, 4096), (129, 256, 11008), (512, 512, 14336), (1000, 128, 2048)])
+def test_w4a16_tiled_within_1e3(ops, oracle, M, N, K):
+    """Prompt-pass / large-batch verify GEMM: tiles of 32..128 tokens x 128 weight rows over the packed int4 buffer
+    (both ring depths: K % 512 == 0 and K % 256 == 0; ragged last token block)."""
+    rng = np.random.default_rng(M + N + K)
+    x = rand_hidden(rng, M, K)
+    wq = oracle.pack_i4(rand_w4(rng, N, K))
+    ws = (rng.random(N) * 0.002 + 0.0005).astype(np.float16)
+    out = torch.full((M + 1, N), 7.0, dtype=torch.float16, device=DEV)   # guard row: nothing beyond M is written
+    ops.w4a16_linear(dev(x), dev(wq), dev(ws), out[:M])
+    assert_close_1e3(host(out[:M]), oracle.gemm_w4a16(x, wq, ws))
+    assert torch.all(out[M] == 7.0)
+
+
+def test_w4a16_tiled_exact_on_integer_data(ops, oracle):
+    """Integer activations: every fp32 partial sum is exact, so a k-permutation / lane-map error is a bit mismatch."""
+    rng = np.random.default_rng(55)
+    M, N, K = 160, 256, 1024
+    x = rng.integers(-4, 5, (M, K)).astype(np.float16)
+    wq = oracle.pack_i4(rand_w4(rng, N, K))
+    ws = np.ones(N, np.float16)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.w4a16_linear(dev(x), dev(wq), dev(ws), out)
+    assert np.array_equal(bits(host(out)), bits(oracle.gemm_w4a16(x, wq, ws)))
