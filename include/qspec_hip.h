@@ -63,7 +63,7 @@ int qspec_fuse_sym_quant(const qspec_half* x, qspec_half* scale, int8_t* q, floa
 
 /* fast_hadamard_transform_cuda.faster_fast_hadamard_transform(x, scale, out) / fast_hadamard_transform(x, scale)
  *   third-party/fast-hadamard-transform/csrc/fast_hadamard_transform.cpp:69-154, ..._cuda.cu:124-198.
- *   rows of length n (power of two, 2..32768); out = h(WHT(x) * scale). */
+ *   rows of length n (power of two, 1..32768; n = 1 only scales and rounds); out = h(WHT(x) * scale). */
 int qspec_fast_hadamard_transform(const qspec_half* x, float scale, qspec_half* out, int64_t rows, int n,
                                   void* stream);
 
@@ -78,6 +78,14 @@ int qspec_hadamard_mix(const qspec_half* y, const qspec_half* hadK, qspec_half* 
  *   q != NULL: int4 rows in q [tokens, heads*head_dim/2] + scale[tokens]  (draft; out_f16 unused) */
 int qspec_heads_hadamard(const qspec_half* attn, qspec_half* out_f16, int8_t* q, qspec_half* scale, float had_scale,
                          float clip_ratio, int tokens, int heads, int head_dim, void* stream);
+
+/* The same head transform for head counts K * 2^p whose get_hadK factor is a table (Llama-2-13B: 40 heads = had40;
+ * matmul_hadU_cuda on rows of `heads`, quarot/functional/hadamard.py:94-124, inside the transposes of
+ * quarot_llama.py:231-234).  attn, out [tokens, heads, head_dim]; hadK [K, K] fp16; heads = K * 2^p, K in 2..172.
+ *   y = h(WHT over the 2^p axis * had_scale);  out[i*2^p + p] = h(sum_k hadK[i,k] * y[k*2^p + p]), fp32 in k order.
+ * The Quantizer behind it is qspec_fuse_sym_quant. */
+int qspec_heads_hadamard_mix(const qspec_half* attn, const qspec_half* hadK, qspec_half* out, float had_scale, int tokens,
+                             int heads, int head_dim, int K, void* stream);
 
 /* `self.act_fn(gate) * up_proj` on the fused gate_up output (quarot_llama.py:279-284): up = [:, :I], gate = [:, I:];
  * out [tokens, I] = h(h(silu(gate)) * up).  Stand-alone form of the first stage of qspec_silu_mul_hadamard. */

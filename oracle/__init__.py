@@ -143,17 +143,18 @@ def rsqrt_scale(n):
     return float(np.float32(1.0) / np.sqrt(np.float32(n)))
 
 
-def heads_hadamard(attn_out, num_heads, scale=None):
+def heads_hadamard(attn_out, num_heads, scale=None, hadK=None, K=1):
     """o_proj online Hadamard over the head axis (quarot_llama.py:231-234):
-    [T, heads*d] viewed [T,heads,d] -> transpose -> rows of `heads` -> FWHT*1/sqrt(heads)
-    -> transpose back -> [T, heads*d]."""
+    [T, heads*d] viewed [T,heads,d] -> transpose -> rows of `heads` -> OnlineHadamard(heads) -> transpose back.
+    heads a power of two: FWHT * 1/sqrt(heads); a head count with a table factor (get_hadK(heads) = hadK, K > 1;
+    40 heads = had40): matmul_hadU_cuda on those rows = FWHT over heads/K, then hadK mix (hadamard.py:94-124)."""
     x = _h(attn_out)
     T = x.shape[0]
     d = x.shape[1] // num_heads
     if scale is None:
         scale = rsqrt_scale(num_heads)
     xt = np.ascontiguousarray(x.reshape(T, num_heads, d).transpose(0, 2, 1)).reshape(T * d, num_heads)
-    yt = fwht(xt, scale)
+    yt = fwht(xt, scale) if K == 1 else mlp_hadamard(xt, hadK, K, scale)
     return np.ascontiguousarray(yt.reshape(T, d, num_heads).transpose(0, 2, 1)).reshape(T, num_heads * d)
 
 

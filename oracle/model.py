@@ -15,11 +15,13 @@ import oracle as O
 
 
 class OracleModel:
-    def __init__(self, cfg, layers, embed_tokens, lm_head, had_rem_dim, had_K, cos_sin_cache, block_size):
+    def __init__(self, cfg, layers, embed_tokens, lm_head, had_rem_dim, had_K, cos_sin_cache, block_size,
+                 head_had=None, head_had_K=1):
         """layers: list of dicts {qkv_w,qkv_s,o_w,o_s,gate_up_w,gate_up_s,down_w,down_s} (numpy)."""
         self.cfg, self.layers = cfg, layers
         self.embed_tokens, self.lm_head = embed_tokens, lm_head
         self.had, self.had_K = had_rem_dim, had_K
+        self.head_had, self.head_had_K = head_had, head_had_K      # table factor of get_hadK(num_heads), if any
         self.cs = cos_sin_cache
         self.block_size = block_size
         self.head_scale = O.rsqrt_scale(cfg.num_attention_heads)
@@ -36,7 +38,9 @@ class OracleModel:
                        down_w=c(l.down_proj.weight), down_s=c(l.down_proj.weight_scales).reshape(-1))
                   for l in (m.layers if max_layers is None else m.layers[:max_layers])]
         had = c(m.had_rem_dim) if m.had_rem_dim is not None else None
-        return cls(m.config, layers, c(m.embed_tokens), c(m.lm_head), had, m.had_K, c(m.cos_sin_cache), block_size)
+        hh = c(m.head_had) if getattr(m, "head_had", None) is not None else None
+        return cls(m.config, layers, c(m.embed_tokens), c(m.lm_head), had, m.had_K, c(m.cos_sin_cache), block_size,
+                   hh, getattr(m, "head_had_K", 1))
 
     def _linear(self, x, w, s, w4a4):
         if w4a4:
@@ -65,7 +69,7 @@ class OracleModel:
             v = qkv[:, (nq + nkv) * d:]
             O.reshape_and_cache_flash(kr.reshape(T, nkv, d), v.reshape(T, nkv, d), kc, vc, slot_mapping)
             attn = O.paged_attention(qr, kc, vc, block_tables, ctx_lens, q_start, self.sm_scale)
-            a = O.heads_hadamard(attn, nq, self.head_scale)
+            a = O.heads_hadamard(attn, nq, self.head_scale, self.head_had, self.head_had_K)
             if w4a4:
                 a = O.rowabsmax_quant_i4(a, 1.0)
             o = self._linear(a, L["o_w"], L["o_s"], w4a4)

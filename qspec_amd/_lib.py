@@ -29,6 +29,7 @@ SIGNATURES = {
     "qspec_fast_hadamard_transform": (_i, [_vp, _f, _vp, _i64, _i, _vp]),
     "qspec_hadamard_mix": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_heads_hadamard": (_i, [_vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
+    "qspec_heads_hadamard_mix": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     "qspec_silu_mul": (_i, [_vp, _vp, _i, _i, _vp]),
     "qspec_silu_mul_hadamard": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
     "qspec_mlp_hadamard": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),

@@ -108,7 +108,7 @@ int qspec_fast_hadamard_transform(const qspec_half* x, float scale, qspec_half* 
     if (rows < 0) return fail("%s: rows < 0", op);
     if (rows == 0) return 0;
     NONNULL(op, x); NONNULL(op, out);
-    if (n < 2 || n > 32768 || (n & (n - 1))) return fail("%s: n=%d must be a power of two in [2, 32768]", op, n);
+    if (n < 1 || n > 32768 || (n & (n - 1))) return fail("%s: n=%d must be a power of two in [1, 32768]", op, n);
     if (rows > 2147483647LL) return fail("%s: too many rows", op);
     return finish(op, qspec::fwht(CH(x), scale, H(out), rows, n, ST));
 }
@@ -129,6 +129,15 @@ int qspec_heads_hadamard(const qspec_half* attn, qspec_half* out_f16, int8_t* q,
     NONNULL(op, attn);
     if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
     return finish(op, qspec::heads_hadamard(CH(attn), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, heads, head_dim, ST));
+}
+int qspec_heads_hadamard_mix(const qspec_half* attn, const qspec_half* hadK, qspec_half* out, float had_scale, int tokens,
+                             int heads, int head_dim, int K, void* stream) {
+    const char* op = "qspec_heads_hadamard_mix";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, attn); NONNULL(op, hadK); NONNULL(op, out);
+    if (attn == out) return fail("%s: in-place not supported", op);
+    return finish(op, qspec::heads_hadamard_mix(CH(attn), CH(hadK), H(out), had_scale, tokens, heads, head_dim, K, ST));
 }
 int qspec_silu_mul(const qspec_half* gate_up, qspec_half* out, int tokens, int intermediate, void* stream) {
     const char* op = "qspec_silu_mul";

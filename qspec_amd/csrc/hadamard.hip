@@ -42,8 +42,19 @@ __global__ __launch_bounds__(256) void fwht_kernel(const f16* __restrict__ x, fl
     for (int i = threadIdx.x; i < N; i += blockDim.x) out[base + i] = f2h(v[i] * scale);
 }
 
+// rows of one element (get_hadK(n) with n / K == 1: 12, 20, 28, 36, 40 ... heads): only the scale and the rounding are left
+__global__ __launch_bounds__(256) void scale_round_kernel(const f16* __restrict__ x, float scale, f16* __restrict__ out,
+                                                           int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = f2h(h2f(x[i]) * scale);
+}
+
 int fwht(const f16* x, float scale, f16* out, int64_t rows, int N, hipStream_t st) {
     if (rows == 0) return 0;
+    if (N == 1) {
+        hipLaunchKernelGGL(scale_round_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, scale, out, rows);
+        return 0;
+    }
     if (N < 2 || N > 32768 || (N & (N - 1))) return -1;
     int threads = N / 2 < 64 ? 64 : (N / 2 > 256 ? 256 : N / 2);
     hipLaunchKernelGGL(fwht_kernel, dim3((unsigned)rows), dim3(threads), (size_t)N * sizeof(float), st, x, scale, out, N);
@@ -70,6 +81,56 @@ int hadk_mix(const f16* y, const f16* hadK, f16* out, int T, int K, int M, hipSt
     if (T == 0) return 0;
     if (K < 1 || K > 172) return -1;
     hipLaunchKernelGGL(hadk_mix_kernel, dim3(T), dim3(256), (size_t)K * K * sizeof(float), st, y, hadK, out, K, M);
+    return 0;
+}
+
+// ------------------------------------------------- heads Hadamard, head count K * 2^p with a table factor K > 1
+// (Llama-2-13B: 40 heads = had40; matmul_hadU_cuda on rows of `heads`, quarot/functional/hadamard.py:94-124, between the
+// two transposes of quarot_llama.py:231-234).  attn [T, heads, d], head index h = k * P + p:
+//   y[h, j] = h( WHT_P over p (fp32, increasing stride) * scale );  out[i * P + p, j] = h( sum_k hadK[i, k] * y[k * P + p, j] )
+// One workgroup per token, the token's [heads, d] tile in LDS.  Not a tuned kernel (the configs on the hot path have
+// 32 / 64 heads); it keeps the other head counts on the packed-weight engine.
+__global__ __launch_bounds__(256) void heads_hadamard_mix_kernel(const f16* __restrict__ attn,
+                                                                  const f16* __restrict__ hadK, f16* __restrict__ out,
+                                                                  float scale, int heads, int d, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* v = reinterpret_cast<float*>(smem_raw);          // [heads * d]
+    float* had = v + (size_t)heads * d;                      // [K * K]
+    const int P = heads / K, n = heads * d;
+    const size_t base = (size_t)blockIdx.x * n;
+    for (int i = threadIdx.x; i < n; i += 256) v[i] = h2f(attn[base + i]);
+    for (int i = threadIdx.x; i < K * K; i += 256) had[i] = h2f(hadK[i]);
+    __syncthreads();
+    for (int stride = 1; stride < P; stride <<= 1) {
+        for (int idx = threadIdx.x; idx < (heads / 2) * d; idx += 256) {
+            const int b = idx / d, j = idx - b * d;
+            const int lo = b & (stride - 1), h = ((b - lo) << 1) + lo;
+            const float a = v[h * d + j], c = v[(h + stride) * d + j];
+            v[h * d + j] = a + c;
+            v[(h + stride) * d + j] = a - c;
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += 256) v[i] = h2f(f2h(v[i] * scale));
+    __syncthreads();
+    const int M = P * d;
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        const int i = idx / M, m = idx - i * M;
+        float acc = 0.0f;
+        for (int k = 0; k < K; k++) acc = __builtin_fmaf(had[i * K + k], v[k * M + m], acc);
+        out[base + idx] = f2h(acc);
+    }
+}
+
+int heads_hadamard_mix(const f16* attn, const f16* hadK, f16* out, float had_scale, int T, int heads, int d, int K,
+                       hipStream_t st) {
+    if (T == 0) return 0;
+    if (K < 2 || K > 172 || heads % K) return -1;
+    const int P = heads / K;
+    if (P & (P - 1)) return -1;
+    const size_t lds = ((size_t)heads * d + (size_t)K * K) * sizeof(float);
+    if (lds > 64 * 1024) return -2;
+    hipLaunchKernelGGL(heads_hadamard_mix_kernel, dim3(T), dim3(256), lds, st, attn, hadK, out, had_scale, heads, d, K);
     return 0;
 }
 

@@ -22,6 +22,8 @@ int fwht(const f16* x, float scale, f16* out, int64_t rows, int N, hipStream_t s
 int hadk_mix(const f16* y, const f16* hadK, f16* out, int T, int K, int M, hipStream_t st);
 int heads_hadamard(const f16* attn, f16* out_f16, int8_t* q, f16* scale, float had_scale, float clip, int T,
                    int heads, int d, hipStream_t st);
+int heads_hadamard_mix(const f16* attn, const f16* hadK, f16* out, float had_scale, int T, int heads, int d, int K,
+                       hipStream_t st);
 int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out_f16, int8_t* q, f16* scale,
                          float had_scale, float clip, int T, int heads, int d, hipStream_t st);
 int silu_mul(const f16* gate_up, f16* out, int T, int I, hipStream_t st);

@@ -126,6 +126,8 @@ class QuarotLlamaForCausalLM:
         self.lm_head = torch.zeros(cfg.vocab_size, cfg.hidden_size, dtype=torch.float16, device=device)
         had, self.had_K = hadamard_tables.get_hadK(cfg.intermediate_size)
         self.had_rem_dim = had.to(torch.float16).to(device) if had is not None else None
+        hh, self.head_had_K = hadamard_tables.get_hadK(cfg.num_attention_heads)   # table factor for 12/20/28/40.. heads
+        self.head_had = hh.to(torch.float16).to(device) if hh is not None else None
         self.head_had_scale = float(1.0 / torch.tensor(cfg.num_attention_heads).sqrt())      # hadamard.py:12
         self.mlp_had_scale = float(1.0 / torch.tensor(cfg.intermediate_size).sqrt())         # hadamard.py:13
         self.sm_scale = cfg.head_dim ** -0.5
@@ -178,10 +180,16 @@ class QuarotLlamaForCausalLM:
         cfg = self.config
         nh = cfg.num_attention_heads
         B = md.ctx_lens.numel()
-        merged = self.MERGE_IN_HADAMARD and cfg.head_dim == 128 and nh in (32, 64) and md.n_splits <= 64
+        merged = (self.MERGE_IN_HADAMARD and cfg.head_dim == 128 and nh in (32, 64) and md.n_splits <= 64
+                  and self.head_had_K == 1)
         ops.paged_attention(qkv, row, kc, vc, md.block_tables, md.ctx_lens, md.q_start, T, md.max_q_len, nh,
                             self.sm_scale, md.n_splits, s.attn_ws, None if merged else attn)
-        if merged:
+        if self.head_had_K > 1:   # head count with a table factor (40 heads = had40): generic kernels, then the Quantizer
+            buf = had if had is not None else s.act_buffer_had[:T]
+            ops.heads_hadamard_mix(attn.view(T, nh, cfg.head_dim), self.head_had, self.head_had_K, self.head_had_scale, buf)
+            if q1 is not None:
+                ops.fuse_sym_quant(buf, sc, q1)
+        elif merged:
             ops.heads_hadamard_merged(s.attn_ws, B * md.max_q_len, md.n_splits, T, nh, cfg.head_dim,
                                       self.head_had_scale, out_f16=had, q=q1, scale=sc)
         elif q1 is not None:

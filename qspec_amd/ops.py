@@ -121,6 +121,17 @@ def heads_hadamard(attn, had_scale: float, out_f16=None, q=None, scale=None, cli
           _opt(scale, "scale", _F16), float(had_scale), float(clip_ratio), T, heads, d, _stream())
 
 
+def heads_hadamard_mix(attn, hadK, K: int, had_scale: float, out):
+    """Head transform for head counts K * 2^p with a table factor (matmul_hadU_cuda between the transposes of
+    quarot_llama.py:231-234); attn [T, heads, d], out the same number of elements, fp16."""
+    if attn.dim() != 3:
+        raise RuntimeError("heads_hadamard_mix: attn must be [T, heads, d]")
+    T, heads, d = attn.shape
+    _call("qspec_heads_hadamard_mix", _chk(attn, "attn", _F16), _chk(hadK, "hadK", _F16), _chk(out, "out", _F16),
+          float(had_scale), T, heads, d, K, _stream())
+    return out
+
+
 def silu_mul(gate_up, out):
     """`act_fn(gate) * up` over the fused gate_up row (quarot_llama.py:279-284)."""
     T, two_i = gate_up.shape

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from qspec_amd import ops
 dev = "cuda:0"
+ROT = float(os.environ.get("QSPEC_ROT_BYTES", "600e6"))   # bytes of weight copies rotated over (> 256 MiB = HBM-cold)
 def timeit(fs, reps=3):
     for f in fs: f()
     torch.cuda.synchronize()
@@ -26,7 +27,7 @@ for M in Ms:
     kc = torch.zeros(256, 16, nkv, d, device=dev, dtype=torch.float16); vc = torch.zeros_like(kc)
     slots = torch.arange(M, device=dev, dtype=torch.int64)
     for name, N, K in (("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336)):
-        L = max(2, int(600e6 // (N * K // 2)))
+        L = max(2, int(ROT // (N * K // 2)))
         ws = [torch.randint(-128, 127, (N, K // 2), dtype=torch.int8, device=dev) for _ in range(L)]
         sc = torch.rand(N, device=dev).half() * 0.01
         xq = torch.randint(-128, 127, (M, K // 2), dtype=torch.int8, device=dev); xs = torch.rand(M, device=dev).half()
@@ -51,7 +52,7 @@ cs = torch.randn(8192, 128, device=dev).half(); pos = torch.randint(0, 8192, (M,
 kc = torch.zeros(256, 16, nkv, d, device=dev, dtype=torch.float16); vc = torch.zeros_like(kc)
 slots = torch.arange(M, device=dev, dtype=torch.int64)
 for name, N, K in (("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336)):
-    L = max(2, int(600e6 // (N * K // 2)))
+    L = max(2, int(ROT // (N * K // 2)))
     ws = [torch.randint(-128, 127, (N, K // 2), dtype=torch.int8, device=dev) for _ in range(L)]
     sc = torch.rand(N, device=dev).half() * 0.01
     xx = x[:, :K].contiguous()

@@ -880,3 +880,28 @@ def test_w4a16_tiled_exact_on_integer_data(ops, oracle):
     out = torch.empty(M, N, dtype=torch.float16, device=DEV)
     ops.w4a16_linear(dev(x), dev(wq), dev(ws), out)
     assert np.array_equal(bits(host(out)), bits(oracle.gemm_w4a16(x, wq, ws)))
+
+
+# ------------------------------------------------------------------ head Hadamard for head counts with a table factor
+
+@pytest.mark.parametrize("T,heads,d", [(3, 40, 128), (2, 24, 64), (1, 80, 128), (5, 12, 128)])
+def test_heads_hadamard_mix_bit_exact(ops, oracle, T, heads, d):
+    from qspec_amd import hadamard_tables
+    rng = np.random.default_rng(heads + T)
+    hadK, K = hadamard_tables.get_hadK(heads)
+    assert K > 1
+    x = (rng.standard_normal((T, heads * d))).astype(np.float16)
+    scale = oracle.rsqrt_scale(heads)
+    ref = oracle.heads_hadamard(x, heads, scale, hadK.numpy().astype(np.float16), K)
+    out = torch.empty(T, heads * d, dtype=torch.float16, device=DEV)
+    ops.heads_hadamard_mix(dev(x).view(T, heads, d), hadK.to(torch.float16).to(DEV), K, scale, out)
+    assert np.array_equal(bits(host(out)), bits(ref))
+
+
+def test_fwht_rows_of_one(ops, oracle):
+    """get_hadK(n) with n / K == 1 (12, 20, 28, 40 heads): the FWHT stage only scales and rounds."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1000, 1)).astype(np.float16)
+    out = torch.empty(1000, 1, dtype=torch.float16, device=DEV)
+    ops.faster_fast_hadamard_transform(dev(x), 0.158, out)
+    assert np.array_equal(bits(host(out)), bits(oracle.fwht(x, 0.158)))

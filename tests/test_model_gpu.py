@@ -216,3 +216,47 @@ def test_worker_api(tiny):
             assert not (seen and t != -1)
             seen = seen or t == -1
     assert w.execute_model(None) == []
+
+
+# ------------------------------------------------------------------ the other model families of BASELINE.json's configs
+
+FAMILIES = {
+    # full layer width of the named config, one layer, small vocabulary (the layer shapes are what differs)
+    "tinyllama-1.1b": (2048, 5632, 32, 4, 10000.0),      # head_dim 64 (generic attention), I = had44 (x) H128
+    "llama-2-13b": (5120, 13824, 40, 40, 10000.0),       # 40 heads = had40 on the head axis, I = had108 (x) H128
+    "llama-3-70b": (8192, 28672, 64, 8, 500000.0),       # 64 heads (FWHT-64), I = had28 (x) H1024
+}
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+@pytest.mark.parametrize("w4a4", [True, False])
+def test_model_family_layer_matches_oracle(oracle, family, w4a4):
+    from oracle.model import OracleModel
+    from qspec_amd.model import QuarotLlamaConfig, QuarotLlamaForCausalLM, Scratch
+    H, I, nh, nkv, theta = FAMILIES[family]
+    cfg = QuarotLlamaConfig(H, I, nh, nkv, 1, 1024, 1e-5, theta, 512, family + "-1layer")
+    model = QuarotLlamaForCausalLM(cfg, DEV).init_synthetic(seed=2, lm_head_std=0.05)
+    rng = np.random.default_rng(4)
+    ctx_lens, q_len = ([33, 150], 1) if w4a4 else ([33, 150], 2)
+    inp = make_inputs(model, rng, ctx_lens, q_len)
+    om = OracleModel.from_torch_model(model, 16)
+    kv_np = [(k.copy(), v.copy()) for k, v in inp["kv_np"]]
+    ref = om.forward(inp["ids"], inp["pos"], kv_np, inp["slots"], inp["bt"], inp["ctx"], inp["q_start"], w4a4)
+    s = Scratch(cfg, inp["T"], len(ctx_lens), q_len, inp["n_splits"], DEV)
+    out = model.forward(inp["ids_t"], inp["pos_t"], inp["kv_t"], inp["md"], s, w4a4=w4a4)
+    torch.cuda.synchronize()
+    diff = np.abs(out.cpu().numpy().astype(np.float64) - ref.astype(np.float64))
+    if w4a4:
+        assert np.median(diff) < 1e-3 and np.quantile(diff, 0.99) < 0.1, (np.median(diff), np.quantile(diff, 0.99))
+        k_hip = inp["kv_t"][0][0].cpu().numpy()
+        assert np.array_equal(k_hip.view(np.uint16), kv_np[0][0].view(np.uint16))
+    else:
+        assert diff.max() < 2e-2 and np.median(diff) < 1e-3, (np.median(diff), diff.max())
+    # and the reference-order module-wise path gives the same bits as the fused one
+    kv_b = [(torch.from_numpy(k).to(DEV), torch.from_numpy(v).to(DEV)) for k, v in inp["kv_np"]]
+    b = model.forward_modulewise(inp["ids_t"], inp["pos_t"], kv_b, inp["md"], w4a4=w4a4)
+    torch.cuda.synchronize()
+    if w4a4:
+        assert torch.equal(out.view(torch.int16), b.view(torch.int16))
+    else:
+        assert (out.float() - b.float()).abs().max().item() < 2e-2
