@@ -52,8 +52,16 @@ def dist_setup(n):
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if world > 1:
         import torch.distributed as dist
+        # QSPEC_BENCH_BACKEND=gloo: rehearsal of the N > 1 harness on a box with fewer GPUs than ranks (ranks share
+        # devices round-robin, collectives staged through the host); the measured configuration is always RCCL
+        backend = os.environ.get("QSPEC_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     assert world == n, f"--gpus {n} but WORLD_SIZE={world}: launch with torch.distributed.run"
     return rank, world, local
 
@@ -250,7 +258,7 @@ def main():
         dt = time.perf_counter() - t0
         if world > 1:
             import torch.distributed as dist
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         acc, emit, draft = (int(v) for v in (eng.sampler.counters - c0).tolist())
@@ -282,7 +290,7 @@ def main():
                                     "ms_per_step": round(dt2 / args.natural_steps * 1e3, 4),
                                     "draft_acceptance_rate": round(acc2 / draft2, 4) if draft2 else None,
                                     "system_efficiency": round(emit2 / ((draft2 // args.k) * (args.k + 1)), 4) if draft2 else None}
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline:   # the draft pass is replicated under TP: rank 0's launches are every rank's
         tot_b, tot_t, n, per_shape = measure_dominant_kernel(model, eng)
         achieved = tot_b / tot_t / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
@@ -297,6 +305,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
+        barrier(world)
         dist.destroy_process_group()
 
 

@@ -188,9 +188,14 @@ __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs
             p[i][c] = s;
         }
     tree_sum_rows<RB>(p, red_mean, j, mean);
+    // Second pass: sum of squared deviations AND max |deviation|.  The reference takes the maximum over
+    // |h((x - mean) * rstd)| after the variance is known (a third block reduction); rstd > 0 and both roundings are
+    // monotonic and sign-symmetric, so that maximum is |h(max|x - mean| * rstd)| bit for bit and the maximum can ride
+    // on the variance pass's barrier.
 #pragma unroll
     for (int i = 0; i < RB; i++) {
         mean[i] = mean[i] / (float)H;
+        float dm = 0.0f;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             float s = 0.0f;
@@ -198,40 +203,25 @@ __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs
             for (int it = 0; it < NI; it++) {
                 const float d = v[i][it][c] - mean[i];
                 s = __builtin_fmaf(d, d, s);
+                dm = fmaxf(dm, __builtin_fabsf(d));
             }
             p[i][c] = s;
         }
+        dm = wave_max_f(dm);
+        if ((j & 63) == 0) red_max[i * 32 + (j >> 6)] = dm;
     }
     tree_sum_rows<RB>(p, red_var, j, var);
-    float amax[RB];
+    float amax[RB], rstd[RB];
 #pragma unroll
     for (int i = 0; i < RB; i++) {
-        const float rstd = 1.0f / __builtin_sqrtf(var[i] / (float)H + a.eps);
-        // v <- (x - mean) * rstd (kept in fp32 for the quantiser); amax over its fp16 rounding, compared as fp16
-        f16x2 am2 = {f2h(1e-6f), f2h(1e-6f)};
-#pragma unroll
-        for (int it = 0; it < NI; it++)
-#pragma unroll
-            for (int c = 0; c < 4; c += 2) {
-                const float t0 = (v[i][it][c] - mean[i]) * rstd, t1 = (v[i][it][c + 1] - mean[i]) * rstd;
-                v[i][it][c] = t0;
-                v[i][it][c + 1] = t1;
-                const f16x2 r2 = {f2h(t0), f2h(t1)};
-                const u32 ab = __builtin_bit_cast(u32, r2) & 0x7FFF7FFFu;
-                const f16x2 a2 = __builtin_bit_cast(f16x2, ab);
-                // NaN (possible only for non-finite input) compares false, as in the reference's `a > amax ? a : amax`
-                am2[0] = a2[0] > am2[0] ? a2[0] : am2[0];
-                am2[1] = a2[1] > am2[1] ? a2[1] : am2[1];
-            }
-        float am = fmaxf(h2f(am2[0]), h2f(am2[1]));
-        am = wave_max_f(am);
-        if ((j & 63) == 0) red_max[i * 32 + (j >> 6)] = am;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < RB; i++) {
+        rstd[i] = 1.0f / __builtin_sqrtf(var[i] / (float)H + a.eps);
         const f32x4 m4 = *reinterpret_cast<const f32x4*>(red_max + i * 32);
-        amax[i] = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        const float dmax = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        const f16 a16 = f2h(dmax * rstd[i]), floor16 = f2h(1e-6f);
+        amax[i] = h2f(a16 > floor16 ? a16 : floor16);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
         const float s = 7.0f / amax[i];
         if (act[i]) {
 #pragma unroll
@@ -239,7 +229,7 @@ __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs
                 u32 nib[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    float t = v[i][it][c] * s;
+                    float t = ((v[i][it][c] - mean[i]) * rstd[i]) * s;
                     t = fmaxf(fminf(t, 7.0f), -8.0f);
                     // round to nearest even: the low bits of (t + 1.5 * 2^23) are the two's complement integer
                     float mg = t + 12582912.0f;

@@ -125,6 +125,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
         p[c] = s;
     }
     const float mean = ref_tree_sum_1024(p[0], p[1], p[2], p[3], red) / (float)H;
+    // max |x - mean| rides on the variance pass: the reference's amax = max |h((x - mean) * rstd)| equals
+    // |h(max|x - mean| * rstd)| bit for bit (rstd > 0, both roundings monotonic and sign-symmetric), which saves the
+    // third block reduction when input_sum (a write-only output the wrapper drops) is not requested
+    float dm = 0.0f;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         float s = 0.0f;
@@ -132,8 +136,13 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
         for (int it = 0; it < NI; it++) {
             float d = v[it][c] - mean;
             s = __builtin_fmaf(d, d, s);
+            dm = fmaxf(dm, __builtin_fabsf(d));
         }
         p[c] = s;
+    }
+    if (MODE == 0) {
+        dm = wave_max_f(dm);
+        if ((j & 63) == 0) red_all[3][j >> 6] = dm;   // published by the barrier inside the variance tree
     }
     const float var = ref_tree_sum_1024(p[0], p[1], p[2], p[3], red_all[1]);
     const float rstd = 1.0f / __builtin_sqrtf(var / (float)H + eps);
@@ -148,21 +157,20 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
         }
         return;
     }
-    float amax = h2f(f2h(1e-6f));
+    float sum_f = 0.0f;
+    if (input_sum) {   // uniform; fp16-accumulated per-thread partials of the rounded values, as the reference keeps them
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        f16 s16 = (f16)0.0f;
+        for (int c = 0; c < 4; c++) {
+            f16 s16 = (f16)0.0f;
 #pragma unroll
-        for (int it = 0; it < NI; it++) {
-            f16 r = f2h((v[it][c] - mean) * rstd);
-            float a = __builtin_fabsf(h2f(r));
-            amax = a > amax ? a : amax;
-            s16 = f2h(h2f(s16) + h2f(r));
+            for (int it = 0; it < NI; it++) s16 = f2h(h2f(s16) + h2f(f2h((v[it][c] - mean) * rstd)));
+            p[c] = h2f(s16);
         }
-        p[c] = h2f(s16);
+        sum_f = ref_tree_sum_1024(p[0], p[1], p[2], p[3], red_all[2]);
     }
-    const float sum_f = input_sum ? ref_tree_sum_1024(p[0], p[1], p[2], p[3], red_all[2]) : 0.0f;   // write-only output
-    amax = block_max_256(amax, red_all[3]);
+    const float dmax = fmaxf(fmaxf(red_all[3][0], red_all[3][1]), fmaxf(red_all[3][2], red_all[3][3]));
+    const f16 a16 = f2h(dmax * rstd), floor16 = f2h(1e-6f);
+    const float amax = h2f(a16 > floor16 ? a16 : floor16);
     const float s = 7.0f / amax;
 #pragma unroll
     for (int it = 0; it < NI; it++) {

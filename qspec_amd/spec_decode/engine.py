@@ -92,6 +92,7 @@ class QSpecEngine:
         self.md_draft = AttentionMetadata(self.d_slots, self.block_tables, self.d_ctx, self.d_qstart, 1, n_splits)
         self.md_verify = AttentionMetadata(self.v_slots, self.block_tables, self.v_ctx, self.v_qstart, k + 1, n_splits)
         self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._graph_draft: Optional[torch.cuda.CUDAGraph] = None   # fallback: proposer only (verify pass eager)
         # test hooks: injected random draws for the rejection sampler (eager mode only)
         self.inject_uniform: Optional[torch.Tensor] = None
         self.inject_exponential: Optional[torch.Tensor] = None
@@ -136,6 +137,10 @@ class QSpecEngine:
 
     # ------------------------------------------------------------------ one speculative cycle (:758-858)
     def _cycle_body(self):
+        self._draft_body()
+        self._verify_body()
+
+    def _draft_body(self):
         m, k, B, bs = self.model, self.k, self.B, self.block_size
         # proposer: k draft steps, W4A4  (execute_model_req.w4a4 = True, :799)
         ops.spec_prepare_draft(self.last_token, self.seq_lens, self.block_tables, bs, self.d_tokens, self.d_pos,
@@ -147,6 +152,9 @@ class QSpecEngine:
             if i != k - 1:  # _gpu_advance_step (draft_model_runner.py:78-135)
                 ops.advance_step_flashattn(B, B, bs, self.d_tokens, self.draft_ids_kb[i], self.d_pos, self.d_ctx,
                                            self.d_slots, self.block_tables)
+
+    def _verify_body(self):
+        m, k, B, bs = self.model, self.k, self.B, self.block_size
         # scorer: one W4A16 pass over [last, d_1..d_k] per sequence  (w4a4 = False, :812; mqa_scorer.py)
         draft_ids = self.draft_ids_kb.transpose(0, 1)            # [B,k] view
         draft_probs = self.draft_probs_kbv.transpose(0, 1)       # [B,k,V] view
@@ -170,12 +178,16 @@ class QSpecEngine:
         if not self.use_graph:
             self._cycle_body()
             return
-        if self._graph is None:
+        if self._graph is None and self._graph_draft is None:
             self._capture()
             if not self.use_graph:
                 self._cycle_body()
                 return
-        self._graph.replay()
+        if self._graph is not None:
+            self._graph.replay()
+        else:   # the verify pass could not be captured (its collectives): proposer from its graph, scorer eagerly
+            self._graph_draft.replay()
+            self._verify_body()
 
     def _capture(self):
         # warm up outside capture (lazy module loads, LDS attribute), on a side stream as torch requires.
@@ -193,11 +205,24 @@ class QSpecEngine:
             with torch.cuda.graph(g):
                 self._cycle_body()
             torch.cuda.synchronize()
-        except Exception as exc:  # e.g. a collective backend that cannot be captured: run eagerly, loudly
+        except Exception as exc:  # e.g. a collective backend that cannot be captured: loudly, not silently
             import warnings
-            warnings.warn(f"hipGraph capture of the cycle failed ({exc!r}); running the cycle eagerly")
-            self.use_graph = False
             torch.cuda.synchronize()
+            for t, s in zip((self.seq_lens, self.last_token, self.gen_tokens, self.gen_lens, self.sampler.counters,
+                             self.sampler.rng_state), state):
+                t.copy_(s)
+            try:   # the proposer has no collectives (replicated under TP): keep its k forwards in a graph
+                gd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gd):
+                    self._draft_body()
+                torch.cuda.synchronize()
+                self._graph_draft = gd
+                warnings.warn(f"hipGraph capture of the whole cycle failed ({exc!r}); "
+                              "the draft pass replays from a graph, the verify pass runs eagerly")
+            except Exception as exc2:
+                warnings.warn(f"hipGraph capture failed ({exc!r}; draft only: {exc2!r}); running the cycle eagerly")
+                self.use_graph = False
+                torch.cuda.synchronize()
             for t, s in zip((self.seq_lens, self.last_token, self.gen_tokens, self.gen_lens, self.sampler.counters,
                              self.sampler.rng_state), state):
                 t.copy_(s)
