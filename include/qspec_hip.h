@@ -114,7 +114,7 @@ int qspec_rowwise_scaled_linear_s4s4(const int8_t* xq, const qspec_half* xs, con
 
 /* The s4s4 linear above followed by the residual add of QuarotDecoderLayer (quarot_llama.py:380 `hidden = residual +
  * o_proj(...)`, :390 `residual + down_proj(...)`): resid_out = h(f(resid_in) + f(h(linear))), an fp16 add of the
- * fp16 GEMM result, in the GEMM's epilogue.  resid_out may alias resid_in.  M <= 16.  The norm that follows then
+ * fp16 GEMM result, in the GEMM's epilogue.  resid_out may alias resid_in.  M <= 32.  The norm that follows then
  * reads one tensor (qspec_ln_*_linear_s4s4 with delta = NULL, hidden_out = NULL). */
 int qspec_rowwise_scaled_linear_s4s4_residual(const int8_t* xq, const qspec_half* xs, const int8_t* wq,
                                               const qspec_half* ws, const qspec_half* resid_in, qspec_half* resid_out,

@@ -179,7 +179,7 @@ int qspec_rowwise_scaled_linear_s4s4_residual(const int8_t* xq, const qspec_half
     if (M == 0 || N == 0) return 0;
     NONNULL(op, xq); NONNULL(op, xs); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, resid_in); NONNULL(op, resid_out);
     if (!qspec::gemm_w4a4_stream_supported(M, N, K, false))
-        return fail("%s: need M <= 16, N %% 16 == 0 and a built K (M=%d N=%d K=%d)", op, M, N, K);
+        return fail("%s: need M <= 32, N %% 16 == 0 and a built K (M=%d N=%d K=%d)", op, M, N, K);
     qspec::StreamActs x;
     x.xq = xq; x.xs = CH(xs);
     return finish(op, qspec::gemm_w4a4_stream_residual(x, wq, CH(ws), CH(resid_in), H(resid_out), M, N, K, ST));
@@ -219,6 +219,8 @@ int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, 
     if (K % 32 || K <= 0) return fail("%s: need K %% 32 == 0 (K=%d)", op, K);
     if (use_stream() && qspec::gemm_f16_stream_supported(M, N, K))
         return finish(op, qspec::gemm_f16_stream(CH(x), CH(w), H(out), M, N, K, ST));
+    if (M > 16 && tiled_min_m() < (1 << 30) && qspec::gemm_f16_tiled_supported(M, N, K))   // prefill / large-batch logits
+        return finish(op, qspec::gemm_f16_tiled(CH(x), CH(w), H(out), M, N, K, ST));
     return finish(op, qspec::gemm_f16(CH(x), CH(w), H(out), M, N, K, ST));
 }
 int qspec_dequant_w4(const int8_t* wq, const qspec_half* ws, qspec_half* out, int N, int K, void* stream) {

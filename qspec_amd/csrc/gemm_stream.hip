@@ -253,8 +253,11 @@ __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs
 #else
 #define QS_SSTAMP(i)
 #endif
-template <int EPI, int PRO, int NW, int UB, int NI>
+// MT = 16-token tiles per workgroup (1: M <= 16; 2: M <= 32, PRO_Q only, activation fragments kept PACKED in registers
+// and widened at each use -- 8 VGPRs per step and tile would not fit beside the weight ring at 1024 threads).
+template <int EPI, int PRO, int NW, int UB, int NI, int MT = 1>
 __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a) {
+    static_assert(MT == 1 || (PRO == PRO_Q && NW >= 8), "two token tiles: (xq, xs) input, >= 512 threads for the epilogue");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef QS_STREAM_STAMPS
     long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -268,10 +271,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
     const int Kb = a.K >> 1, RS = Kb + 32;
     const int MP = a.M <= 4 ? 4 : (a.M <= 8 ? 8 : 16);
     unsigned char* xq_lds = smem;
-    float* xs_lds = reinterpret_cast<float*>(smem + (size_t)MP * RS);
-    int* red = reinterpret_cast<int*>(xs_lds + 16);                 // [2][NW][256]
-    f16* ex = reinterpret_cast<f16*>(red + 2 * NW * 256);            // [2][256]
-    float* lnred = reinterpret_cast<float*>(ex + 2 * 256);           // [3][NG][RB][32]
+    float* xs_lds = reinterpret_cast<float*>(smem + (PRO == PRO_Q ? (size_t)0 : (size_t)MP * RS));   // (xq, xs) input: no staged rows
+    int* red = reinterpret_cast<int*>(xs_lds + 16);                 // [2][NW][MT][256]
+    f16* ex = reinterpret_cast<f16*>(red + 2 * NW * MT * 256);       // [2][MT * 256]
+    float* lnred = reinterpret_cast<float*>(ex + 2 * MT * 256);      // [3][NG][RB][32]
     const int NB = Kb / (64 * NW * UB);                              // batches per tile (exact: checked on the host)
 
     // epilogue thread (tid < 256) owns accumulator element (token m, tile column c)
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
     // other waves go straight back to streaming.  ridx = where the MFMA left that element in a wave's accumulators.
     const int c = tid & 15, m = tid >> 4;
     const bool ethread = m < a.M;
-    const int ridx = (m & 3) * 64 + ((m >> 2) & 3) * 16 + c;
+    const int ridx = (m >> 4) * 256 + (m & 3) * 64 + ((m >> 2) & 3) * 16 + c;   // (token tile, element) in a wave's block
     const int mc = m < a.M ? m : 0;
 
     // No load in this kernel sits behind a branch: hipcc resolves control flow around vector-memory operations
@@ -310,24 +313,42 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
     // (PRO_Q) no LDS staging and no barrier in front of the first MFMA at all.
     const unsigned char* arow = xq_lds + (size_t)(r & (MP - 1)) * RS + g * 16;
     i32x4 af0[UB], af1[UB];
+    u32x4 apk[MT][UB];   // MT == 2: packed fragments
     float xs_m = 0.0f;   // activation scale of this epilogue thread's token
-    i32x4 acc = {0, 0, 0, 0};
+    i32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] = i32x4{0, 0, 0, 0};
     auto use = [&](const u32x4& w, int b, int u) {
         const i32x4 b0 = widen16(w[0], w[1]), b1 = widen16(w[2], w[3]);
-        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af0[u], b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1[u], b1, acc, 0, 0, 0);
+        if constexpr (MT == 1) {
+            acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af0[u], b0, acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1[u], b1, acc[0], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                // the widening is loop invariant (a wave meets the same K steps in every tile): left visible, hipcc
+                // hoists it and keeps 8 VGPRs per step and tile live -- spills at 1024 threads.  Opaque copies keep it here.
+                u32 p0 = apk[mt][u][0], p1 = apk[mt][u][1], p2 = apk[mt][u][2], p3 = apk[mt][u][3];
+                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+                acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(widen16(p0, p1), b0, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(widen16(p2, p3), b1, acc[mt], 0, 0, 0);
+            }
+        }
     };
     auto finish = [&](int tile, int par, const Pre& pre) {
-        int* rb = red + par * NW * 256;
+        int* rb = red + par * NW * MT * 256;
 #pragma unroll
-        for (int i = 0; i < 4; i++) rb[wave * 256 + i * 64 + lane] = acc[i];
-        acc = i32x4{0, 0, 0, 0};
+        for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) rb[(wave * MT + mt) * 256 + i * 64 + lane] = acc[mt][i];
+            acc[mt] = i32x4{0, 0, 0, 0};
+        }
         __syncthreads();
         f16 hv = (f16)0.0f;
         if (ethread) {
             int sum = 0;
 #pragma unroll
-            for (int w2 = 0; w2 < NW; w2++) sum += rb[w2 * 256 + ridx];
+            for (int w2 = 0; w2 < NW; w2++) sum += rb[w2 * MT * 256 + ridx];
             const float v = ((float)(sum >> 8) * xs_m) * h2f(pre.swn);  // both operands carried a factor 16
             hv = f2h(v);
         }
@@ -339,8 +360,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
             if (ethread) a.resid_out[(size_t)m * a.N + tile * 16 + c] = f2h(h2f(pre.cf) + h2f(hv));
             return;
         }
-        f16* e = ex + par * 256;
-        if (tid < 256) e[tid] = hv;
+        f16* e = ex + par * MT * 256;
+        if (tid < MT * 256) e[tid] = hv;
         __syncthreads();
         if (!ethread) return;
         const f16 partner = e[tid ^ 8];
@@ -479,6 +500,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
         const unsigned char* xrow = reinterpret_cast<const unsigned char*>(a.xq) + (size_t)(r < a.M ? r : 0) * Kb + g * 16;
 #pragma unroll
         for (int u = 0; u < UB; u++) araw[u] = *reinterpret_cast<const u32x4*>(xrow + step_off<NW, UB>(wave, u));
+        if constexpr (MT > 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const int row = mt * 16 + r;
+                const unsigned char* xr = reinterpret_cast<const unsigned char*>(a.xq) + (size_t)(row < a.M ? row : 0) * Kb + g * 16;
+#pragma unroll
+                for (int u = 0; u < UB; u++) apk[mt][u] = *reinterpret_cast<const u32x4*>(xr + step_off<NW, UB>(wave, u));
+            }
+        }
         const f16 xsh = a.xs[mc];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -898,10 +928,11 @@ static bool stream_shape(int K, StreamShape* sh) {
     return false;
 }
 
-static size_t stream_lds_bytes(int M, int K, int NW) {
+static size_t stream_lds_bytes(int M, int K, int NW, bool staged_rows, int MT) {
     const int MP = M <= 4 ? 4 : (M <= 8 ? 8 : 16);
     const int NG = NW / 4, RB = NW == 4 ? 4 : (NW == 8 ? 2 : 1);
-    return (size_t)MP * (K / 2 + 32) + 64 + (size_t)2 * NW * 1024 + 1024 + (size_t)3 * NG * RB * 32 * 4;
+    return (staged_rows ? (size_t)MP * (K / 2 + 32) : 0) + 64 + (size_t)2 * NW * MT * 1024 + (size_t)MT * 1024 +
+           (size_t)3 * NG * RB * 32 * 4;
 }
 
 static int g_stream_cap = 0;  // workgroups per launch above which a workgroup loops over several tiles
@@ -914,12 +945,12 @@ static int stream_cap() {
     return g_stream_cap;
 }
 
-template <int EPI, int PRO, int NW, int UB, int NI>
+template <int EPI, int PRO, int NW, int UB, int NI, int MT = 1>
 static int launch_stream_inst(const StreamArgs& a, hipStream_t st) {
-    const size_t lds = stream_lds_bytes(a.M, a.K, NW);
+    const size_t lds = stream_lds_bytes(a.M, a.K, NW, PRO != PRO_Q, MT);
     if (lds > 160 * 1024) return -7;
     static size_t attr_set = 0;  // per instantiation
-    auto kern = gemm_w4a4_stream_kernel<EPI, PRO, NW, UB, NI>;
+    auto kern = gemm_w4a4_stream_kernel<EPI, PRO, NW, UB, NI, MT>;
     if (lds > 64 * 1024 && lds > attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -8;
@@ -939,7 +970,15 @@ static int launch_stream_inst(const StreamArgs& a, hipStream_t st) {
 template <int EPI>
 static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
     StreamShape sh;
-    if (a.M < 1 || a.M > 16 || !stream_shape(a.K, &sh)) return -1;
+    if (a.M < 1 || a.M > 32 || !stream_shape(a.K, &sh)) return -1;
+    if (a.M > 16) {   // two token tiles: (xq, xs) input, shapes with >= 512 threads
+        if (ln) return -1;
+        if (sh.NW == 8 && sh.UB == 4) return launch_stream_inst<EPI, PRO_Q, 8, 4, 0, 2>(a, st);
+        if (sh.NW == 16 && sh.UB == 7) return launch_stream_inst<EPI, PRO_Q, 16, 7, 0, 2>(a, st);
+        if (sh.NW == 8 && sh.UB == 8) return launch_stream_inst<EPI, PRO_Q, 8, 8, 0, 2>(a, st);
+        if (sh.NW == 8 && sh.UB == 5) return launch_stream_inst<EPI, PRO_Q, 8, 5, 0, 2>(a, st);
+        return -1;
+    }
     if (!ln) {
         if (sh.NW == 8 && sh.UB == 4) return launch_stream_inst<EPI, PRO_Q, 8, 4, 0>(a, st);
         if (sh.NW == 16 && sh.UB == 7) return launch_stream_inst<EPI, PRO_Q, 16, 7, 0>(a, st);
@@ -1100,9 +1139,10 @@ int gemm_w4a16_stream_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws
 
 bool gemm_w4a4_stream_supported(int M, int N, int K, bool ln) {
     StreamShape sh;
-    if (M < 1 || M > 16 || N % 16 || K > (1 << 19) || !stream_shape(K, &sh)) return false;
+    if (M < 1 || M > 32 || N % 16 || K > (1 << 19) || !stream_shape(K, &sh)) return false;
+    if (M > 16 && (ln || sh.NW < 8)) return false;   // two token tiles: (xq, xs) input only
     if (ln && !(K == 1024 || K == 2048 || K == 4096 || K == 5120 || K == 8192)) return false;
-    return stream_lds_bytes(M, K, sh.NW) <= 160 * 1024;
+    return stream_lds_bytes(M, K, sh.NW, ln, M > 16 ? 2 : 1) <= 160 * 1024;
 }
 
 // act: either (xq, xs) or (hidden_in, delta, hidden_out, eps) -- see StreamArgs.

@@ -230,4 +230,120 @@ int gemm_w4a16_tiled(const f16* x, const int8_t* wq, const f16* ws, f16* out, in
     return 0;
 }
 
+// ------------------------------------------------------------------ fp16 x fp16 (lm_head) at prefill-sized M
+// out[m,n] = h( sum_k f(x[m,k]) * f(w[n,k]) ), fp32 accumulate (LogitsProcessor's plain nn.Linear,
+// vllm/model_executor/layers/logits_processor.py:92-97).  Same tiling as above; the weight fragment of
+// v_mfma_f32_32x32x16_f16 is 8 consecutive halves of a row, i.e. the 16-byte load itself (no dequantiser).
+// One weight step = 16 k (32 bytes of a row, 16 per k-group); a stage of 128 k = 8 steps; 16 steps (32 KiB per
+// wave... 16 B x 64 lanes x 16) in flight.  blockIdx.x walks the token blocks so that workgroups sharing a weight tile
+// are dispatched together (the second reader hits the infinity cache).  N % 32 == 0; rows past N are clamped, not stored.
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_f16_tiled_kernel(const f16* __restrict__ x, const f16* __restrict__ wt,
+                                                              f16* __restrict__ out, int M, int N, int K) {
+    constexpr int BM = 32 * MT, ROWB = QS_T_STAGE_K * 2, CPR = ROWB / 16, LPT = BM * CPR / 256;
+    constexpr int RING = 16, SPS = 8, NS = RING / SPS;      // steps in flight, steps per stage, stages per round
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 31, kg = lane >> 5;
+    const int n0 = blockIdx.y * 128 + wave * 32, m0 = blockIdx.x * BM;
+    const int nrow = min(n0 + nl, N - 1);
+    const int nrounds = K / (16 * RING);
+    const unsigned char* wrow = reinterpret_cast<const unsigned char*>(wt + (size_t)nrow * K) + kg * 16;  // step s: + 32 s
+
+    u32x4 areg[LPT];
+    auto a_load = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < LPT; i++) {
+            const int cidx = tid + i * 256, row = cidx / CPR, q = cidx % CPR;
+            const int m = min(m0 + row, M - 1);
+            areg[i] = *reinterpret_cast<const u32x4*>(x + (size_t)m * K + (size_t)stage * QS_T_STAGE_K + q * 8);
+        }
+    };
+    auto a_store = [&](int buf) {
+        unsigned char* b = smem + (size_t)buf * BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < LPT; i++) {
+            const int cidx = tid + i * 256, row = cidx / CPR, q = cidx % CPR;
+            *reinterpret_cast<u32x4*>(b + (size_t)row * ROWB + ((q ^ (row & 15)) << 4)) = areg[i];
+        }
+    };
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[mt][i] = 0.0f;
+    a_load(0);
+    u32x4 w[RING];
+#pragma unroll
+    for (int u = 0; u < RING; u++) w[u] = *reinterpret_cast<const u32x4*>(wrow + (size_t)u * 32);
+    a_store(0);
+    __syncthreads();
+    auto step_compute = [&](int buf, int j, const u32x4& wv) {   // step j of the stage: k = 16 j + 8 kg .. + 7 = chunk 2 j + kg
+        const unsigned char* b = smem + (size_t)buf * BM * ROWB;
+        const f16x8 bf = __builtin_bit_cast(f16x8, wv);
+        const int q = 2 * j + kg;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int row = mt * 32 + nl;
+            const f16x8 av = *reinterpret_cast<const f16x8*>(b + (size_t)row * ROWB + ((q ^ (row & 15)) << 4));
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bf, acc[mt], 0, 0, 0);
+        }
+    };
+    for (int r = 0; r < nrounds - 1; r++) {
+        const unsigned char* wnext = wrow + (size_t)(r + 1) * RING * 32;
+#pragma unroll
+        for (int sg = 0; sg < NS; sg++) {
+            a_load(r * NS + sg + 1);
+#pragma unroll
+            for (int j = 0; j < SPS; j++) {
+                step_compute(sg & 1, j, w[sg * SPS + j]);
+                __builtin_amdgcn_sched_barrier(0);
+                w[sg * SPS + j] = *reinterpret_cast<const u32x4*>(wnext + (size_t)(sg * SPS + j) * 32);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            a_store((sg & 1) ^ 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int sg = 0; sg < NS; sg++) {
+        if (sg + 1 < NS) a_load((nrounds - 1) * NS + sg + 1);
+#pragma unroll
+        for (int j = 0; j < SPS; j++) step_compute(sg & 1, j, w[sg * SPS + j]);
+        if (sg + 1 < NS) {
+            a_store((sg & 1) ^ 1);
+            __syncthreads();
+        }
+    }
+    if (n0 + nl < N) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int m = m0 + mt * 32 + (i >> 2) * 8 + kg * 4 + (i & 3);
+                if (m < M) out[(size_t)m * N + n0 + nl] = f2h(acc[mt][i]);
+            }
+    }
+}
+
+bool gemm_f16_tiled_supported(int M, int N, int K) { return M >= 1 && N % 32 == 0 && K % 256 == 0 && K >= 512; }
+
+int gemm_f16_tiled(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st) {
+    if (!gemm_f16_tiled_supported(M, N, K)) return -1;
+    const int blocks = (M + 127) / 128;
+    const int per = (M + blocks - 1) / blocks;
+    const int MT = (per + 31) / 32;   // 1..4: fewest token blocks, least padding (192 -> 2 x 96): the weights stream once per block
+    const dim3 grid((M + 32 * MT - 1) / (32 * MT), (N + 127) / 128);
+    const size_t lds = (size_t)2 * 32 * MT * (QS_T_STAGE_K * 2);
+    switch (MT) {
+        case 1: hipLaunchKernelGGL((gemm_f16_tiled_kernel<1>), grid, dim3(256), lds, st, x, w, out, M, N, K); break;
+        case 2: hipLaunchKernelGGL((gemm_f16_tiled_kernel<2>), grid, dim3(256), lds, st, x, w, out, M, N, K); break;
+        case 3: hipLaunchKernelGGL((gemm_f16_tiled_kernel<3>), grid, dim3(256), lds, st, x, w, out, M, N, K); break;
+        case 4: hipLaunchKernelGGL((gemm_f16_tiled_kernel<4>), grid, dim3(256), lds, st, x, w, out, M, N, K); break;
+        default: return -1;
+    }
+    return 0;
+}
+
 }  // namespace qspec

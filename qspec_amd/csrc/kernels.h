@@ -95,6 +95,9 @@ bool gemm_w4a16_tiled_supported(int M, int N, int K);
 int gemm_w4a16_tiled(const f16* x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K, float* part,
                      size_t part_bytes, hipStream_t st);
 
+bool gemm_f16_tiled_supported(int M, int N, int K);
+int gemm_f16_tiled(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st);
+
 bool gemm_f16_stream_supported(int M, int N, int K);
 int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st);
 int prefetch_l2(const void* p, size_t bytes, int workgroups, hipStream_t st);

@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import os
+
 import torch
 
 from .. import ops
@@ -34,6 +36,9 @@ def n_splits_for(ctx: int, n_groups: int = 0) -> int:
     length: a split longer than 128 keys is walked in 128-key chunks inside the kernel, so the partials the next launch
     merges do not grow with the context.  Prefill-sized queries (n_groups = 0) fill the chip with row blocks: 1."""
     if n_groups > 0:
+        forced = int(os.environ.get("QSPEC_ATTN_SPLITS", "0"))   # dev knob for sweeps
+        if forced > 0:
+            return forced
         return max(1, min(16, (256 + n_groups - 1) // n_groups))
     return 1
 

@@ -35,3 +35,11 @@ for M in Ms:
             us3 = t(lambda: torch.matmul(x, wd.t(), out=out))
             line += f" | dequant+lib {us2:8.1f} us | lib only {us3:8.1f} us {fl/us3/1e6:7.1f} TF"
         print(line, flush=True)
+# ---- lm_head (fp16 x fp16)
+N, K = 128256, 4096
+w = (torch.randn(N, K, device=dev) * 0.02).half()
+for M in (4, 16, 32, 96, 192, 512):
+    x = torch.randn(M, K, device=dev, dtype=torch.float16)
+    out = torch.empty(M, N, device=dev, dtype=torch.float16)
+    us = t(lambda: ops.linear_f16(x, w, out))
+    print(f"lm_head M={M:4d}: {us:8.1f} us  {N*K*2/us/1e6:6.2f} TB/s weights  {2.0*M*N*K/us/1e6:7.1f} TF", flush=True)

@@ -905,3 +905,75 @@ def test_fwht_rows_of_one(ops, oracle):
     out = torch.empty(1000, 1, dtype=torch.float16, device=DEV)
     ops.faster_fast_hadamard_transform(dev(x), 0.158, out)
     assert np.array_equal(bits(host(out)), bits(oracle.fwht(x, 0.158)))
+
+
+@pytest.mark.parametrize("M,N,K", [(17, 160, 512), (32, 2048, 4096), (192, 1504, 4096), (200, 128, 768), (513, 96, 1024)])
+def test_linear_f16_tiled_within_1e3(ops, oracle, M, N, K):
+    """lm_head at prefill / large-batch M (M-tiled kernel): ragged token block, N not a multiple of the 128-row tile."""
+    rng = np.random.default_rng(M + N + K)
+    x = rand_hidden(rng, M, K)
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float16)
+    out = torch.full((M + 1, N), 7.0, dtype=torch.float16, device=DEV)
+    ops.linear_f16(dev(x), dev(w), out[:M])
+    assert_close_1e3(host(out[:M]), oracle.gemm_f16(x, w))
+    assert torch.all(out[M] == 7.0)
+
+
+# ------------------------------------------------------------------ W4A4 streaming kernels with two token tiles (M 17..32)
+
+@pytest.mark.parametrize("M", [17, 24, 32])
+def test_w4a4_two_token_tiles_layer_shapes(ops, oracle, M):
+    """Batch 32 draft pass: the streaming W4A4 kernels with two 16-token tiles per workgroup (packed activation
+    fragments) at the Llama-3-8B layer shapes -- plain / qkv+RoPE+KV / gate_up+silu / residual epilogues against the
+    oracle formula (bit for bit) and against the separate reference ops."""
+    rng = np.random.default_rng(M)
+    K, nq, nkv, d, bs, I = 4096, 32, 8, 128, 16, 14336
+    N = (nq + 2 * nkv) * d
+    xq_np, xs_np = oracle.pack_i4(rand_w4(rng, M, K)), (rng.random(M) * 0.1 + 0.01).astype(np.float16)
+    xq, xs = dev(xq_np), dev(xs_np)
+    w_np = rng.integers(-128, 128, (N, K // 2)).astype(np.int8)
+    ws_np = (rng.random(N) * 0.01 + 0.001).astype(np.float16)
+    wq, ws = dev(w_np), dev(ws_np)
+    # plain, against the oracle
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq, xs, wq, ws, None, out)
+    assert np.array_equal(bits(host(out)), bits(oracle.gemm_w4a4(xq_np, xs_np, w_np, ws_np)))
+    # qkv + RoPE + KV write == plain + rope_kv_write
+    cs = dev(oracle.make_cos_sin_cache(d, 2048, 500000.0))
+    pos = dev(rng.integers(0, 2048, M).astype(np.int64))
+    slots = dev(rng.permutation(64 * bs)[:M].astype(np.int64))
+    kc0 = torch.zeros(64, bs, nkv, d, dtype=torch.float16, device=DEV); vc0 = torch.zeros_like(kc0)
+    ref = out.clone()
+    ops.rope_kv_write(pos, ref, cs, kc0, vc0, slots, nq, nkv, d)
+    kc1 = torch.zeros_like(kc0); vc1 = torch.zeros_like(kc0)
+    qkv = torch.empty_like(ref)
+    ops.qkv_rope_linear(xq, xs, wq, ws, qkv, pos, cs, kc1, vc1, slots, nq, nkv, d)
+    torch.cuda.synchronize()
+    assert torch.equal(qkv.view(torch.int16), ref.view(torch.int16))
+    assert torch.equal(kc1, kc0) and torch.equal(vc1, vc0)
+    # gate_up + silu*up == plain + silu_mul
+    wg = dev(rng.integers(-128, 128, (2 * I, K // 2)).astype(np.int8)); wgs = dev((rng.random(2 * I) * 0.01 + 0.001).astype(np.float16))
+    gu = torch.empty(M, 2 * I, dtype=torch.float16, device=DEV)
+    ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq, xs, wg, wgs, None, gu)
+    ref_act = ops.silu_mul(gu, torch.empty(M, I, dtype=torch.float16, device=DEV))
+    act = ops.gate_up_silu_linear(xq, xs, wg, wgs, torch.empty(M, I, dtype=torch.float16, device=DEV))
+    assert torch.equal(act.view(torch.int16), ref_act.view(torch.int16))
+    # down_proj (K = 14336, 1024 threads) + residual
+    x3_np, w3_np = oracle.pack_i4(rand_w4(rng, M, I)), rng.integers(-128, 128, (K, I // 2)).astype(np.int8)
+    w3s_np = (rng.random(K) * 0.002 + 0.0005).astype(np.float16)
+    resid_np = rand_hidden(rng, M, K)
+    hid = dev(resid_np).clone()
+    ops.rowwise_scaled_linear_s4s4_residual(dev(x3_np), xs, dev(w3_np), dev(w3s_np), hid, hid)
+    assert np.array_equal(bits(host(hid)), bits(oracle.add_f16(resid_np, oracle.gemm_w4a4(x3_np, xs_np, w3_np, w3s_np))))
+
+
+@pytest.mark.parametrize("M,N,K", [(20, 256, 8192), (32, 128, 5120), (31, 4096, 14336)])
+def test_w4a4_two_token_tiles_other_k(ops, oracle, M, N, K):
+    rng = np.random.default_rng(M + K)
+    xq, xs = oracle.pack_i4(rand_w4(rng, M, K)), (rng.random(M) * 0.1 + 0.01).astype(np.float16)
+    w = rng.integers(-128, 128, (N, K // 2)).astype(np.int8)
+    ws = (rng.random(N) * 0.01 + 0.001).astype(np.float16)
+    out = torch.full((M + 1, N), 3.0, dtype=torch.float16, device=DEV)
+    ops.rowwise_scaled_linear_cutlass_s4s4_unified(dev(xq), dev(xs), dev(w), dev(ws), None, out[:M])
+    assert np.array_equal(bits(host(out[:M])), bits(oracle.gemm_w4a4(xq, xs, w, ws)))
+    assert torch.all(out[M] == 3.0)
