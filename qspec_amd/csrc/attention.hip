@@ -9,6 +9,8 @@
 //
 // KV cache layout is vLLM's flash layout: [num_blocks, block_size, n_kv, d] fp16,
 // one tensor for K and one for V, shared by the draft and the verify pass.
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -162,6 +164,10 @@ __device__ __forceinline__ u32x2 lds_read_tr_b16(uint32_t lds_byte_addr) {
     return r;
 }
 
+// PF: the loads of chunk i+1 fly underneath chunk i (64 more VGPRs: one workgroup per CU -- the decode shape at small
+// batch, where the launch is 256 workgroups of dependent round trips).  PF = false halves the register footprint so that
+// two workgroups share a CU: large batches, where occupancy hides the same latency.
+template <bool PF>
 __global__ __launch_bounds__(256) void paged_attention_kernel(
     const f16* __restrict__ q, int64_t q_stride, const f16* __restrict__ key_cache, const f16* __restrict__ value_cache,
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
     };
     Slots sl_cur, sl_nxt;
     lookup(sl_cur, k_begin);
-    lookup(sl_nxt, k_begin + (n_it > 1 ? QS_ATT_CHUNK : 0));
+    if constexpr (PF) lookup(sl_nxt, k_begin + (n_it > 1 ? QS_ATT_CHUNK : 0));
     u32x4 qfrag[4];
     {  // lane (row c16, d slice 8*g4 + 32j); rows >= R repeat row 0 (their outputs are never stored)
         const int r = r0 + (c16 < R ? c16 : 0);
@@ -368,10 +374,16 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
 
     int kb = k_begin;
     for (int it = 0; it < n_it - 1; it++) {
-        fetch(nxt, sl_nxt);                                         // chunk it+1: in flight underneath chunk it
-        lookup(sl_nxt, kb + 2 * QS_ATT_CHUNK);                      // table entries of chunk it+2 (clamped)
-        process(cur, kb, false);
-        cur = nxt;
+        if constexpr (PF) {
+            fetch(nxt, sl_nxt);                                     // chunk it+1: in flight underneath chunk it
+            lookup(sl_nxt, kb + 2 * QS_ATT_CHUNK);                  // table entries of chunk it+2 (clamped)
+            process(cur, kb, false);
+            cur = nxt;
+        } else {
+            lookup(sl_nxt, kb + QS_ATT_CHUNK);                      // the next chunk's table entries under this chunk
+            process(cur, kb, false);
+            fetch(cur, sl_nxt);
+        }
         kb += QS_ATT_CHUNK;
     }
     process(cur, kb, true);
@@ -589,9 +601,17 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
     float* ws_ml = ws_o + Tmax * nq * n_splits * d;
     const size_t lds = QS_ATT_MAXR * QS_ATT_CHUNK * 4 + 2 * QS_ATT_MAXR * QS_ATT_CHUNK * 2 +
                        QS_ATT_CHUNK * QS_ATT_VSTRIDE * 2 + (2 * QS_ATT_MAXR + QS_ATT_MAXR * QS_ATT_MAXSPLIT + 4) * 4;
-    hipLaunchKernelGGL(paged_attention_kernel, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), lds, st, q, q_stride,
-                       key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv, bs_log2,
-                       group_log2, sm_scale, n_splits, n_rb, cnt, ws_o, ws_ml, out, out != nullptr ? 1 : 0);
+    // more workgroups than CUs: occupancy (two per CU) instead of the in-workgroup prefetch
+    static const int pf_env = getenv("QSPEC_ATTN_PF") ? atoi(getenv("QSPEC_ATTN_PF")) : -1;   // dev knob
+    const bool pf = pf_env >= 0 ? pf_env != 0 : (size_t)n_seqs * nkv * n_rb * n_splits <= 256;
+    if (pf)
+        hipLaunchKernelGGL(paged_attention_kernel<true>, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), lds, st, q,
+                           q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv, bs_log2,
+                           group_log2, sm_scale, n_splits, n_rb, cnt, ws_o, ws_ml, out, out != nullptr ? 1 : 0);
+    else
+        hipLaunchKernelGGL(paged_attention_kernel<false>, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), lds, st, q,
+                           q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv, bs_log2,
+                           group_log2, sm_scale, n_splits, n_rb, cnt, ws_o, ws_ml, out, out != nullptr ? 1 : 0);
     return 0;
 }
 

@@ -4,10 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from qspec_amd import ops
 dev = "cuda:0"
-B, nq, nkv, d, bs, L = 4, 32, 8, 128, 16, 32
+B, nq, nkv, d, bs, L = int(os.environ.get("B", 4)), 32, 8, 128, 16, int(os.environ.get("L", 32))
 ctx0, max_len = 512, 640
 for q_len in (1, 4):
-    n_splits = 8
+    n_splits = int(os.environ.get("S", 8))
     nb = B * (max_len // bs)
     kcs = [torch.randn(nb, bs, nkv, d, device=dev).half() for _ in range(L)]
     vcs = [torch.randn(nb, bs, nkv, d, device=dev).half() for _ in range(L)]
