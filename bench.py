@@ -88,7 +88,13 @@ def measure_dominant_kernel(model, engine, reps=5):
     hid, o = s.hidden[:B], s.act_buffer_output[:B]
     eps = cfg.rms_norm_eps
     kinds = ("qkv", "o", "gate_up", "down")
-    ln_fused = ops.ln_linear_s4s4_supported(B, cfg.q_size + 2 * cfg.kv_size, cfg.hidden_size)
+    # the same dispatch as QuarotLlamaForCausalLM.forward: fused epilogues need head_dim 128, fused norms M <= 16
+    fuse = cfg.head_dim == 128
+    ln_fused = (fuse and ops.ln_linear_s4s4_supported(B, cfg.q_size + 2 * cfg.kv_size, cfg.hidden_size)
+                and ops.ln_linear_s4s4_supported(B, 2 * cfg.intermediate_size, cfg.hidden_size)
+                and ops.rowwise_scaled_linear_s4s4_residual_supported(B, cfg.hidden_size, cfg.hidden_size)
+                and ops.rowwise_scaled_linear_s4s4_residual_supported(B, cfg.hidden_size, cfg.intermediate_size))
+    gu_out = s.act_buffer_gate_up[:B]
 
     def launch(layer, kc, vc, kind):
         if kind == "qkv":
@@ -96,10 +102,13 @@ def measure_dominant_kernel(model, engine, reps=5):
                 ops.ln_qkv_rope_linear(hid, None, None, eps, layer.qkv_proj.weight, layer.qkv_proj._scales(),
                                        s.act_buffer_qkv[:B], engine.d_pos, model.cos_sin_cache, kc, vc, md.slot_mapping,
                                        cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim)
-            else:
+            elif fuse:
                 ops.qkv_rope_linear(xq, sc, layer.qkv_proj.weight, layer.qkv_proj._scales(), s.act_buffer_qkv[:B],
                                     engine.d_pos, model.cos_sin_cache, kc, vc, md.slot_mapping, cfg.num_attention_heads,
                                     cfg.num_key_value_heads, cfg.head_dim)
+            else:
+                ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq, sc, layer.qkv_proj.weight, layer.qkv_proj._scales(), None,
+                                                               s.act_buffer_qkv[:B])
         elif kind == "o":
             if ln_fused:
                 ops.rowwise_scaled_linear_s4s4_residual(xq, sc, layer.o_proj.weight, layer.o_proj._scales(), hid, hid)
@@ -109,8 +118,10 @@ def measure_dominant_kernel(model, engine, reps=5):
             if ln_fused:
                 ops.ln_gate_up_silu_linear(hid, None, None, eps, layer.gate_up.weight, layer.gate_up._scales(),
                                            s.act_buffer_had_mlp[:B])
-            else:
+            elif fuse:
                 ops.gate_up_silu_linear(xq, sc, layer.gate_up.weight, layer.gate_up._scales(), s.act_buffer_had_mlp[:B])
+            else:
+                ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq, sc, layer.gate_up.weight, layer.gate_up._scales(), None, gu_out)
         elif ln_fused:
             ops.rowwise_scaled_linear_s4s4_residual(s.quantized_buffer_mlp[:B], sc, layer.down_proj.weight, layer.down_proj._scales(), hid, hid)
         else:
@@ -295,8 +306,9 @@ def main():
         achieved = tot_b / tot_t / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                            "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic_per_launch(),
-                           "kernel": "qspec::gemm_w4a4_stream_kernel (the four decoder GEMM launches of a draft forward, M = batch: "
-                                     "LN+int4-quant prologue -> qkv+RoPE+KV-write / gate_up+silu*up; o_proj / down_proj + residual add)",
+                           "kernel": "qspec::gemm_w4a4_stream_kernel (the four decoder GEMM launches of a draft forward, M = batch, in "
+                                     "the forms the cycle launches for this shape: LN+int4-quant prologue -> qkv+RoPE+KV-write / "
+                                     "gate_up+silu*up and o_proj / down_proj + residual add where built, the plain (xq, xs) forms otherwise)",
                            "launches": n, "avg_launch_us": round(tot_t / n * 1e6, 2),
                            "bytes_per_launch_avg": int(tot_b / n), "per_shape": per_shape}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

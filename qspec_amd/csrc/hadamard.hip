@@ -718,18 +718,19 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
                 }
             }
         } else {
-            for (int j2 = tid; j2 < P / 2; j2 += NT) {
-                for (int i = 0; i < K; i++) {
-                    float a0 = 0.0f, a1 = 0.0f;
-                    for (int k = 0; k < K; k++) {
-                        float h = had[i * K + k];
-                        f16x2 yy = *reinterpret_cast<const f16x2*>(ylds + (size_t)k * P + 2 * j2);
-                        a0 = __builtin_fmaf(h, h2f(yy[0]), a0);
-                        a1 = __builtin_fmaf(h, h2f(yy[1]), a1);
-                    }
-                    f16x2 zz = {f2h(a0), f2h(a1)};
-                    *reinterpret_cast<f16x2*>(zlds + (size_t)i * P + 2 * j2) = zz;
+            // generic table (had108, had40, ...): (output row, column pair) items over all threads -- with the column
+            // pairs alone only P/2 threads would work (64 of 1024 for 13824 = 108 x 128)
+            for (int item = tid; item < K * (P / 2); item += NT) {
+                const int i = item / (P / 2), j2 = item - i * (P / 2);
+                float a0 = 0.0f, a1 = 0.0f;
+                for (int k = 0; k < K; k++) {
+                    float h = had[i * K + k];
+                    f16x2 yy = *reinterpret_cast<const f16x2*>(ylds + (size_t)k * P + 2 * j2);
+                    a0 = __builtin_fmaf(h, h2f(yy[0]), a0);
+                    a1 = __builtin_fmaf(h, h2f(yy[1]), a1);
                 }
+                f16x2 zz = {f2h(a0), f2h(a1)};
+                *reinterpret_cast<f16x2*>(zlds + (size_t)i * P + 2 * j2) = zz;
             }
         }
         __syncthreads();
