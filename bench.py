@@ -289,6 +289,11 @@ def main():
                                f"prompt_len={args.prompt_len} greedy, synthetic int4 weights (SURVEY 8d), {agree_txt}; "
                                f"1 step = 1 cycle = {args.k} draft fwd + 1 verify fwd + rejection sampling",
                    "num_speculative_tokens": args.k, "batch": args.batch, "parallelism": f"tp{world}",
+                   "tp_plan": (None if world == 1 else
+                               ("verify pass: o_proj/gate_up/down_proj sharded (3 collectives per layer) + vocab-parallel lm_head"
+                                if model.tp.shard_layers else
+                                "verify pass: vocab-parallel lm_head + all-gather; decoder layers replicated (their collectives "
+                                "would cost more than the weight stream they save at this size); draft pass replicated")),
                    "agreement": rho},
         "draft_acceptance_rate": round(rate, 4), "system_efficiency": round(eff, 4),
         "accepted_tokens": acc, "emitted_tokens": emit, "draft_tokens": draft,

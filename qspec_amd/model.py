@@ -217,7 +217,8 @@ class QuarotLlamaForCausalLM:
         row = cfg.q_size + 2 * cfg.kv_size
         fuse = cfg.head_dim == 128 and (w4a4 or T <= self.BIG_M)   # fused GEMM epilogues (decode-sized M)
         # tensor parallelism only on the verify pass at decode-sized M; the draft pass and prefill run replicated
-        tp_on = self.tp is not None and self.tp.world > 1 and not w4a4 and fuse and T <= 32
+        tp_on = (self.tp is not None and self.tp.world > 1 and getattr(self.tp, "shard_layers", True) and not w4a4
+                 and fuse and T <= 32)
         act = s.act_buffer_had_mlp[:T]                            # silu(gate)*up, [T, I]
         nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         # draft pass at decode-sized M: residual add + LN + int4 quant run in the prologue of the qkv / gate_up GEMM

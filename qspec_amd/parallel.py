@@ -38,10 +38,35 @@ def shard_range(n: int, world: int, rank: int, align: int) -> Tuple[int, int]:
     return lo * align, hi * align
 
 
+# Planning constants for shard_layers_pays(): what a CU-saturating weight stream reaches on MI355X (measured)
+# and a conservative cost of one small RCCL collective inside the captured graph (128-460 KB over xGMI: latency-bound;
+# NOT measured here -- no multi-GPU box in this round; QSPEC_TP_LAYERS=0/1 overrides the plan).
+STREAM_BYTES_PER_US = 4.5e6
+COLLECTIVE_US = {2: 12.0, 4: 18.0, 8: 25.0}
+
+
+def shard_layers_pays(layer_weight_bytes: int, world: int) -> bool:
+    """Sharding the verify pass's o_proj / gate_up / down_proj costs three collectives per layer and saves
+    (1 - 1/world) of the layer's weight stream.  At decode-sized M that only pays when the layer is big:
+    Llama-3-8B: 109 MB -> 12-21 us saved against 36-75 us of collectives (replicated layers, vocab-parallel lm_head
+    only); Llama-3-70B at 8 GPUs: 436 MB -> 85 us saved against ~75 us."""
+    import os
+    forced = os.environ.get("QSPEC_TP_LAYERS")
+    if forced is not None:
+        return forced != "0"
+    if world < 2:
+        return False
+    t_coll = COLLECTIVE_US.get(world, 12.0 + 2.0 * world)
+    saved = layer_weight_bytes * (1.0 - 1.0 / world) / STREAM_BYTES_PER_US
+    return saved > 3.0 * t_coll
+
+
 class TensorParallel:
-    def __init__(self, rank: int, world: int, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, rank: int, world: int, group: Optional[dist.ProcessGroup] = None, shard_layers: bool = True):
         self.rank, self.world, self.group = rank, world, group
         self.backend = dist.get_backend(group) if world > 1 else "none"
+        # False: the decoder layers of the verify pass stay replicated (no collectives); lm_head stays vocab-parallel
+        self.shard_layers = shard_layers
 
     def k_range(self, K: int) -> Tuple[int, int]:
         """Row-parallel K range: multiples of 128 (one MFMA step of the W4A16 kernel)."""
@@ -100,5 +125,6 @@ def build_tp_model(cfg, device: str, world: int, rank: int, seed: int = 0, lm_he
     """Same synthetic weights on every rank (same seed), TP context attached."""
     from .model import QuarotLlamaForCausalLM
     m = QuarotLlamaForCausalLM(cfg, device).init_synthetic(seed, lm_head_std)
-    m.tp = TensorParallel(rank, world, None)
+    layer_bytes = sum(lin.weight.numel() for lin in m.layers[0].linears())
+    m.tp = TensorParallel(rank, world, None, shard_layers=shard_layers_pays(layer_bytes, world))
     return m

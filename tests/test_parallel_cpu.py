@@ -64,3 +64,17 @@ def test_gloo_world2_collectives():
         ok1, ok2, ok3, _ = ret[r]
         assert ok1 and ok2 and ok3, (r, ret[r])
     assert ret[0][3] != ret[1][3] and ret[0][3][1] == ret[1][3][0]
+
+
+def test_tp_plan_shards_layers_only_when_it_pays(monkeypatch):
+    """Llama-3-8B layers (109 MB) stay replicated at every world size; Llama-3-70B layers (436 MB) shard at 8."""
+    from qspec_amd.parallel import shard_layers_pays
+    monkeypatch.delenv("QSPEC_TP_LAYERS", raising=False)
+    l8b = (6144 + 4096 + 28672) * 2048 + 4096 * 7168
+    l70b = (10240 + 8192 + 57344) * 4096 + 8192 * 14336
+    assert not any(shard_layers_pays(l8b, w) for w in (1, 2, 4, 8))
+    assert shard_layers_pays(l70b, 8) and not shard_layers_pays(l70b, 1)
+    monkeypatch.setenv("QSPEC_TP_LAYERS", "1")
+    assert shard_layers_pays(l8b, 2)
+    monkeypatch.setenv("QSPEC_TP_LAYERS", "0")
+    assert not shard_layers_pays(l70b, 8)
