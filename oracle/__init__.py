@@ -349,3 +349,12 @@ def advance_step(input_tokens, sampled, positions, seq_lens, slot_mapping, block
         seq_lens[i] = nsl
         positions[i] = nsl - 1
         slot_mapping[i] = block_tables[i, (nsl - 1) // block_size] * block_size + (nsl - 1) % block_size
+
+
+def count_div3_mismatches(s_lo: int, s_hi: int) -> int:
+    """Exhaustive check of the HIP quantisers' three-instruction h(x / s) (common.cuh:div3_h) against the fp16
+    rounding of the correctly rounded fp32 quotient, for scales with fp16 bit patterns in [s_lo, s_hi) and every
+    non-negative finite fp16 x."""
+    f = lib().qo_count_div3_mismatches
+    f.restype = ctypes.c_longlong
+    return int(f(c_int(s_lo), c_int(s_hi)))

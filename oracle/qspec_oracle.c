@@ -512,3 +512,24 @@ void qo_softmax_argmax(const uint16_t* logits, int T, int V, float* probs, int64
         token[t] = am;
     }
 }
+
+/* Test support for qspec_amd/csrc/common.cuh:div3_h -- the three-instruction form of h(x / s) used by the HIP
+ * quantisers (x, s fp16 values): counts the pairs (s in [s_lo, s_hi) as fp16 bit patterns, every non-negative finite
+ * fp16 x; the expression is odd in x) whose fp16 result differs from h(fl32(x / s)), the reference's __hdiv
+ * (third-party/QuaRot/quarot/kernels/quant.cu:147).  Expected: 0 for every positive finite s. */
+long long qo_count_div3_mismatches(int s_lo, int s_hi) {
+    long long bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(dynamic, 64)
+    for (int si = s_lo; si < s_hi; si++) {
+        const float s = h2f((uint16_t)si);
+        const float r = 1.0f / s;
+        for (int xi = 0; xi < 0x7C00; xi++) {
+            const float x = h2f((uint16_t)xi);
+            const float q0 = x * r;
+            const float rem = fmaf(-q0, s, x);
+            const float q1 = fmaf(rem, r, q0);
+            bad += f2h(x / s) != f2h(q1);
+        }
+    }
+    return bad;
+}

@@ -54,6 +54,17 @@ __device__ __forceinline__ float qexpf(float x) {
 }
 
 // round-to-nearest-even to integer with saturation, NaN -> 0
+// x / s rounded to fp16, for x and s that are fp16 VALUES (the quantisers: h(x / scale), quant.cu:147), in three
+// instructions: q0 = x * r, q1 = q0 + (x - q0 * s) * r with r = 1 / s correctly rounded (once per row).  The fp16
+// rounding of q1 equals the fp16 rounding of the correctly rounded fp32 quotient for EVERY pair of finite fp16 x and
+// positive finite fp16 s -- checked exhaustively (2^30 pairs) by tests/test_oracle_golden.py::test_three_op_fp16_division;
+// s = 0 (all-zero row) gives NaN like 0 / 0 does.  (An IEEE fp32 division is ~11 instructions.)
+__device__ __forceinline__ float div3_h(float x, float r, float s) {
+    const float q0 = x * r;
+    const float rem = __builtin_fmaf(-q0, s, x);
+    return __builtin_fmaf(rem, r, q0);
+}
+
 __device__ __forceinline__ int rni_sat(float v, int lo, int hi) {
     if (v != v) return 0;
     float r = __builtin_rintf(v);

@@ -197,12 +197,13 @@ __global__ __launch_bounds__(128) void heads_hadamard_kernel(const f16* __restri
     }
     const f16 sc = f2h(h2f(f2h(amax / 7.0f)) * h2f(f2h(clip)));
     const float scf = h2f(sc);
+    const float rcf = 1.0f / scf;   // correctly rounded reciprocal for div3_h
     if (j == 0) scale[t] = sc;
     if (!act) return;
 #pragma unroll
     for (int h = 0; h < NH; h++) {
-        int q0 = rni_sat(h2f(f2h(v0[h] / scf)), -8, 7);
-        int q1 = rni_sat(h2f(f2h(v1[h] / scf)), -8, 7);
+        int q0 = rni_sat(h2f(f2h(div3_h(v0[h], rcf, scf))), -8, 7);
+        int q1 = rni_sat(h2f(f2h(div3_h(v1[h], rcf, scf))), -8, 7);
         q[(size_t)t * (NH * d / 2) + (size_t)h * (d / 2) + j] = (int8_t)pack_nib(q0, q1);
     }
 }
@@ -298,11 +299,12 @@ __global__ __launch_bounds__(NH * 8) void heads_hadamard_wide_kernel(const f16* 
     for (int j = 1; j < HG; j++) amax = fmaxf(amax, red[j]);
     const f16 sc = f2h(h2f(f2h(amax / 7.0f)) * h2f(f2h(clip)));
     const float scf = h2f(sc);
+    const float rcf = 1.0f / scf;   // correctly rounded reciprocal for div3_h
     if (tid == 0) scale[t] = sc;
 #pragma unroll
     for (int h = 0; h < 8; h++) {
-        int q0 = rni_sat(h2f(f2h(v0[h] / scf)), -8, 7);
-        int q1 = rni_sat(h2f(f2h(v1[h] / scf)), -8, 7);
+        int q0 = rni_sat(h2f(f2h(div3_h(v0[h], rcf, scf))), -8, 7);
+        int q1 = rni_sat(h2f(f2h(div3_h(v1[h], rcf, scf))), -8, 7);
         q[(obase + (size_t)h * D) / 2] = (int8_t)pack_nib(q0, q1);
     }
 }
@@ -459,11 +461,12 @@ __global__ __launch_bounds__(1024) void heads_hadamard_merge_kernel(const float*
     for (int j = 1; j < HG; j++) amax = fmaxf(amax, red[j]);
     const f16 sc = f2h(h2f(f2h(amax / 7.0f)) * h2f(f2h(clip)));
     const float scf = h2f(sc);
+    const float rcf = 1.0f / scf;   // correctly rounded reciprocal for div3_h
     if (tid == 0) scale[t] = sc;
 #pragma unroll
     for (int h = 0; h < 8; h++) {
-        int q0 = rni_sat(h2f(f2h(v0[h] / scf)), -8, 7);
-        int q1 = rni_sat(h2f(f2h(v1[h] / scf)), -8, 7);
+        int q0 = rni_sat(h2f(f2h(div3_h(v0[h], rcf, scf))), -8, 7);
+        int q1 = rni_sat(h2f(f2h(div3_h(v1[h], rcf, scf))), -8, 7);
         q[(obase + (size_t)h * D) / 2] = (int8_t)pack_nib(q0, q1);
     }
 }
@@ -761,13 +764,14 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
     for (int w = 1; w < NW; w++) amax = fmaxf(amax, red[w]);
     const f16 sc = f2h(h2f(f2h(amax / 7.0f)) * h2f(f2h(clip)));
     const float scf = h2f(sc);
+    const float rcf = 1.0f / scf;   // correctly rounded reciprocal for div3_h
     if (tid == 0) scale[t] = sc;
     for (int i = tid; i < nvec; i += NT) {
         f16x8 a = *reinterpret_cast<const f16x8*>(zsrc + 8 * i);
         uint32_t w = 0;
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-            int v = rni_sat(h2f(f2h(h2f(a[c]) / scf)), -8, 7);
+            int v = rni_sat(h2f(f2h(div3_h(h2f(a[c]), rcf, scf))), -8, 7);
             w |= (uint32_t)(v & 0xF) << (4 * c);
         }
         *reinterpret_cast<uint32_t*>(q + (size_t)t * (I / 2) + 4 * i) = w;

@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void rowabsmax_quant_kernel(const f16* __restr
     amax = block_max_256(amax, red);
     const f16 sc = f2h(h2f(f2h(amax / 7.0f)) * h2f(f2h(clip)));
     const float scf = h2f(sc);
+    const float rcf = 1.0f / scf;   // correctly rounded reciprocal for div3_h
     if (j == 0) scale[row] = sc;
     int8_t* qr = q + (size_t)row * (K / 2);
     for (int i = j; i < nvec; i += 256) {
@@ -263,15 +264,15 @@ __global__ __launch_bounds__(256) void rowabsmax_quant_kernel(const f16* __restr
         uint32_t w = 0;
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-            float d = h2f(f2h(h2f(a[c]) / scf));
+            float d = h2f(f2h(div3_h(h2f(a[c]), rcf, scf)));
             int v = rni_sat(d, -8, 7);
             w |= (uint32_t)(v & 0xF) << (4 * c);
         }
         *reinterpret_cast<uint32_t*>(qr + 4 * i) = w;
     }
     for (int i = nvec * 4 + j; i < K / 2; i += 256) {
-        int v0 = rni_sat(h2f(f2h(h2f(xr[2 * i]) / scf)), -8, 7);
-        int v1 = rni_sat(h2f(f2h(h2f(xr[2 * i + 1]) / scf)), -8, 7);
+        int v0 = rni_sat(h2f(f2h(div3_h(h2f(xr[2 * i]), rcf, scf))), -8, 7);
+        int v1 = rni_sat(h2f(f2h(div3_h(h2f(xr[2 * i + 1]), rcf, scf))), -8, 7);
         qr[i] = (int8_t)pack_nib(v0, v1);
     }
 }

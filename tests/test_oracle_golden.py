@@ -152,3 +152,10 @@ def test_rowabsmax_edge_rows(oracle):
     assert (u[0] == 0).all() and scale[0] == 0
     assert scale[1] == np.float16(1.0) and u[1, 0] == -7 and u[1, -1] == 7
     assert list(u[2, :5]) == [4, 2, -2, -4, 7]
+
+
+def test_three_op_fp16_division_is_exact_for_every_fp16_pair(oracle):
+    """The HIP quantisers compute h(x / scale) as q0 = x*r, q1 = q0 + (x - q0*s)*r with r = 1/s (common.cuh:div3_h).
+    For fp16-valued x and s that is the fp16 rounding of the IEEE quotient for EVERY pair: all 31743 positive finite
+    scales x all 31744 non-negative finite x (the expression is odd in x), 10^9 pairs."""
+    assert oracle.count_div3_mismatches(1, 0x7C00) == 0
