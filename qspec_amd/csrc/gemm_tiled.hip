@@ -44,8 +44,10 @@ __device__ __forceinline__ f16x8 tshuffle_act8(u32x4 a) {  // 8 consecutive fp16
 
 #define QS_T_STAGE_K 128                    // k per activation stage = 2 weight steps of 64 k
 
-// RING = weight steps (64 k each, 16 B per lane) in flight per wave: 8 (K % 512 == 0) or 4 (K % 256 == 0).
-template <int MT, int RING>
+// RING = weight steps (64 k each, 16 B per lane and weight tile) in flight per wave: 8 (K % 512 == 0) or 4 (K % 256 == 0).
+// NT = 32-row weight tiles per wave (workgroup = 128 * NT weight rows): with 2, every activation fragment read from LDS
+// feeds two MFMAs -- the LDS read per MFMA is what bounds the NT = 1 form at large M.
+template <int MT, int RING, int NT>
 __global__ __launch_bounds__(256) void gemm_w4a16_tiled_kernel(const f16* __restrict__ x, const uint8_t* __restrict__ wq,
                                                                 const f16* __restrict__ ws, f16* __restrict__ out,
                                                                 float* __restrict__ part, int M, int N, int K, int Ks) {
@@ -58,11 +60,12 @@ __global__ __launch_bounds__(256) void gemm_w4a16_tiled_kernel(const f16* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = lane & 31, kg = lane >> 5;
-    const int n0 = blockIdx.x * 128 + wave * 32, m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * (128 * NT) + wave * (32 * NT), m0 = blockIdx.y * BM;
     const int Kb = K >> 1;
     const int nrounds = Ks / (64 * RING);                  // this workgroup's K slice: [blockIdx.z * Ks, + Ks)
     const int k0 = blockIdx.z * Ks;
-    const uint8_t* wrow = wq + (size_t)(n0 + nl) * Kb + (k0 >> 1) + kg * 16;     // step s: + 32 * s bytes (64 k)
+    const uint8_t* wrow = wq + (size_t)(n0 + nl) * Kb + (k0 >> 1) + kg * 16;     // step s: + 32 s bytes; tile nt: + 32 nt rows
+    const size_t tstride = (size_t)32 * Kb;
     x += k0;
 
     // activation stage: coalesced 16-byte loads, stored k-shuffled (order of the dequantiser) and chunk-swizzled
@@ -83,33 +86,41 @@ __global__ __launch_bounds__(256) void gemm_w4a16_tiled_kernel(const f16* __rest
             *reinterpret_cast<f16x8*>(b + (size_t)row * ROWB + ((q ^ (row & 15)) << 4)) = tshuffle_act8(areg[i]);
         }
     };
-    f32x16 acc[MT];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[mt][i] = 0.0f;
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[mt][nt][i] = 0.0f;
 
     a_load(0);
-    u32x4 w[RING];
+    u32x4 w[RING][NT];
 #pragma unroll
-    for (int u = 0; u < RING; u++) w[u] = *reinterpret_cast<const u32x4*>(wrow + (size_t)u * 32);
+    for (int u = 0; u < RING; u++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) w[u][nt] = *reinterpret_cast<const u32x4*>(wrow + nt * tstride + (size_t)u * 32);
     a_store(0);
     __syncthreads();
 
     // one stage = 2 weight steps; lane (weight row nl, k-group kg), step j, dword dd <-> k = 64 j + 32 kg + 8 dd
-    auto stage_compute = [&](int buf, const u32x4& w0, const u32x4& w1) {
+    auto stage_compute = [&](int buf, const u32x4 (&w0)[NT], const u32x4 (&w1)[NT]) {
         const unsigned char* b = smem + (size_t)buf * BM * ROWB;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
 #pragma unroll
             for (int dd = 0; dd < 4; dd++) {
-                const f16x8 bf = tdequant_s4x8(j == 0 ? w0[dd] : w1[dd]);
+                f16x8 bf[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) bf[nt] = tdequant_s4x8(j == 0 ? w0[nt][dd] : w1[nt][dd]);
                 const int q = j * 8 + kg * 4 + dd;
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
                     const int row = mt * 32 + nl;
                     const f16x8 av = *reinterpret_cast<const f16x8*>(b + (size_t)row * ROWB + ((q ^ (row & 15)) << 4));
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bf, acc[mt], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bf[nt], acc[mt][nt], 0, 0, 0);
                 }
             }
         }
@@ -122,8 +133,11 @@ __global__ __launch_bounds__(256) void gemm_w4a16_tiled_kernel(const f16* __rest
             a_load(r * NS + s + 1);                       // next stage's activations fly under this stage's MFMAs
             stage_compute(s & 1, w[2 * s], w[2 * s + 1]);
             __builtin_amdgcn_sched_barrier(0);
-            w[2 * s] = *reinterpret_cast<const u32x4*>(wnext + (size_t)(2 * s) * 32);
-            w[2 * s + 1] = *reinterpret_cast<const u32x4*>(wnext + (size_t)(2 * s + 1) * 32);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                w[2 * s][nt] = *reinterpret_cast<const u32x4*>(wnext + nt * tstride + (size_t)(2 * s) * 32);
+                w[2 * s + 1][nt] = *reinterpret_cast<const u32x4*>(wnext + nt * tstride + (size_t)(2 * s + 1) * 32);
+            }
             __builtin_amdgcn_sched_barrier(0);
             a_store((s & 1) ^ 1);
             __syncthreads();
@@ -145,20 +159,25 @@ __global__ __launch_bounds__(256) void gemm_w4a16_tiled_kernel(const f16* __rest
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int m = m0 + mt * 32 + (i >> 2) * 8 + kg * 4 + (i & 3);
-                if (m < M) pz[(size_t)m * N + n0 + nl] = acc[mt][i];
-            }
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int m = m0 + mt * 32 + (i >> 2) * 8 + kg * 4 + (i & 3);
+                    if (m < M) pz[(size_t)m * N + n0 + nt * 32 + nl] = acc[mt][nt][i];
+                }
         return;
     }
-    const float swn = h2f(ws[n0 + nl]);
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++)
+    for (int nt = 0; nt < NT; nt++) {
+        const float swn = h2f(ws[n0 + nt * 32 + nl]);
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int m = m0 + mt * 32 + (i >> 2) * 8 + kg * 4 + (i & 3);
-            if (m < M) out[(size_t)m * N + n0 + nl] = f2h(acc[mt][i] * swn);
-        }
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int m = m0 + mt * 32 + (i >> 2) * 8 + kg * 4 + (i & 3);
+                if (m < M) out[(size_t)m * N + n0 + nt * 32 + nl] = f2h(acc[mt][nt][i] * swn);
+            }
+    }
 }
 
 bool gemm_w4a16_tiled_supported(int M, int N, int K) { return M >= 1 && N % 128 == 0 && K % 256 == 0 && K >= 512; }
@@ -206,20 +225,28 @@ int gemm_w4a16_tiled(const f16* x, const int8_t* wq, const f16* ws, f16* out, in
     if (!gemm_w4a16_tiled_supported(M, N, K)) return -1;
     int MT, S;
     gemm_w4a16_tiled_plan(M, N, K, part ? part_bytes : 0, &MT, &S);
-    const dim3 grid(N / 128, (M + 32 * MT - 1) / (32 * MT), S);
+    // two weight tiles per wave when that still leaves two workgroups per CU (large M): halves the LDS reads per MFMA
+    static const int force_nt = env_int("QSPEC_TILED_NT", 0);
+    const int mblocks = (M + 32 * MT - 1) / (32 * MT);
+    int NT = (N % 256 == 0 && (long long)(N / 256) * mblocks * S >= 512) ? 2 : 1;
+    if (force_nt == 1 || (force_nt == 2 && N % 256 == 0)) NT = force_nt;
+    const dim3 grid(N / (128 * NT), mblocks, S);
     const size_t lds = (size_t)2 * 32 * MT * (QS_T_STAGE_K * 2);   // <= 64 KiB
     const uint8_t* w8 = reinterpret_cast<const uint8_t*>(wq);
-    const bool r8 = K % 512 == 0;
+    const bool r8 = K % 512 == 0 && NT == 1;   // two tiles per wave: 4 steps in flight (the registers go to the accumulators)
     float* p = S > 1 ? part : nullptr;
     const int Ks = K / S;
 #define QS_TILED(MTV)                                                                                                   \
     case MTV:                                                                                                           \
-        if (r8)                                                                                                         \
-            hipLaunchKernelGGL((gemm_w4a16_tiled_kernel<MTV, 8>), grid, dim3(256), lds, st, x, w8, ws, out, p, M, N, K, \
-                               Ks);                                                                                     \
+        if (NT == 2)                                                                                                    \
+            hipLaunchKernelGGL((gemm_w4a16_tiled_kernel<MTV, 4, 2>), grid, dim3(256), lds, st, x, w8, ws, out, p, M, N, \
+                               K, Ks);                                                                                  \
+        else if (r8)                                                                                                    \
+            hipLaunchKernelGGL((gemm_w4a16_tiled_kernel<MTV, 8, 1>), grid, dim3(256), lds, st, x, w8, ws, out, p, M, N, \
+                               K, Ks);                                                                                  \
         else                                                                                                            \
-            hipLaunchKernelGGL((gemm_w4a16_tiled_kernel<MTV, 4>), grid, dim3(256), lds, st, x, w8, ws, out, p, M, N, K, \
-                               Ks);                                                                                     \
+            hipLaunchKernelGGL((gemm_w4a16_tiled_kernel<MTV, 4, 1>), grid, dim3(256), lds, st, x, w8, ws, out, p, M, N, \
+                               K, Ks);                                                                                  \
         break;
     switch (MT) {
         QS_TILED(1) QS_TILED(2) QS_TILED(3) QS_TILED(4)
