@@ -498,6 +498,194 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------- prompt-sized queries (flash-attn varlen, head 128)
+// The kernel above keeps 16 rows per workgroup: right for decode (1 .. k+1 query tokens per sequence), but a prompt pass
+// would stream K/V once per 4 query tokens.  Here a workgroup holds 64 rows (16 query tokens x the GQA group of one kv
+// head), 16 per wave, and walks the visible keys in 64-key chunks (FlashAttention-2 form):
+//   * the chunk's K and V go through LDS once per workgroup (K rows XOR-swizzled in 16-byte pieces for the fragment
+//     reads, V rows padded for the transposing reads); the next chunk's rows are in flight in registers meanwhile;
+//   * a wave's S = Q K^T (16 x 64), its running (max, sum) and its 16 x 128 output live in registers; only P goes
+//     through a wave-private LDS tile to change from the accumulator layout to the A-operand layout (as hi + lo fp16,
+//     two MFMAs, so that P.V keeps fp32-class accuracy);
+//   * no context split: one (o, m, l) per row, stored as the single-split partial heads_hadamard_merge expects and/or
+//     normalised into `out`.
+#define QS_FA_ROWS 64
+#define QS_FA_KEYS 64
+__global__ __launch_bounds__(256) void paged_attention_prefill_kernel(
+    const f16* __restrict__ q, int64_t q_stride, const f16* __restrict__ key_cache, const f16* __restrict__ value_cache,
+    const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
+    const int32_t* __restrict__ q_start, int nq, int nkv, int bs_log2, int group_log2, float sm_scale, int n_rb,
+    float* __restrict__ ws_o, float* __restrict__ ws_ml, f16* __restrict__ out) {
+    constexpr int D = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned char* kl = reinterpret_cast<unsigned char*>(smem_raw);                       // [64 keys][256 B], swizzled
+    f16* vl = reinterpret_cast<f16*>(kl + QS_FA_KEYS * 256);                               // [64 keys][QS_ATT_VSTRIDE]
+    f16* pl_all = vl + QS_FA_KEYS * QS_ATT_VSTRIDE;                                        // [4 waves][hi, lo][16][72]
+    constexpr int PSTR = 72;   // halves per P row (144 B): the 16 rows of an A-fragment read fall on distinct banks
+    const int seq = blockIdx.x, kvh = blockIdx.y / n_rb, rb = blockIdx.y % n_rb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int gmask = (1 << group_log2) - 1, bmask = (1 << bs_log2) - 1;
+    int meta = 0;
+    if (lane < 3) meta = lane < 2 ? q_start[seq + lane] : ctx_lens[seq];
+    const int qs = __shfl(meta, 0, 64), qlen = __shfl(meta, 1, 64) - qs;
+    const int ctx = __shfl(meta, 2, 64);
+    const int total_rows = qlen << group_log2;
+    if (rb * QS_FA_ROWS >= total_rows) return;   // uniform
+    const int rbase = rb * QS_FA_ROWS + wave * 16;
+    f16* pl = pl_all + wave * 2 * 16 * PSTR;
+    const int32_t* bt = block_tables + (size_t)seq * max_blocks;
+
+    // causal horizon of the workgroup: the last valid row's token sees keys 0 .. pos
+    const int last_row = min(rb * QS_FA_ROWS + QS_FA_ROWS - 1, total_rows - 1);
+    const int n_keys = min(ctx, ctx - qlen + (last_row >> group_log2) + 1);
+    const int n_chunks = (n_keys + QS_FA_KEYS - 1) / QS_FA_KEYS;
+
+    // Q fragments: lane (row c16, d slice 8 g4 + 32 j); rows past the end repeat the last valid row (never stored)
+    u32x4 qfrag[4];
+    {
+        const int r = min(rbase + c16, total_rows - 1);
+        const f16* qp = q + (size_t)(qs + (r >> group_log2)) * q_stride + (size_t)((kvh << group_log2) + (r & gmask)) * D + g4 * 8;
+#pragma unroll
+        for (int j = 0; j < 4; j++) qfrag[j] = *reinterpret_cast<const u32x4*>(qp + 32 * j);
+    }
+    // positions of this lane's accumulator rows (4 g4 + reg)
+    int pos[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int rr = rbase + 4 * g4 + reg;
+        pos[reg] = rr < total_rows ? ctx - qlen + (rr >> group_log2) : -1;
+    }
+    float row_m[4], row_l[4];
+    f32x4 o[8];
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        row_m[reg] = -__builtin_inff();
+        row_l[reg] = 0.0f;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 8; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: thread (key = tid / 4, quarter = tid % 4) moves 64 B of the key's K row and of its V row
+    const int skey = tid >> 2, spart = tid & 3;
+    u32x4 kreg[4], vreg[4];
+    auto stage_load = [&](int kb) {   // unconditional, clamped (no load behind a branch)
+        const int p = min(kb + skey, ctx - 1);
+        const int64_t slot = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
+        const f16* kp = key_cache + (slot * nkv + kvh) * D + spart * 32;
+        const f16* vp = value_cache + (slot * nkv + kvh) * D + spart * 32;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            kreg[i] = *reinterpret_cast<const u32x4*>(kp + 8 * i);
+            vreg[i] = *reinterpret_cast<const u32x4*>(vp + 8 * i);
+        }
+    };
+    stage_load(0);
+    for (int c = 0; c < n_chunks; c++) {
+        const int kb = c * QS_FA_KEYS;
+        const int nk = min(n_keys - kb, QS_FA_KEYS);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int ci = spart * 4 + i;
+            *reinterpret_cast<u32x4*>(kl + skey * 256 + ((ci ^ (skey & 15)) << 4)) = kreg[i];
+            const u32x4 vz = skey < nk ? vreg[i] : u32x4{0, 0, 0, 0};   // zero rows keep the MFMA clean
+            *reinterpret_cast<u32x4*>(vl + skey * QS_ATT_VSTRIDE + ci * 8) = vz;
+        }
+        __syncthreads();
+        stage_load(kb + QS_FA_KEYS);   // next chunk underneath this one (clamped re-read behind the last chunk)
+
+        // ---- S = Q K^T for the wave's 16 rows x 64 keys: lane holds rows 4 g4 + reg, key column t * 16 + c16
+        f32x4 sacc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int row = t * 16 + c16;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(kl + row * 256 + (((g4 + 4 * j) ^ (row & 15)) << 4));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, qfrag[j]),
+                                                             __builtin_bit_cast(f16x8, kf), acc, 0, 0, 0);
+            }
+            const int p = kb + t * 16 + c16;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) sacc[t][reg] = p <= pos[reg] ? acc[reg] * sm_scale : -__builtin_inff();
+        }
+        // ---- online softmax per row: the 16 lanes of a g4 group hold the 64 keys of rows 4 g4 + reg
+        float alpha[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            float mx = fmaxf(fmaxf(sacc[0][reg], sacc[1][reg]), fmaxf(sacc[2][reg], sacc[3][reg]));
+            mx = fmaxf(mx, dpp_xor<8>(mx));
+            mx = fmaxf(mx, dpp_xor<4>(mx));
+            mx = fmaxf(mx, dpp_xor<2>(mx));
+            mx = fmaxf(mx, dpp_xor<1>(mx));
+            const float m_old = row_m[reg], m_new = fmaxf(m_old, mx);
+            float sum = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float pv = m_new == -__builtin_inff() ? 0.0f : qexpf(sacc[t][reg] - m_new);
+                const f16 ph = f2h(pv);
+                pl[(4 * g4 + reg) * PSTR + t * 16 + c16] = ph;
+                pl[(16 + 4 * g4 + reg) * PSTR + t * 16 + c16] = f2h(pv - h2f(ph));
+                sum += pv;
+            }
+            sum += dpp_xor<8>(sum);
+            sum += dpp_xor<4>(sum);
+            sum += dpp_xor<2>(sum);
+            sum += dpp_xor<1>(sum);
+            alpha[reg] = m_old == -__builtin_inff() ? 0.0f : qexpf(m_old - m_new);
+            row_m[reg] = m_new;
+            row_l[reg] = __builtin_fmaf(row_l[reg], alpha[reg], sum);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 8; dt++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) o[dt][reg] *= alpha[reg];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own P tile: LDS is in order per wave
+        // ---- O += P V: A = P (row c16, keys st * 32 + 8 g4 ..), B = V[keys][d0 + c16] through the transposing read
+        {
+            const uint32_t vl_base = (uint32_t)(uintptr_t)vl;
+            const int qd = c16 >> 2, pq = c16 & 3;
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                const f16x8 pa = *reinterpret_cast<const f16x8*>(pl + c16 * PSTR + st * 32 + g4 * 8);
+                const f16x8 pb = *reinterpret_cast<const f16x8*>(pl + (16 + c16) * PSTR + st * 32 + g4 * 8);
+                const int krow = st * 32 + g4 * 8 + qd;
+#pragma unroll
+                for (int dt = 0; dt < 8; dt++) {
+                    const uint32_t a0 = vl_base + (uint32_t)((krow * QS_ATT_VSTRIDE + dt * 16 + 4 * pq) * 2);
+                    const u32x2 lo = lds_read_tr_b16(a0);
+                    const u32x2 hi = lds_read_tr_b16(a0 + 4 * QS_ATT_VSTRIDE * 2);
+                    const u32x4 bw = {lo[0], lo[1], hi[0], hi[1]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();   // kl / vl are rewritten by the next chunk
+    }
+    // ---- results: lane holds rows 4 g4 + reg, columns dt * 16 + c16
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int rr = rbase + 4 * g4 + reg;
+        if (rr < total_rows) {
+            const size_t th = (size_t)(qs + (rr >> group_log2)) * nq + (kvh << group_log2) + (rr & gmask);
+            if (ws_o) {
+#pragma unroll
+                for (int dt = 0; dt < 8; dt++) ws_o[th * D + dt * 16 + c16] = o[dt][reg];
+                if (c16 == 0) {
+                    ws_ml[th * 2] = row_m[reg];
+                    ws_ml[th * 2 + 1] = row_l[reg];
+                }
+            }
+            if (out) {
+#pragma unroll
+                for (int dt = 0; dt < 8; dt++) out[th * D + dt * 16 + c16] = f2h(o[dt][reg] / row_l[reg]);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- generic head size (plumbing path)
 // Any head_size <= 256 (TinyLlama: 64).  One 128-thread workgroup per (query token, head): scores of all visible keys
 // into LDS (fp32 dot products), one softmax over them, then thread j accumulates output dimension j over the keys in
@@ -591,6 +779,18 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
     if (n_splits < 1 || n_splits > QS_ATT_MAXSPLIT) return -3;
     const int bs_log2 = ilog2_exact(block_size), group_log2 = ilog2_exact(nq / nkv);
     if (bs_log2 < 0 || group_log2 < 0) return -5;  // block size and GQA group must be powers of two
+    static const int fa_env = getenv("QSPEC_ATTN_PREFILL") ? atoi(getenv("QSPEC_ATTN_PREFILL")) : 1;   // dev knob
+    if (fa_env && n_splits == 1 && (max_q_len << group_log2) >= 2 * QS_FA_ROWS) {   // prompt-sized queries
+        const int n_rb64 = ((max_q_len << group_log2) + QS_FA_ROWS - 1) / QS_FA_ROWS;
+        const size_t Tm = (size_t)n_seqs * max_q_len;
+        float* fo = ws + QS_ATT_CNT_SLOTS;
+        float* fml = fo + Tm * nq * d;
+        const size_t flds = (size_t)QS_FA_KEYS * 256 + (size_t)QS_FA_KEYS * QS_ATT_VSTRIDE * 2 + (size_t)4 * 2 * 16 * 72 * 2;
+        hipLaunchKernelGGL(paged_attention_prefill_kernel, dim3(n_seqs, nkv * n_rb64), dim3(256), flds, st, q, q_stride,
+                           key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv, bs_log2,
+                           group_log2, sm_scale, n_rb64, fo, fml, out);
+        return 0;
+    }
     const int n_rb = ((max_q_len << group_log2) + QS_ATT_MAXR - 1) / QS_ATT_MAXR;
     if (out && (size_t)n_seqs * nkv * n_rb > QS_ATT_CNT_SLOTS) return -4;   // ticket counters: in-kernel merge only
     // workspace: [ticket counters | o partials | (m,l) partials]; sized by the host for n_seqs*max_q_len tokens.

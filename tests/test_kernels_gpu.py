@@ -977,3 +977,42 @@ def test_w4a4_two_token_tiles_other_k(ops, oracle, M, N, K):
     ops.rowwise_scaled_linear_cutlass_s4s4_unified(dev(xq), dev(xs), dev(w), dev(ws), None, out[:M])
     assert np.array_equal(bits(host(out[:M])), bits(oracle.gemm_w4a4(xq, xs, w, ws)))
     assert torch.all(out[M] == 3.0)
+
+
+# ------------------------------------------------------------------ attention, prompt-sized queries (64-row flash kernel)
+
+@pytest.mark.parametrize("ctx_lens,q_lens,nq,nkv", [
+    ([300], [300], 32, 8),                  # one full prompt, ragged last row block and last key chunk
+    ([64, 129, 511], [64, 129, 511], 8, 2),  # several prompts of different lengths in one call
+    ([400, 90], [150, 33], 32, 8),           # chunked prefill: queries are the tail of a longer context
+    ([200], [200], 8, 8),                    # no GQA (group 1): 64 query tokens per workgroup
+    ([1030], [1030], 16, 4),
+])
+def test_paged_attention_prompt_sized_queries_within_1e3(ops, oracle, ctx_lens, q_lens, nq, nkv):
+    rng = np.random.default_rng(sum(ctx_lens) + nq)
+    d, bs = 128, 16
+    n_seqs = len(ctx_lens)
+    bt, kc, vc = make_paged(rng, n_seqs, ctx_lens, nkv, d, bs)
+    T = sum(q_lens)
+    row = (nq + 2 * nkv) * d
+    qkv = (rng.standard_normal((T, row)) * 0.5).astype(np.float16)
+    q_start = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    ctx = np.array(ctx_lens, np.int32)
+    scale = d ** -0.5
+    ref = oracle.paged_attention(qkv[:, : nq * d], kc, vc, bt, ctx, q_start, scale)
+    ws = torch.zeros(ops.paged_attention_workspace_bytes(n_seqs * max(q_lens), nq, d, 1), dtype=torch.uint8, device=DEV)
+    out = torch.full((T + 1, nq * d), 5.0, dtype=torch.float16, device=DEV)
+    ops.paged_attention(dev(qkv), row, dev(kc), dev(vc), dev(bt), dev(ctx), dev(q_start), T, max(q_lens), nq, scale, 1,
+                        ws, out[:T])
+    assert_close_1e3(host(out[:T]), ref)
+    assert torch.all(out[T] == 5.0)
+    # the un-merged form (single-split partials for the head-Hadamard launch) gives the same rows
+    if nq in (32,) and len(set(q_lens)) == 1:
+        ws2 = torch.zeros_like(ws)
+        ops.paged_attention(dev(qkv), row, dev(kc), dev(vc), dev(bt), dev(ctx), dev(q_start), T, max(q_lens), nq, scale,
+                            1, ws2, None)
+        had_a = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
+        ops.heads_hadamard_merged(ws2, n_seqs * max(q_lens), 1, T, nq, d, 0.1767, out_f16=had_a)
+        had_b = torch.empty_like(had_a)
+        ops.heads_hadamard(out[:T].contiguous(), 0.1767, out_f16=had_b, heads=nq)
+        assert torch.equal(had_a.view(torch.int16), had_b.view(torch.int16))
