@@ -164,6 +164,26 @@ __device__ __forceinline__ u32x2 lds_read_tr_b16(uint32_t lds_byte_addr) {
     return r;
 }
 
+// Eight d tiles of one 32-key step at once (the prompt kernel): 16 transposing reads from one base address with
+// immediate offsets (d tile: +32 B, second key quad: +4 V rows), ONE wait behind all of them.
+__device__ __forceinline__ void lds_read_tr_b16_x16(uint32_t a, u32x2 (&lo)[8], u32x2 (&hi)[8]) {
+    static_assert(QS_ATT_VSTRIDE * 8 == 1152, "immediate offsets below assume 288-byte V rows");
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %16 offset:0\n\tds_read_b64_tr_b16 %8, %16 offset:1152\n\t"
+        "ds_read_b64_tr_b16 %1, %16 offset:32\n\tds_read_b64_tr_b16 %9, %16 offset:1184\n\t"
+        "ds_read_b64_tr_b16 %2, %16 offset:64\n\tds_read_b64_tr_b16 %10, %16 offset:1216\n\t"
+        "ds_read_b64_tr_b16 %3, %16 offset:96\n\tds_read_b64_tr_b16 %11, %16 offset:1248\n\t"
+        "ds_read_b64_tr_b16 %4, %16 offset:128\n\tds_read_b64_tr_b16 %12, %16 offset:1280\n\t"
+        "ds_read_b64_tr_b16 %5, %16 offset:160\n\tds_read_b64_tr_b16 %13, %16 offset:1312\n\t"
+        "ds_read_b64_tr_b16 %6, %16 offset:192\n\tds_read_b64_tr_b16 %14, %16 offset:1344\n\t"
+        "ds_read_b64_tr_b16 %7, %16 offset:224\n\tds_read_b64_tr_b16 %15, %16 offset:1376\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(lo[4]), "=&v"(lo[5]), "=&v"(lo[6]), "=&v"(lo[7]),
+          "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3]), "=&v"(hi[4]), "=&v"(hi[5]), "=&v"(hi[6]), "=&v"(hi[7])
+        : "v"(a)
+        : "memory");
+}
+
 // PF: the loads of chunk i+1 fly underneath chunk i (64 more VGPRs: one workgroup per CU -- the decode shape at small
 // batch, where the launch is 256 workgroups of dependent round trips).  PF = false halves the register footprint so that
 // two workgroups share a CU: large batches, where occupancy hides the same latency.
@@ -522,7 +542,8 @@ __global__ __launch_bounds__(256) void paged_attention_prefill_kernel(
     f16* vl = reinterpret_cast<f16*>(kl + QS_FA_KEYS * 256);                               // [64 keys][QS_ATT_VSTRIDE]
     f16* pl_all = vl + QS_FA_KEYS * QS_ATT_VSTRIDE;                                        // [4 waves][hi, lo][16][72]
     constexpr int PSTR = 72;   // halves per P row (144 B): the 16 rows of an A-fragment read fall on distinct banks
-    const int seq = blockIdx.x, kvh = blockIdx.y / n_rb, rb = blockIdx.y % n_rb;
+    // the last row blocks see the most keys (causal): dispatch them first so that the tail of the launch is short blocks
+    const int seq = blockIdx.x, rb = n_rb - 1 - blockIdx.y / nkv, kvh = blockIdx.y % nkv;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
     const int gmask = (1 << group_log2) - 1, bmask = (1 << bs_log2) - 1;
@@ -651,12 +672,11 @@ __global__ __launch_bounds__(256) void paged_attention_prefill_kernel(
                 const f16x8 pa = *reinterpret_cast<const f16x8*>(pl + c16 * PSTR + st * 32 + g4 * 8);
                 const f16x8 pb = *reinterpret_cast<const f16x8*>(pl + (16 + c16) * PSTR + st * 32 + g4 * 8);
                 const int krow = st * 32 + g4 * 8 + qd;
+                u32x2 lo[8], hi[8];
+                lds_read_tr_b16_x16(vl_base + (uint32_t)((krow * QS_ATT_VSTRIDE + 4 * pq) * 2), lo, hi);
 #pragma unroll
                 for (int dt = 0; dt < 8; dt++) {
-                    const uint32_t a0 = vl_base + (uint32_t)((krow * QS_ATT_VSTRIDE + dt * 16 + 4 * pq) * 2);
-                    const u32x2 lo = lds_read_tr_b16(a0);
-                    const u32x2 hi = lds_read_tr_b16(a0 + 4 * QS_ATT_VSTRIDE * 2);
-                    const u32x4 bw = {lo[0], lo[1], hi[0], hi[1]};
+                    const u32x4 bw = {lo[dt][0], lo[dt][1], hi[dt][0], hi[dt][1]};
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
                 }
