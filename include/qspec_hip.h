@@ -249,8 +249,9 @@ int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_hal
 /* qspec_heads_hadamard on the un-merged output of qspec_paged_attention(..., out = NULL): split merge (same
  * expression as the attention kernel's own merge, rounded to fp16 where flash-attn returns fp16) + head Hadamard
  * (+ row-absmax int4 quant when q != NULL).  attn_workspace / max_tokens (= n_seqs * max_q_len) / n_splits are
- * those of the attention call.  head_dim 128, 32 or 64 heads.  Bit-identical to merging inside the attention
- * kernel and calling qspec_heads_hadamard. */
+ * those of the attention call.  head_dim 128, 32 or 64 heads.  The merge itself is the attention kernel's expression;
+ * with splits of at most 128 keys the result is bit-identical to qspec_paged_attention(out != NULL) followed by
+ * qspec_heads_hadamard (longer splits take a kernel with another summation order inside a split: equal within 1e-3). */
 int qspec_heads_hadamard_merged(const void* attn_workspace, int max_tokens, int n_splits, qspec_half* out_f16, int8_t* q,
                                 qspec_half* scale, float had_scale, float clip_ratio, int tokens, int heads,
                                 int head_dim, void* stream);

@@ -158,6 +158,12 @@ int rope_kv_write(const int64_t* positions, f16* qkv, const f16* cos_sin_cache, 
 #define QS_ATT_VSTRIDE 144     // halves per V row in LDS (288 B): 4 rows x 4 column quads hit 16 distinct bank pairs
 #define QS_ATT_MAXSPLIT 64
 
+// e^x of the attention probabilities: the hardware 2^x (v_exp_f32, ~1 ulp) on x * log2(e).  Attention is compared with
+// the oracle at 1e-3, not bit for bit, and the ~20-instruction deterministic qexpf (kept where bits are compared: SiLU,
+// the sampler's softmax, the split merge) was most of the softmax phase: one wave per SIMD has nothing to hide it behind.
+// 2^0 = 1 and 2^-inf = 0 exactly, which the running-maximum logic relies on.
+__device__ __forceinline__ float aexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 __device__ __forceinline__ u32x2 lds_read_tr_b16(uint32_t lds_byte_addr) {
     u32x2 r;
     asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_byte_addr) : "memory");
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
             f16x8 p8, p8lo;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const float pv = m_new == -__builtin_inff() ? 0.0f : qexpf(s8[i] - m_new);
+                const float pv = m_new == -__builtin_inff() ? 0.0f : aexp(s8[i] - m_new);
                 // the matrix core takes fp16 operands: carry the fp32 probability as hi + lo so that P.V keeps
                 // fp32-class accuracy (22 bits) for two MFMAs instead of one
                 const f16 ph = f2h(pv);
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
             *reinterpret_cast<f16x8*>(pl + r * QS_ATT_CHUNK + ks * 8) = p8;
             *reinterpret_cast<f16x8*>(pl2 + r * QS_ATT_CHUNK + ks * 8) = p8lo;
             if (ks == 0) {
-                const float alpha = m_old == -__builtin_inff() ? 0.0f : qexpf(m_old - m_new);   // e^0 = 1 exactly
+                const float alpha = m_old == -__builtin_inff() ? 0.0f : aexp(m_old - m_new);   // e^0 = 1 exactly
                 row_a[r] = alpha;
                 row_m[r] = m_new;
                 row_l[r] = __builtin_fmaf(row_l[r], alpha, sum);   // first chunk: 0 * 0 + sum
@@ -518,6 +524,231 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------- decode, the keys of a workgroup split over its WAVES
+// Same grid, same partials as paged_attention_kernel (16 rows per workgroup, context splits on blockIdx.z), but no
+// workgroup-wide phase inside the key loop: wave w walks the 32-key slices w, w+4, ... of the split on its own -- K
+// fragments straight from the cache into registers, V through a wave-private LDS tile for the transposing reads,
+// S / softmax / P.V and a running (max, sum, output) per wave -- and the four waves' results are combined once at
+// the end (wave order: deterministic).  The next slice's loads fly underneath the current one.  Where the 128-key
+// chunk loop of paged_attention_kernel spends 2.7 us in barrier-separated phases per chunk, the waves here overlap
+// each other: large batches and long contexts (more than one chunk per workgroup).  Partials only (out == NULL form).
+#define QS_AW_KEYS 32
+__global__ __launch_bounds__(256) void paged_attention_waves_kernel(
+    const f16* __restrict__ q, int64_t q_stride, const f16* __restrict__ key_cache, const f16* __restrict__ value_cache,
+    const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
+    const int32_t* __restrict__ q_start, int nq, int nkv, int bs_log2, int group_log2, float sm_scale, int n_splits,
+    int n_rb, float* __restrict__ ws_o, float* __restrict__ ws_ml) {
+    constexpr int D = 128, PSTR = 40;   // P row stride in halves (80 B)
+    constexpr int WAVE_LDS = QS_AW_KEYS * QS_ATT_VSTRIDE * 2 + 2 * 16 * PSTR * 2;   // V tile + P hi/lo tile, bytes
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int seq = blockIdx.x, kvh = blockIdx.y / n_rb, rb = blockIdx.y % n_rb, split = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int gmask = (1 << group_log2) - 1, bmask = (1 << bs_log2) - 1;
+    f16* vl = reinterpret_cast<f16*>(smem_raw + wave * WAVE_LDS);
+    f16* pl = vl + QS_AW_KEYS * QS_ATT_VSTRIDE;
+    int meta = 0;
+    if (lane < 3) meta = lane < 2 ? q_start[seq + lane] : ctx_lens[seq];
+    const int qs = __shfl(meta, 0, 64), qlen = __shfl(meta, 1, 64) - qs;
+    const int ctx = __shfl(meta, 2, 64);
+    const int r0 = rb * QS_ATT_MAXR;
+    const int R = min(QS_ATT_MAXR, (qlen << group_log2) - r0);
+    if (R <= 0) return;  // uniform for the whole workgroup
+    const int kps = (((ctx + n_splits - 1) / n_splits) + 15) & ~15;
+    const int k_begin = split * kps;
+    const int k_end = min(ctx, k_begin + kps);
+    const int n_sl = (max(k_end - k_begin, 0) + QS_AW_KEYS - 1) / QS_AW_KEYS;
+    const int32_t* bt = block_tables + (size_t)seq * max_blocks;
+
+    struct Slots {
+        int64_t k[2], v[8];
+    };
+    struct KV {
+        u32x4 kf[2][4], vr[8];
+    };
+    auto lookup = [&](Slots& sl, int sb) {   // clamped: no load behind a branch
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {
+            const int p = sb + t2 * 16 + c16;
+            sl.k[t2] = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int p = sb + i * 4 + g4;
+            sl.v[i] = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
+        }
+    };
+    auto fetch = [&](KV& kv, const Slots& sl) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {   // lane (key c16 of tile t2, d slice 8 g4 + 32 j)
+            const f16* kp = key_cache + (sl.k[t2] * nkv + kvh) * D + g4 * 8;
+#pragma unroll
+            for (int j = 0; j < 4; j++) kv.kf[t2][j] = *reinterpret_cast<const u32x4*>(kp + 32 * j);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)   // 16 lanes cover one 256-byte V row: key 4 i + g4 of the slice
+            kv.vr[i] = *reinterpret_cast<const u32x4*>(value_cache + (sl.v[i] * nkv + kvh) * D + c16 * 8);
+    };
+    int sb = k_begin + wave * QS_AW_KEYS;
+    Slots sl_cur, sl_nxt;
+    lookup(sl_cur, sb);
+    lookup(sl_nxt, sb + 4 * QS_AW_KEYS);
+    u32x4 qfrag[4];
+    {
+        const int r = r0 + (c16 < R ? c16 : 0);
+        const int tok = qs + (r >> group_log2), head = (kvh << group_log2) + (r & gmask);
+        const f16* qp = q + (size_t)tok * q_stride + (size_t)head * D + g4 * 8;
+#pragma unroll
+        for (int j = 0; j < 4; j++) qfrag[j] = *reinterpret_cast<const u32x4*>(qp + 32 * j);
+    }
+    KV cur;
+    fetch(cur, sl_cur);
+    int pos[4];
+    float row_m[4], row_l[4];
+    f32x4 o[8];
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        pos[reg] = ctx - qlen + ((r0 + 4 * g4 + reg) >> group_log2);
+        row_m[reg] = -__builtin_inff();
+        row_l[reg] = 0.0f;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 8; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t vl_base = (uint32_t)(uintptr_t)vl;
+    const int qd = c16 >> 2, pq = c16 & 3;
+
+    for (int s2 = wave; s2 < n_sl; s2 += 4) {
+        const int nkeys = max(0, min(k_end - sb, QS_AW_KEYS));
+        // ---- S = Q K^T: lane holds rows 4 g4 + reg, key column t2 * 16 + c16.  Each K register is refilled with the
+        // wave's NEXT slice right behind its last use (as the weight ring of gemm_stream.hip): the loads never stop.
+        f32x4 sacc[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, qfrag[j]),
+                                                             __builtin_bit_cast(f16x8, cur.kf[t2][j]), acc, 0, 0, 0);
+            const int kk = t2 * 16 + c16, p = sb + kk;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++)
+                sacc[t2][reg] = (kk < nkeys && p <= pos[reg]) ? acc[reg] * sm_scale : -__builtin_inff();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {
+            const f16* kp = key_cache + (sl_nxt.k[t2] * nkv + kvh) * D + g4 * 8;
+#pragma unroll
+            for (int j = 0; j < 4; j++) cur.kf[t2][j] = *reinterpret_cast<const u32x4*>(kp + 32 * j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // V rows -> the wave's LDS tile (zeros past the end keep the MFMA clean), registers refilled the same way
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int kk = i * 4 + g4;
+            const u32x4 vz = kk < nkeys ? cur.vr[i] : u32x4{0, 0, 0, 0};
+            *reinterpret_cast<u32x4*>(vl + kk * QS_ATT_VSTRIDE + c16 * 8) = vz;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            cur.vr[i] = *reinterpret_cast<const u32x4*>(value_cache + (sl_nxt.v[i] * nkv + kvh) * D + c16 * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        lookup(sl_nxt, sb + 8 * QS_AW_KEYS);             // table entries of the slice after the next (clamped)
+        // ---- running softmax: the 16 lanes of a g4 group hold the 32 keys of rows 4 g4 + reg
+        float alpha[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            float mx = fmaxf(sacc[0][reg], sacc[1][reg]);
+            mx = fmaxf(mx, dpp_xor<8>(mx));
+            mx = fmaxf(mx, dpp_xor<4>(mx));
+            mx = fmaxf(mx, dpp_xor<2>(mx));
+            mx = fmaxf(mx, dpp_xor<1>(mx));
+            const float m_old = row_m[reg], m_new = fmaxf(m_old, mx);
+            float sum = 0.0f;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; t2++) {
+                const float pv = m_new == -__builtin_inff() ? 0.0f : aexp(sacc[t2][reg] - m_new);
+                const f16 ph = f2h(pv);
+                pl[(4 * g4 + reg) * PSTR + t2 * 16 + c16] = ph;
+                pl[(16 + 4 * g4 + reg) * PSTR + t2 * 16 + c16] = f2h(pv - h2f(ph));
+                sum += pv;
+            }
+            sum += dpp_xor<8>(sum);
+            sum += dpp_xor<4>(sum);
+            sum += dpp_xor<2>(sum);
+            sum += dpp_xor<1>(sum);
+            alpha[reg] = m_old == -__builtin_inff() ? 0.0f : aexp(m_old - m_new);
+            row_m[reg] = m_new;
+            row_l[reg] = __builtin_fmaf(row_l[reg], alpha[reg], sum);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 8; dt++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) o[dt][reg] *= alpha[reg];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own tiles: LDS is in order per wave
+        // ---- O += P V (one 32-key step): A = P (row c16, keys 8 g4 ..), B = V through the transposing reads
+        {
+            const f16x8 pa = *reinterpret_cast<const f16x8*>(pl + c16 * PSTR + g4 * 8);
+            const f16x8 pb = *reinterpret_cast<const f16x8*>(pl + (16 + c16) * PSTR + g4 * 8);
+            u32x2 lo[8], hi[8];
+            lds_read_tr_b16_x16(vl_base + (uint32_t)(((g4 * 8 + qd) * QS_ATT_VSTRIDE + 4 * pq) * 2), lo, hi);
+#pragma unroll
+            for (int dt = 0; dt < 8; dt++) {
+                const u32x4 bw = {lo[dt][0], lo[dt][1], hi[dt][0], hi[dt][1]};
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
+            }
+        }
+        sb += 4 * QS_AW_KEYS;
+    }
+    // ---- combine the four waves (wave order), store the split's partial: ws_o [T, nq, n_splits, D], ws_ml [.., 2]
+    __syncthreads();   // every wave is done with its private tiles: the same LDS now carries the exchange
+    float* co = reinterpret_cast<float*>(smem_raw);          // [4][16][128]
+    float* cml = co + 4 * 16 * D;                             // [4][16][2]
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int r = 4 * g4 + reg;
+#pragma unroll
+        for (int dt = 0; dt < 8; dt++) co[(wave * 16 + r) * D + dt * 16 + c16] = o[dt][reg];
+        if (c16 == 0) {
+            cml[(wave * 16 + r) * 2] = row_m[reg];
+            cml[(wave * 16 + r) * 2 + 1] = row_l[reg];
+        }
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 4, c8 = (tid & 15) * 8;
+        if (r < R) {
+            float M = -__builtin_inff();
+#pragma unroll
+            for (int w = 0; w < 4; w++) M = fmaxf(M, cml[(w * 16 + r) * 2]);
+            float l = 0.0f, acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const float m = cml[(w * 16 + r) * 2];
+                const float wg = m == -__builtin_inff() ? 0.0f : aexp(m - M);
+                l = __builtin_fmaf(wg, cml[(w * 16 + r) * 2 + 1], l);
+                const float4 a = *reinterpret_cast<const float4*>(co + (w * 16 + r) * D + c8);
+                const float4 b = *reinterpret_cast<const float4*>(co + (w * 16 + r) * D + c8 + 4);
+                acc8[0] = __builtin_fmaf(wg, a.x, acc8[0]); acc8[1] = __builtin_fmaf(wg, a.y, acc8[1]);
+                acc8[2] = __builtin_fmaf(wg, a.z, acc8[2]); acc8[3] = __builtin_fmaf(wg, a.w, acc8[3]);
+                acc8[4] = __builtin_fmaf(wg, b.x, acc8[4]); acc8[5] = __builtin_fmaf(wg, b.y, acc8[5]);
+                acc8[6] = __builtin_fmaf(wg, b.z, acc8[6]); acc8[7] = __builtin_fmaf(wg, b.w, acc8[7]);
+            }
+            const int rr = r0 + r;
+            const size_t th = (size_t)(qs + (rr >> group_log2)) * nq + (kvh << group_log2) + (rr & gmask);
+            float* dst = ws_o + (th * n_splits + split) * D + c8;
+            *reinterpret_cast<float4*>(dst) = float4{acc8[0], acc8[1], acc8[2], acc8[3]};
+            *reinterpret_cast<float4*>(dst + 4) = float4{acc8[4], acc8[5], acc8[6], acc8[7]};
+            if ((tid & 15) == 0) {
+                ws_ml[(th * n_splits + split) * 2] = M;
+                ws_ml[(th * n_splits + split) * 2 + 1] = l;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- prompt-sized queries (flash-attn varlen, head 128)
 // The kernel above keeps 16 rows per workgroup: right for decode (1 .. k+1 query tokens per sequence), but a prompt pass
 // would stream K/V once per 4 query tokens.  Here a workgroup holds 64 rows (16 query tokens x the GQA group of one kv
@@ -644,7 +875,7 @@ __global__ __launch_bounds__(256) void paged_attention_prefill_kernel(
             float sum = 0.0f;
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                const float pv = m_new == -__builtin_inff() ? 0.0f : qexpf(sacc[t][reg] - m_new);
+                const float pv = m_new == -__builtin_inff() ? 0.0f : aexp(sacc[t][reg] - m_new);
                 const f16 ph = f2h(pv);
                 pl[(4 * g4 + reg) * PSTR + t * 16 + c16] = ph;
                 pl[(16 + 4 * g4 + reg) * PSTR + t * 16 + c16] = f2h(pv - h2f(ph));
@@ -654,7 +885,7 @@ __global__ __launch_bounds__(256) void paged_attention_prefill_kernel(
             sum += dpp_xor<4>(sum);
             sum += dpp_xor<2>(sum);
             sum += dpp_xor<1>(sum);
-            alpha[reg] = m_old == -__builtin_inff() ? 0.0f : qexpf(m_old - m_new);
+            alpha[reg] = m_old == -__builtin_inff() ? 0.0f : aexp(m_old - m_new);
             row_m[reg] = m_new;
             row_l[reg] = __builtin_fmaf(row_l[reg], alpha[reg], sum);
         }
@@ -821,6 +1052,18 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
     float* ws_ml = ws_o + Tmax * nq * n_splits * d;
     const size_t lds = QS_ATT_MAXR * QS_ATT_CHUNK * 4 + 2 * QS_ATT_MAXR * QS_ATT_CHUNK * 2 +
                        QS_ATT_CHUNK * QS_ATT_VSTRIDE * 2 + (2 * QS_ATT_MAXR + QS_ATT_MAXR * QS_ATT_MAXSPLIT + 4) * 4;
+    // Partials only, and a split may be longer than one 128-key chunk (large batch: one split; long contexts): the keys
+    // go over the waves of a workgroup instead of through barrier-separated chunk phases (bs=32: 21.1 -> 20.3 us, 4 K
+    // context: 20.8 -> 19.1 us per launch; equal at 64 keys per split).  QSPEC_ATTN_WAVES=0/1 forces either kernel.
+    static const int aw_env = getenv("QSPEC_ATTN_WAVES") ? atoi(getenv("QSPEC_ATTN_WAVES")) : -1;
+    const bool long_splits = ((int64_t)max_blocks << bs_log2) > (int64_t)QS_ATT_CHUNK * n_splits;
+    if (!out && (aw_env >= 0 ? aw_env != 0 : long_splits)) {
+        const size_t wlds = (size_t)4 * (QS_AW_KEYS * QS_ATT_VSTRIDE * 2 + 2 * 16 * 40 * 2);
+        hipLaunchKernelGGL(paged_attention_waves_kernel, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), wlds, st, q,
+                           q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv, bs_log2,
+                           group_log2, sm_scale, n_splits, n_rb, ws_o, ws_ml);
+        return 0;
+    }
     // more workgroups than CUs: occupancy (two per CU) instead of the in-workgroup prefetch
     static const int pf_env = getenv("QSPEC_ATTN_PF") ? atoi(getenv("QSPEC_ATTN_PF")) : -1;   // dev knob
     const bool pf = pf_env >= 0 ? pf_env != 0 : (size_t)n_seqs * nkv * n_rb * n_splits <= 256;

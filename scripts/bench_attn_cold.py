@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from qspec_amd import ops
 dev = "cuda:0"
-B, nq, nkv, d, bs, L = int(os.environ.get("B", 4)), 32, 8, 128, 16, int(os.environ.get("L", 32))
-ctx0, max_len = 512, 640
+B, nq, nkv, d, bs, L = int(os.environ.get("B", 4)), int(os.environ.get("NQ", 32)), int(os.environ.get("NKV", 8)), 128, 16, int(os.environ.get("L", 32))
+ctx0 = int(os.environ.get("CTX", 512)); max_len = ctx0 + 128
 for q_len in (1, 4):
     n_splits = int(os.environ.get("S", 8))
     nb = B * (max_len // bs)
@@ -39,5 +39,13 @@ for q_len in (1, 4):
     st = None
     t_att = run("att")
     stx = ws[2048 * 4:2048 * 4 + 9 * 8].view(torch.int64).cpu().tolist()
+    stw = ws[8192:8192 + 48].view(torch.int64).cpu().tolist()
+    if os.environ.get("QSPEC_ATTN_WAVES") == "1" and any(stw):
+        print("  waves-kernel slice stamps (ticks): K wait+QK %d, refill K %d, V->LDS %d, refill V+lookup+softmax %d, PV %d"
+              % tuple(stw[i + 1] - stw[i] for i in range(5)), flush=True)
+    if nq not in (32, 64):
+        kvb = B * ctx0 * nkv * d * 2 * 2
+        print(f"q_len={q_len}: attention(partials, cold KV) {t_att:.2f} us  ({kvb / t_att / 1e6:.2f} TB/s of KV)", flush=True)
+        continue
     print(f"q_len={q_len}: attention(partials, cold KV) {t_att:.2f} us | merge+hadamard {run('had'):.2f} us | both {run('both'):.2f} us"
           + (f" | stamps {[stx[i+1]-stx[i] for i in range(5)]}" if any(stx) else ""), flush=True)

@@ -667,6 +667,11 @@ def test_heads_hadamard_merged_equals_attention_merge_then_hadamard(ops, oracle,
     ops.heads_hadamard_merged(ws2, T, n_splits, T, nq, d, had_scale, q=q1, scale=s1)
     ops.heads_hadamard_merged(ws2, T, n_splits, T, nq, d, had_scale, out_f16=o1)
     torch.cuda.synchronize()
+    if bt.shape[1] * bs > 128 * n_splits:
+        # splits that may exceed one 128-key chunk: the partials come from the keys-over-waves kernel, whose summation
+        # order differs from the chunk kernel that merges in place -- same rows within the attention tolerance
+        assert_close_1e3(host(o1), host(o0))
+        return
     assert torch.equal(q0, q1) and torch.equal(s0.view(torch.int16), s1.view(torch.int16))
     assert torch.equal(o0.view(torch.int16), o1.view(torch.int16))
 
