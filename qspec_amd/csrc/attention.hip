@@ -158,12 +158,6 @@ int rope_kv_write(const int64_t* positions, f16* qkv, const f16* cos_sin_cache, 
 #define QS_ATT_VSTRIDE 144     // halves per V row in LDS (288 B): 4 rows x 4 column quads hit 16 distinct bank pairs
 #define QS_ATT_MAXSPLIT 64
 
-// e^x of the attention probabilities: the hardware 2^x (v_exp_f32, ~1 ulp) on x * log2(e).  Attention is compared with
-// the oracle at 1e-3, not bit for bit, and the ~20-instruction deterministic qexpf (kept where bits are compared: SiLU,
-// the sampler's softmax, the split merge) was most of the softmax phase: one wave per SIMD has nothing to hide it behind.
-// 2^0 = 1 and 2^-inf = 0 exactly, which the running-maximum logic relies on.
-__device__ __forceinline__ float aexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
-
 __device__ __forceinline__ u32x2 lds_read_tr_b16(uint32_t lds_byte_addr) {
     u32x2 r;
     asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_byte_addr) : "memory");
@@ -495,7 +489,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
                 float den = 0.0f;
                 for (int s2 = 0; s2 < n_splits; s2++) {
                     const float m = ws_ml[(t2 * n_splits + s2) * 2];
-                    const float w = m == -__builtin_inff() ? 0.0f : qexpf(m - M);
+                    const float w = m == -__builtin_inff() ? 0.0f : aexp(m - M);
                     wgt[tid * QS_ATT_MAXSPLIT + s2] = w;
                     den = __builtin_fmaf(w, ws_ml[(t2 * n_splits + s2) * 2 + 1], den);
                 }

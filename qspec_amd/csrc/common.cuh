@@ -54,6 +54,12 @@ __device__ __forceinline__ float qexpf(float x) {
 }
 
 // round-to-nearest-even to integer with saturation, NaN -> 0
+// e^x of the attention probabilities: the hardware 2^x (v_exp_f32, ~1 ulp) on x * log2(e).  Attention is compared with
+// the oracle at 1e-3, not bit for bit, and the ~20-instruction deterministic qexpf (kept where bits are compared: SiLU,
+// the sampler's softmax) was most of the softmax phase: one wave per SIMD has nothing to hide it behind.
+// 2^0 = 1 and 2^-inf = 0 exactly, which the running-maximum logic relies on.
+__device__ __forceinline__ float aexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 // x / s rounded to fp16, for x and s that are fp16 VALUES (the quantisers: h(x / scale), quant.cu:147), in three
 // instructions: q0 = x * r, q1 = q0 + (x - q0 * s) * r with r = 1 / s correctly rounded (once per row).  The fp16
 // rounding of q1 equals the fp16 rounding of the correctly rounded fp32 quotient for EVERY pair of finite fp16 x and

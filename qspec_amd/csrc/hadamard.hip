@@ -365,7 +365,7 @@ __global__ __launch_bounds__(1024) void heads_hadamard_merge_kernel(const float*
             for (int s2 = 0; s2 < SMAX; s2++) {
                 if (s0 + s2 < S) {
                     const float m = ml[s2].x;
-                    const float w = m == -__builtin_inff() ? 0.0f : qexpf(m - M);
+                    const float w = m == -__builtin_inff() ? 0.0f : aexp(m - M);   // = attention.hip's own merge
                     den = __builtin_fmaf(w, ml[s2].y, den);
 #pragma unroll
                     for (int v4 = 0; v4 < CP / 4; v4++)
