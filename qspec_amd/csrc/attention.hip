@@ -184,19 +184,6 @@ __device__ __forceinline__ void lds_read_tr_b16_x16(uint32_t a, u32x2 (&lo)[8], 
         : "memory");
 }
 
-// four d tiles (half of the above): 8 reads, one wait -- for kernels that are short of registers
-__device__ __forceinline__ void lds_read_tr_b16_x8(uint32_t a, u32x2 (&lo)[4], u32x2 (&hi)[4]) {
-    asm volatile(
-        "ds_read_b64_tr_b16 %0, %8 offset:0\n\tds_read_b64_tr_b16 %4, %8 offset:1152\n\t"
-        "ds_read_b64_tr_b16 %1, %8 offset:32\n\tds_read_b64_tr_b16 %5, %8 offset:1184\n\t"
-        "ds_read_b64_tr_b16 %2, %8 offset:64\n\tds_read_b64_tr_b16 %6, %8 offset:1216\n\t"
-        "ds_read_b64_tr_b16 %3, %8 offset:96\n\tds_read_b64_tr_b16 %7, %8 offset:1248\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
-        : "v"(a)
-        : "memory");
-}
-
 // PF: the loads of chunk i+1 fly underneath chunk i (64 more VGPRs: one workgroup per CU -- the decode shape at small
 // batch, where the launch is 256 workgroups of dependent round trips).  PF = false halves the register footprint so that
 // two workgroups share a CU: large batches, where occupancy hides the same latency.
@@ -698,17 +685,13 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
         {
             const f16x8 pa = *reinterpret_cast<const f16x8*>(pl + c16 * PSTR + g4 * 8);
             const f16x8 pb = *reinterpret_cast<const f16x8*>(pl + (16 + c16) * PSTR + g4 * 8);
+            u32x2 lo[8], hi[8];   // all 16 reads behind ONE wait (in two halves: 16 VGPRs fewer, but two waits: slower)
+            lds_read_tr_b16_x16(vl_base + (uint32_t)(((g4 * 8 + qd) * QS_ATT_VSTRIDE + 4 * pq) * 2), lo, hi);
 #pragma unroll
-            for (int half = 0; half < 2; half++) {   // four d tiles at a time (two workgroups per CU measured no faster)
-                u32x2 lo[4], hi[4];
-                lds_read_tr_b16_x8(vl_base + (uint32_t)(((g4 * 8 + qd) * QS_ATT_VSTRIDE + half * 64 + 4 * pq) * 2), lo, hi);
-#pragma unroll
-                for (int d4 = 0; d4 < 4; d4++) {
-                    const int dt = half * 4 + d4;
-                    const u32x4 bw = {lo[d4][0], lo[d4][1], hi[d4][0], hi[d4][1]};
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
-                }
+            for (int dt = 0; dt < 8; dt++) {
+                const u32x4 bw = {lo[dt][0], lo[dt][1], hi[dt][0], hi[dt][1]};
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
             }
         }
         sb += 4 * QS_AW_KEYS;
