@@ -696,6 +696,46 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
             static_assert(KH % IQ == 0 && KH % 4 == 0, "row split");
             constexpr int ROWS = KH / IQ;
             const int j2 = tid % (P / 2), iq = tid / (P / 2);
+            if constexpr (P >= 512 && KH % 4 == 0) {
+                // Four columns per thread (half the threads): the table reads -- 16-byte broadcasts whose 1 KB return
+                // per wave is what bounds this phase -- are shared by twice as many fmas.  Per output the fp32 chain
+                // in k order is unchanged.  k in quads outside, the thread's KH/4 rows inside: 2 x KH/4 accumulators.
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                constexpr int RQ = KH / 4;                     // rows per thread
+                const int j4 = tid % (P / 4), rq = tid / (P / 4);
+                if (rq < 4) {
+                    f32x2 a0[RQ], a1[RQ];
+#pragma unroll
+                    for (int r = 0; r < RQ; r++) a0[r] = a1[r] = f32x2{0.0f, 0.0f};
+#pragma unroll
+                    for (int kq = 0; kq < KH / 4; kq++) {
+                        f32x2 y0[4], y1[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const f16x4 yy = *reinterpret_cast<const f16x4*>(ylds + (size_t)(4 * kq + kk) * P + 4 * j4);
+                            y0[kk] = f32x2{h2f(yy[0]), h2f(yy[1])};
+                            y1[kk] = f32x2{h2f(yy[2]), h2f(yy[3])};
+                        }
+#pragma unroll
+                        for (int r = 0; r < RQ; r++) {
+                            const float4 h = *reinterpret_cast<const float4*>(had + (rq * RQ + r) * KH + 4 * kq);
+                            a0[r] = __builtin_elementwise_fma(f32x2{h.x, h.x}, y0[0], a0[r]);
+                            a1[r] = __builtin_elementwise_fma(f32x2{h.x, h.x}, y1[0], a1[r]);
+                            a0[r] = __builtin_elementwise_fma(f32x2{h.y, h.y}, y0[1], a0[r]);
+                            a1[r] = __builtin_elementwise_fma(f32x2{h.y, h.y}, y1[1], a1[r]);
+                            a0[r] = __builtin_elementwise_fma(f32x2{h.z, h.z}, y0[2], a0[r]);
+                            a1[r] = __builtin_elementwise_fma(f32x2{h.z, h.z}, y1[2], a1[r]);
+                            a0[r] = __builtin_elementwise_fma(f32x2{h.w, h.w}, y0[3], a0[r]);
+                            a1[r] = __builtin_elementwise_fma(f32x2{h.w, h.w}, y1[3], a1[r]);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < RQ; r++) {
+                        const f16x4 zz = {f2h(a0[r][0]), f2h(a0[r][1]), f2h(a1[r][0]), f2h(a1[r][1])};
+                        *reinterpret_cast<f16x4*>(zlds + (size_t)(rq * RQ + r) * P + 4 * j4) = zz;
+                    }
+                }
+            } else
             if (iq < IQ) {
                 // the column pair rides in one 64-bit register pair: v_pk_fma_f32 does both columns per instruction
                 // (each component is an ordinary fp32 fma, so the k-ordered chain of the oracle is unchanged)
