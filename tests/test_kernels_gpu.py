@@ -1021,3 +1021,34 @@ def test_paged_attention_prompt_sized_queries_within_1e3(ops, oracle, ctx_lens, 
         had_b = torch.empty_like(had_a)
         ops.heads_hadamard(out[:T].contiguous(), 0.1767, out_f16=had_b, heads=nq)
         assert torch.equal(had_a.view(torch.int16), had_b.view(torch.int16))
+
+
+@pytest.mark.parametrize("ctx_lens,q_len,n_splits,nq,nkv", [
+    ([37, 130, 260, 515], 4, 1, 32, 8),      # one split over the whole context: 32-key slices over the four waves
+    ([700], 6, 2, 32, 8),                    # verify with k = 5; a ragged last slice per split
+    ([1500, 3000, 17], 1, 4, 32, 8),         # long contexts next to a sequence shorter than one slice
+    ([333, 90], 2, 1, 64, 8),                # 64 heads, GQA group 8
+])
+def test_attention_partials_long_splits_then_merge_within_1e3(ops, oracle, ctx_lens, q_len, n_splits, nq, nkv):
+    """Partials mode with splits that may exceed one 128-key chunk (the keys-over-waves kernel) + the merging head
+    Hadamard, against the oracle's attention followed by the oracle's head Hadamard."""
+    rng = np.random.default_rng(sum(ctx_lens) + q_len + nq)
+    d, bs = 128, 16
+    n_seqs = len(ctx_lens)
+    bt, kc, vc = make_paged(rng, n_seqs, ctx_lens, nkv, d, bs)
+    assert bt.shape[1] * bs > 128 * n_splits
+    T = n_seqs * q_len
+    row = (nq + 2 * nkv) * d
+    qkv = (rng.standard_normal((T, row)) * 0.5).astype(np.float16)
+    q_start = (np.arange(n_seqs + 1) * q_len).astype(np.int32)
+    ctx = np.array(ctx_lens, np.int32)
+    scale = d ** -0.5
+    had_scale = oracle.rsqrt_scale(nq)
+    ref = oracle.heads_hadamard(oracle.paged_attention(qkv[:, : nq * d], kc, vc, bt, ctx, q_start, scale), nq, had_scale)
+    ws = torch.zeros(ops.paged_attention_workspace_bytes(T, nq, d, n_splits), dtype=torch.uint8, device=DEV)
+    ops.paged_attention(dev(qkv), row, dev(kc), dev(vc), dev(bt), dev(ctx), dev(q_start), T, q_len, nq, scale, n_splits,
+                        ws, None)
+    out = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
+    ops.heads_hadamard_merged(ws, T, n_splits, T, nq, d, had_scale, out_f16=out)
+    # the head transform sums 32 / 64 attention outputs scaled by 1/sqrt(heads): errors of 1e-3 each stay below 1e-3 * sqrt(heads) / sqrt(heads)
+    assert_close_1e3(host(out), ref)
