@@ -99,6 +99,10 @@ def load():
         raise QSpecLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C qspec_amd/csrc`).  There is no CPU fallback for the QSpec hot path.")
+    # torch first: its bundled HIP runtime must be THE runtime of the process (device memory and streams come from
+    # torch).  Loaded the other way round, this library binds to the system libamdhip64 and a later torch brings a
+    # second runtime: every launch then fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
