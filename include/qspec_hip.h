@@ -233,12 +233,19 @@ int qspec_rope_kv_write(const int64_t* positions, qspec_half* qkv, const qspec_h
 
 /* flash_attn_with_kvcache (draft, q_len 1) / flash_attn_varlen_func (verify, q_len k+1, causal) over the paged
  * cache  (vllm/attention/backends/flash_attn.py:741-830).  q rows of sequence s are tokens q_start[s]..q_start[s+1]-1
- * and sit at absolute positions ctx_lens[s]-q_len .. ctx_lens[s]-1.  head_size must be 128.
+ * and sit at absolute positions ctx_lens[s]-q_len .. ctx_lens[s]-1.
  * workspace: qspec_paged_attention_workspace_bytes(n_seqs*max_q_len, ...) bytes, ZERO-FILLED once before its
  * first use (it starts with the split-merge ticket counters, which every call leaves at zero again).
  * out == NULL: the context splits are NOT merged; their partials (o, m, l) stay in the workspace for
  * qspec_heads_hadamard_merged, which merges them in front of the head transform (the launch boundary then is the
- * hand-off between the split workgroups and no ticket / fence is needed). */
+ * hand-off between the split workgroups and no ticket / fence is needed).
+ * Three kernels sit behind this entry (attention.hip), chosen from the shape alone: 16-row workgroups walking 128-key
+ * chunks (decode / verify, splits of at most one chunk; also every out != NULL call with n_splits > 1); the same grid
+ * with the keys over the waves of a workgroup (out == NULL and block_tables wide enough for splits longer than 128
+ * keys); 64-row flash-style workgroups for prompt-sized queries (n_splits == 1, max_q_len * num_heads / num_kv_heads
+ * >= 128).  Every block_tables entry must be a valid block number (unused tail entries: 0, as vLLM pads them): rows
+ * past a sequence's context are read (clamped prefetch) and masked, never used.  head_size != 128 (<= 256): a generic
+ * kernel, out != NULL only. */
 size_t qspec_paged_attention_workspace_bytes(int max_tokens, int num_heads, int head_size, int n_splits);
 int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_half* key_cache,
                           const qspec_half* value_cache, const int32_t* block_tables, int max_blocks_per_seq,
