@@ -63,7 +63,7 @@ def gen_hadamard():
         assert k == K
         out[f"had{K}"] = hadK.numpy().astype(np.int8)
     g = torch.Generator().manual_seed(1)
-    for n in (32, 512, 14336, 28672, 13824):
+    for n in (32, 512, 14336, 28672, 13824, 40, 80):   # 40 / 80: head counts whose get_hadK factor is had40 (n/K = 1, 2)
         # fp16-representable inputs, so the fp64 result is the exact transform of what the fp16 kernels see
         x = torch.randn(3 if n <= 512 else 1, n, generator=g).to(torch.float16).to(torch.float64)
         y = hd.matmul_hadU(x)

@@ -159,3 +159,17 @@ def test_three_op_fp16_division_is_exact_for_every_fp16_pair(oracle):
     For fp16-valued x and s that is the fp16 rounding of the IEEE quotient for EVERY pair: all 31743 positive finite
     scales x all 31744 non-negative finite x (the expression is odd in x), 10^9 pairs."""
     assert oracle.count_div3_mismatches(1, 0x7C00) == 0
+
+
+@pytest.mark.parametrize("heads", [40, 80])
+def test_heads_hadamard_with_table_factor_matches_reference_matmul_hadU(oracle, golden_dir, heads):
+    """Head counts whose get_hadK factor is a table (Llama-2-13B: 40 heads = had40; 80 = had40 (x) H2): the head
+    transform is matmul_hadU on rows of `heads` between the two transposes (quarot_llama.py:231-234); the reference's
+    own matmul_hadU was run on these rows (tests/golden/make_golden.py)."""
+    g = _load(golden_dir, "hadamard.npz")
+    x, y = g[f"x_{heads}"], g[f"y_{heads}"]          # [3, heads]: three (token, d) columns
+    hadK = g["had40"].astype(np.float16)
+    d = 1
+    attn = x.astype(np.float16).reshape(3, heads * d)   # [T, heads, d = 1]
+    out = oracle.heads_hadamard(attn, heads, None, hadK, 40).astype(np.float64)
+    assert np.allclose(out, y, atol=5e-3, rtol=0), np.abs(out - y).max()
