@@ -279,6 +279,8 @@ def main():
     rate = acc / draft if draft else float("nan")
     eff = emit / ((draft // args.k) * (args.k + 1)) if draft else float("nan")
     alg_bytes_cycle = (args.k + 1) * cfg.algorithmic_bytes_per_forward()
+    macs_per_token = 2 * cfg.packed_weight_bytes_per_layer() * cfg.num_hidden_layers + cfg.vocab_size * cfg.hidden_size
+    flops_cycle = 2.0 * macs_per_token * args.batch * (2 * args.k + 1)
     agree_txt = "weights' own agreement" if rho is None else f"synthetic draft/target agreement {rho}"
     out = {
         "metric": "accepted_tokens_per_s", "value": round(emit / dt, 2), "unit": "tokens/s", "n_gpus": world,
@@ -298,6 +300,10 @@ def main():
         "draft_acceptance_rate": round(rate, 4), "system_efficiency": round(eff, 4),
         "accepted_tokens": acc, "emitted_tokens": emit, "draft_tokens": draft,
         "cycle_hbm_GBps_algorithmic": round(alg_bytes_cycle / (dt / args.steps) / 1e9, 1),
+        # matrix-core work of a cycle: 2 flop per weight per token (layers + lm_head), k x B draft + (k+1) x B verify tokens,
+        # against the 2.5 PFLOP/s dense fp16 / int8-as-fp16-equivalent peak: decode is nowhere near MFMA-bound
+        "cycle_mfma_TFLOPs": round(flops_cycle / (dt / args.steps) / 1e12, 2),
+        "cycle_mfma_frac_of_2.5PF": round(flops_cycle / (dt / args.steps) / 2.5e15, 4),
     }
     if rho is not None and args.natural_steps > 0:
         # the same engine code with the random weights' own agreement (acceptance ~ a few %): reported beside the headline
