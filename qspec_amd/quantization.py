@@ -59,17 +59,16 @@ except Exception:  # ModuleNotFoundError (msgspec, ...) in this image
 
         @staticmethod
         def get_from_keys(config: Dict[str, Any], keys: List[str]) -> Any:
-            for key in keys:
-                if key in config:
-                    return config[key]
-            raise ValueError(f"Cannot find any of {keys} in the model's quantization config.")
+            """First of `keys` present in `config` (same contract as the vLLM helper: ValueError when none is)."""
+            hit = next((k for k in keys if k in config), None)
+            if hit is None:
+                raise ValueError(f"none of {keys} is in the quantization config")
+            return config[hit]
 
         @staticmethod
         def get_from_keys_or(config: Dict[str, Any], keys: List[str], default: Any) -> Any:
-            try:
-                return QuantizationConfig.get_from_keys(config, keys)
-            except ValueError:
-                return default
+            hit = next((k for k in keys if k in config), None)
+            return default if hit is None else config[hit]
 
     class LinearMethodBase(ABC):     # linear.py:85-116
         @abstractmethod
@@ -81,11 +80,11 @@ except Exception:  # ModuleNotFoundError (msgspec, ...) in this image
 
     LinearBase = torch.nn.Module
 
-    def set_weight_attrs(weight: torch.Tensor, weight_attrs: Optional[Dict[str, Any]]):   # model_executor/utils.py
-        if weight_attrs is None:
-            return
-        for key, value in weight_attrs.items():
-            assert not hasattr(weight, key), f"Overwriting existing tensor attribute: {key}"
+    def set_weight_attrs(weight: torch.Tensor, weight_attrs: Optional[Dict[str, Any]]):
+        """Attach loader metadata to a parameter (vllm.model_executor.utils.set_weight_attrs): no silent overwrite."""
+        for key, value in (weight_attrs or {}).items():
+            if hasattr(weight, key):
+                raise AssertionError(f"parameter attribute {key!r} is already set")
             setattr(weight, key, value)
 
     def register_quantization_config(name: str):
