@@ -178,6 +178,21 @@ class QSpecEngine:
         ops.spec_commit(self.out_tokens, self.seq_lens, self.last_token, self.gen_tokens, self.gen_lens)
 
     @torch.no_grad()
+    def step_no_spec(self):
+        """One NON-speculative decode step (spec_decode_worker.py:666-720 on a decode batch: the scorer alone, W4A16,
+        one token per sequence): taken when speculation is disabled for a step (`num_lookahead_slots == 0`,
+        `speculative_disable_by_batch_size`).  Eager: it is the rare path, the captured graph is the cycle's."""
+        m, bs = self.model, self.block_size
+        ops.spec_prepare_draft(self.last_token, self.seq_lens, self.block_tables, bs, self.d_tokens, self.d_pos,
+                               self.d_slots, self.d_ctx)                   # [last token] at position seq_len - 1
+        hs = m.forward(self.d_tokens, self.d_pos, self.kv_caches, self.md_draft, self.scratch_draft, w4a4=False)
+        logits = m.compute_logits(hs, self.scratch_draft)
+        ops.softmax_argmax(logits, self.draft_probs_kbv[0], self.draft_ids_kb[0])
+        self.out_tokens.fill_(-1)
+        self.out_tokens[:, 0] = self.draft_ids_kb[0]
+        ops.spec_commit(self.out_tokens, self.seq_lens, self.last_token, self.gen_tokens, self.gen_lens)
+
+    @torch.no_grad()
     def step(self):
         """Enqueue one cycle on the current stream (graph replay after the first call)."""
         if not self.use_graph:

@@ -194,10 +194,16 @@ class SpecDecodeWorker:
     def _run_no_spec(self, req: ExecuteModelRequest, skip_proposer: bool) -> List[SamplerOutput]:
         """:666-720.  Prompts: W4A16 prefill, first token sampled by the target."""
         sgml = req.seq_group_metadata_list
-        if not all(s.is_prompt for s in sgml):
-            raise NotImplementedError("non-speculative decode steps: run the engine with num_speculative_tokens=0")
-        prompts = [next(iter(s.seq_data.values())).prompt_token_ids for s in sgml]
         assert req.w4a4 is False
+        if not any(s.is_prompt for s in sgml):
+            # decode batch with speculation off for this step: the scorer alone emits one token per sequence
+            assert [self._slots[s.request_id] for s in sgml] == list(range(len(sgml))), "the batch is fixed after prefill"
+            self.engine.step_no_spec()
+            self.scorer_calls += 1
+            return [SamplerOutput(self.engine.out_tokens[:, 0].cpu(), self._request_ids(sgml))]
+        if not all(s.is_prompt for s in sgml):
+            raise NotImplementedError("mixed prompt / decode batches are not scheduled onto this worker")
+        prompts = [next(iter(s.seq_data.values())).prompt_token_ids for s in sgml]
         self.engine.add_sequences(prompts)
         self.scorer_calls += 1
         self._slots = {s.request_id: i for i, s in enumerate(sgml)}

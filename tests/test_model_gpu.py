@@ -260,3 +260,44 @@ def test_model_family_layer_matches_oracle(oracle, family, w4a4):
         assert torch.equal(out.view(torch.int16), b.view(torch.int16))
     else:
         assert (out.float() - b.float()).abs().max().item() < 2e-2
+
+
+def test_worker_decode_step_with_speculation_disabled(tiny):
+    """num_lookahead_slots == 0 on a decode batch (or speculative_disable_by_batch_size reached): the scorer alone runs,
+    W4A16, one token per sequence (spec_decode_worker.py:497-538,666-720).  The token is cross-checked against the
+    module-wise (reference op order) forward on a copy of the KV cache: same positions, slots and context lengths."""
+    from qspec_amd.model import AttentionMetadata
+    from qspec_amd.spec_decode import ExecuteModelRequest, SequenceGroupMetadata, create_spec_worker
+    from qspec_amd.spec_decode.worker import SequenceData, SpeculativeConfig
+    rng = np.random.default_rng(9)
+    w = create_spec_worker(model_config=tiny.config, model=tiny, speculative_config=SpeculativeConfig(3, speculative_disable_by_batch_size=2),
+                           max_num_seqs=4, max_model_len=256, block_size=16, device=DEV)
+    w.init_device()
+    nb, _ = w.determine_num_available_blocks()
+    w.initialize_cache(nb, 0)
+    lens = [10, 23, 5, 40]
+    sg = [SequenceGroupMetadata(f"r{i}", True, {i: SequenceData(rng.integers(0, 2048, n).tolist())}) for i, n in enumerate(lens)]
+    w.execute_model(ExecuteModelRequest(sg, num_lookahead_slots=0))
+    for s in sg:
+        s.is_prompt = False
+    eng = w.engine
+    seq0, last0 = eng.seq_lens.clone(), eng.last_token.clone()
+    # expectation from the module-wise path on a copy of the cache
+    kv = [(k.clone(), v.clone()) for k, v in eng.kv_caches]
+    pos = (seq0 - 1).to(torch.int64)
+    slots = torch.stack([eng._slots_for(b, pos[b:b + 1])[0] for b in range(4)])
+    md = AttentionMetadata(slots, eng.block_tables, seq0.clone(), torch.arange(5, dtype=torch.int32, device=DEV), 1, 1)
+    hs = tiny.forward_modulewise(last0, pos, kv, md, w4a4=False)
+    from qspec_amd.model import Scratch
+    expect = tiny.compute_logits(hs, Scratch(tiny.config, 4, 4, 1, 1, DEV)).float().argmax(-1)
+    calls = (w.proposer_calls, w.scorer_calls)
+    # (a) the scheduler asks for no lookahead slots; (b) the running queue reaches speculative_disable_by_batch_size
+    outs = w.execute_model(ExecuteModelRequest(sg, num_lookahead_slots=0))
+    assert len(outs) == 1 and torch.equal(outs[0].sampled_token_ids, expect.cpu())
+    assert (w.proposer_calls, w.scorer_calls) == (calls[0], calls[1] + 1)
+    assert torch.equal(eng.seq_lens, seq0 + 1) and torch.equal(eng.last_token, expect)
+    outs = w.execute_model(ExecuteModelRequest(sg, num_lookahead_slots=3, running_queue_size=2))
+    assert len(outs) == 1 and (outs[0].sampled_token_ids >= 0).all() and w.proposer_calls == calls[0]
+    # and a speculative step still works afterwards
+    outs = w.execute_model(ExecuteModelRequest(sg, num_lookahead_slots=3))
+    assert 1 <= len(outs) <= 4 and w.proposer_calls == calls[0] + 3
