@@ -187,7 +187,10 @@ __device__ __forceinline__ void lds_read_tr_b16_x16(uint32_t a, u32x2 (&lo)[8], 
 // PF: the loads of chunk i+1 fly underneath chunk i (64 more VGPRs: one workgroup per CU -- the decode shape at small
 // batch, where the launch is 256 workgroups of dependent round trips).  PF = false halves the register footprint so that
 // two workgroups share a CU: large batches, where occupancy hides the same latency.
-template <bool PF>
+// BT: the sequence's block-table row (<= 128 entries) is fetched into two registers per lane together with the
+// per-sequence metadata, and the chunk lookups become lane permutes: the dependent chain metadata -> table entry -> K / V
+// loses one memory round trip.
+template <bool PF, bool BT>
 __global__ __launch_bounds__(256) void paged_attention_kernel(
     const f16* __restrict__ q, int64_t q_stride, const f16* __restrict__ key_cache, const f16* __restrict__ value_cache,
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
@@ -208,6 +211,12 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
     const int gmask = (1 << group_log2) - 1, bmask = (1 << bs_log2) - 1;
     // per-sequence metadata through the VECTOR memory path: a uniform address would become an s_load, and a scalar
     // cache miss on data the previous kernel has just written costs microseconds, not hundreds of cycles
+    int btv0 = 0, btv1 = 0;
+    if constexpr (BT) {   // in the same round trip as the metadata (the early return below depends on it)
+        const int32_t* btr = block_tables + (size_t)blockIdx.x * max_blocks;
+        btv0 = btr[min((int)(threadIdx.x & 63), max_blocks - 1)];
+        btv1 = btr[min((int)(threadIdx.x & 63) + 64, max_blocks - 1)];
+    }
     int meta = 0;
     if (lane < 3) meta = lane < 2 ? q_start[seq + lane] : ctx_lens[seq];
     const int qs = __shfl(meta, 0, 64), qlen = __shfl(meta, 1, 64) - qs;
@@ -226,6 +235,14 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
     const int n_it = max(1, (min(kps, max(k_end - k_begin, 0)) + QS_ATT_CHUNK - 1) / QS_ATT_CHUNK);
     const int c16 = lane & 15, g4 = lane >> 4;
     const int32_t* bt = block_tables + (size_t)seq * max_blocks;
+    auto bt_get = [&](int bi) -> int {   // bi already clamped to the table
+        if constexpr (BT) {
+            const int a = __shfl(btv0, bi & 63, 64), b = __shfl(btv1, bi & 63, 64);
+            return bi < 64 ? a : b;
+        } else {
+            return bt[bi];
+        }
+    };
 #ifdef QS_ATT_STAMPS
     long long stamp[10];
 #define QS_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i])::"memory")
@@ -247,12 +264,12 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
 #pragma unroll
         for (int t2 = 0; t2 < 2; t2++) {
             const int p = kb + (wave * 2 + t2) * 16 + c16;
-            sl.k[t2] = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
+            sl.k[t2] = ((int64_t)bt_get(min(p >> bs_log2, max_blocks - 1)) << bs_log2) + (p & bmask);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int p = kb + wave * 4 + g4 + 16 * i;
-            sl.v[i] = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
+            sl.v[i] = ((int64_t)bt_get(min(p >> bs_log2, max_blocks - 1)) << bs_log2) + (p & bmask);
         }
     };
     auto fetch = [&](KV& kv, const Slots& sl) {
@@ -1061,14 +1078,16 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
     // more workgroups than CUs: occupancy (two per CU) instead of the in-workgroup prefetch
     static const int pf_env = getenv("QSPEC_ATTN_PF") ? atoi(getenv("QSPEC_ATTN_PF")) : -1;   // dev knob
     const bool pf = pf_env >= 0 ? pf_env != 0 : (size_t)n_seqs * nkv * n_rb * n_splits <= 256;
-    if (pf)
-        hipLaunchKernelGGL(paged_attention_kernel<true>, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), lds, st, q,
-                           q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv, bs_log2,
-                           group_log2, sm_scale, n_splits, n_rb, cnt, ws_o, ws_ml, out, out != nullptr ? 1 : 0);
-    else
-        hipLaunchKernelGGL(paged_attention_kernel<false>, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), lds, st, q,
-                           q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv, bs_log2,
-                           group_log2, sm_scale, n_splits, n_rb, cnt, ws_o, ws_ml, out, out != nullptr ? 1 : 0);
+    const bool btreg = max_blocks <= 128;
+#define QS_ATT_LAUNCH(PFV, BTV)                                                                                        \
+    hipLaunchKernelGGL((paged_attention_kernel<PFV, BTV>), dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), lds, st, q,     \
+                       q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv, bs_log2, \
+                       group_log2, sm_scale, n_splits, n_rb, cnt, ws_o, ws_ml, out, out != nullptr ? 1 : 0)
+    if (pf && btreg) QS_ATT_LAUNCH(true, true);
+    else if (pf) QS_ATT_LAUNCH(true, false);
+    else if (btreg) QS_ATT_LAUNCH(false, true);
+    else QS_ATT_LAUNCH(false, false);
+#undef QS_ATT_LAUNCH
     return 0;
 }
 
