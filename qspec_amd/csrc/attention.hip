@@ -544,6 +544,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
 // chunk loop of paged_attention_kernel spends 2.7 us in barrier-separated phases per chunk, the waves here overlap
 // each other: large batches and long contexts (more than one chunk per workgroup).  Partials only (out == NULL form).
 #define QS_AW_KEYS 32
+template <bool BT>   // BT: block-table row in registers, lookups as lane permutes (see paged_attention_kernel)
 __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
     const f16* __restrict__ q, int64_t q_stride, const f16* __restrict__ key_cache, const f16* __restrict__ value_cache,
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
@@ -558,6 +559,12 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
     const int gmask = (1 << group_log2) - 1, bmask = (1 << bs_log2) - 1;
     f16* vl = reinterpret_cast<f16*>(smem_raw + wave * WAVE_LDS);
     f16* pl = vl + QS_AW_KEYS * QS_ATT_VSTRIDE;
+    int btv0 = 0, btv1 = 0;
+    if constexpr (BT) {
+        const int32_t* btr = block_tables + (size_t)blockIdx.x * max_blocks;
+        btv0 = btr[min(lane, max_blocks - 1)];
+        btv1 = btr[min(lane + 64, max_blocks - 1)];
+    }
     int meta = 0;
     if (lane < 3) meta = lane < 2 ? q_start[seq + lane] : ctx_lens[seq];
     const int qs = __shfl(meta, 0, 64), qlen = __shfl(meta, 1, 64) - qs;
@@ -571,6 +578,14 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
     const int n_sl = (max(k_end - k_begin, 0) + QS_AW_KEYS - 1) / QS_AW_KEYS;
     const int32_t* bt = block_tables + (size_t)seq * max_blocks;
 
+    auto bt_get = [&](int bi) -> int {   // bi already clamped to the table
+        if constexpr (BT) {
+            const int a = __shfl(btv0, bi & 63, 64), b = __shfl(btv1, bi & 63, 64);
+            return bi < 64 ? a : b;
+        } else {
+            return bt[bi];
+        }
+    };
     struct Slots {
         int64_t k[2], v[8];
     };
@@ -581,12 +596,12 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
 #pragma unroll
         for (int t2 = 0; t2 < 2; t2++) {
             const int p = sb + t2 * 16 + c16;
-            sl.k[t2] = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
+            sl.k[t2] = ((int64_t)bt_get(min(p >> bs_log2, max_blocks - 1)) << bs_log2) + (p & bmask);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int p = sb + i * 4 + g4;
-            sl.v[i] = ((int64_t)bt[min(p >> bs_log2, max_blocks - 1)] << bs_log2) + (p & bmask);
+            sl.v[i] = ((int64_t)bt_get(min(p >> bs_log2, max_blocks - 1)) << bs_log2) + (p & bmask);
         }
     };
     auto fetch = [&](KV& kv, const Slots& sl) {
@@ -1070,9 +1085,14 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
     const bool long_splits = ((int64_t)max_blocks << bs_log2) > (int64_t)QS_ATT_CHUNK * n_splits;
     if (!out && (aw_env >= 0 ? aw_env != 0 : long_splits)) {
         const size_t wlds = (size_t)4 * (QS_AW_KEYS * QS_ATT_VSTRIDE * 2 + 2 * 16 * 40 * 2);
-        hipLaunchKernelGGL(paged_attention_waves_kernel, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), wlds, st, q,
-                           q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv, bs_log2,
-                           group_log2, sm_scale, n_splits, n_rb, ws_o, ws_ml);
+        if (max_blocks <= 128)
+            hipLaunchKernelGGL(paged_attention_waves_kernel<true>, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), wlds, st,
+                               q, q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv,
+                               bs_log2, group_log2, sm_scale, n_splits, n_rb, ws_o, ws_ml);
+        else
+            hipLaunchKernelGGL(paged_attention_waves_kernel<false>, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), wlds, st,
+                               q, q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv,
+                               bs_log2, group_log2, sm_scale, n_splits, n_rb, ws_o, ws_ml);
         return 0;
     }
     // more workgroups than CUs: occupancy (two per CU) instead of the in-workgroup prefetch
