@@ -73,17 +73,32 @@ class OracleModel:
             if w4a4:
                 a = O.rowabsmax_quant_i4(a, 1.0)
             o = self._linear(a, L["o_w"], L["o_s"], w4a4)
+            if return_trace:   # per-layer intermediates for teacher-forced tests (input = the previous hidden_{li-1})
+                trace[f"qkv_{li}"] = np.concatenate([qr, kr, v], axis=1)
+                trace[f"attn_{li}"] = attn
+                trace[f"o_in_{li}"] = a          # (q, scale) under w4a4, fp16 otherwise
+                trace[f"o_out_{li}"] = o
+                trace[f"ln1_{li}"] = x           # the layer's first norm: (q, scale) under w4a4, fp16 otherwise
             hidden = O.add_f16(hidden, o)
+            if return_trace:
+                trace[f"hidden_attn_{li}"] = hidden.copy()
             if w4a4:
                 q, s, _ = O.ln_quant_i4(hidden, eps)
                 x = (q, s)
             else:
                 x = O.ln_fp16(hidden, eps)
             gu = self._linear(x, L["gate_up_w"], L["gate_up_s"], w4a4)
-            g = O.mlp_hadamard(O.silu_mul(gu, cfg.intermediate_size), self.had, self.had_K, self.mlp_scale)
+            act = O.silu_mul(gu, cfg.intermediate_size)
+            g = O.mlp_hadamard(act, self.had, self.had_K, self.mlp_scale)
             if w4a4:
                 g = O.rowabsmax_quant_i4(g, 1.0)
+            if return_trace:
+                trace[f"ln2_{li}"] = x
+                trace[f"act_{li}"] = act
+                trace[f"down_in_{li}"] = g
             dn = self._linear(g, L["down_w"], L["down_s"], w4a4)
+            if return_trace:
+                trace[f"down_out_{li}"] = dn
             hidden = O.add_f16(hidden, dn)
             if return_trace:
                 trace[f"hidden_{li}"] = hidden.copy()
@@ -109,6 +124,7 @@ class OracleEngine:
         self.last_token = np.zeros(B, np.int64)
         self.generated = [[] for _ in range(B)]
         self.counters = [0, 0, 0]
+        self.prefill_probs = [None] * B   # the target's distribution at the end of each prompt (near-tie diagnostics)
         self.agreement_rho = None  # bench-only synthetic agreement (see qspec_bench_force_agreement)
         self._agree_rng = np.random.default_rng(1234)
 
@@ -122,7 +138,8 @@ class OracleEngine:
             pos = np.arange(T, dtype=np.int64)
             hs = self.m.forward(np.asarray(p), pos, self.kv, self._slots(b, pos), self.block_tables[b:b + 1],
                                 np.array([T], np.int32), np.array([0, T], np.int32), w4a4=False)
-            _, tok = O.softmax_argmax(self.m.logits(hs[T - 1:T]))
+            pr, tok = O.softmax_argmax(self.m.logits(hs[T - 1:T]))
+            self.prefill_probs[b] = pr[0]
             self.seq_lens[b] = T + 1
             self.last_token[b] = tok[0]
             self.generated[b].append(int(tok[0]))

@@ -277,11 +277,10 @@ class QuarotLlamaForCausalLM:
                 x, xs = normed, None
             # gate_up -> silu*up -> online hadamard (+ quant) -> down_proj                              :266-299
             if fuse:
-                if tp_on:   # column-parallel gate_up: own channels into a zeroed [T, I], all-reduce = concatenation
+                if tp_on:   # column-parallel gate_up: own channels of [T, I], then all-gather of the channel ranges
                     c0, c1 = self.tp.channel_range(cfg.intermediate_size)
-                    act.zero_()
                     ops.gate_up_silu_linear_shard(x, gu_w, gu_s, act, c0, c1 - c0)
-                    self.tp.all_reduce(act)
+                    self.tp.all_gather_channels(act, cfg.intermediate_size)
                 else:
                     ops.gate_up_silu_linear(x, xs, gu_w, gu_s, act)
                 if w4a4:
@@ -325,7 +324,7 @@ class QuarotLlamaForCausalLM:
         logits = scratch.logits[:T]
         if shard_vocab and self.tp is not None and self.tp.world > 1:
             v0, v1 = self.tp.vocab_range(self.config.vocab_size)
-            local = torch.empty(T, v1 - v0, dtype=torch.float16, device=self.device)
+            local = self.tp._buf("vocab.local", (T, v1 - v0), torch.float16, self.device)
             ops.linear_f16(hidden_states, self.lm_head[v0:v1], local)
             return self.tp.all_gather_vocab(local, logits, self.config.vocab_size)
         ops.linear_f16(hidden_states, self.lm_head, logits)

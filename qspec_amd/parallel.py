@@ -8,8 +8,7 @@ The reference QSpec model has no TP (plain nn.Embedding / Linear4bit / HF lm_hea
     bit-identical tokens (the Philox state of the rejection sampler is seeded identically);
   * the VERIFY pass (decode-sized M) shards the three weight-heavy GEMMs that tolerate it:
         o_proj    row-parallel  (K range of the Hadamard output)          -> all-reduce [T, H]  fp16
-        gate_up   column-parallel (channel range, silu*up fused)          -> all-reduce [T, I]  fp16 of zero-padded
-                                                                             shards (= concatenation, exact)
+        gate_up   column-parallel (channel range, silu*up fused)          -> all-gather [T, I/tp] fp16 (exact)
         down_proj row-parallel  (K range of the Hadamard output)          -> all-reduce [T, H]  fp16
         lm_head   vocab-parallel                                          -> all-gather [T, V/tp]
     qkv_proj + RoPE + KV write + attention stay replicated (the online Hadamards mix all heads / all of I and
@@ -61,12 +60,108 @@ def shard_layers_pays(layer_weight_bytes: int, world: int) -> bool:
     return saved > 3.0 * t_coll
 
 
+class TorchDistComm:
+    """Collectives through torch.distributed: RCCL (backend "nccl" on ROCm) on device tensors, enqueued on the current
+    stream; `gloo` for tests (device tensors are staged through the host)."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+        self.group = group
+        self.backend = dist.get_backend(group)
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        if self.backend == "gloo" and t.is_cuda:
+            c = t.cpu()
+            dist.all_reduce(c, group=self.group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, group=self.group)
+        return t
+
+    def all_gather(self, recv: torch.Tensor, send: torch.Tensor) -> torch.Tensor:
+        """recv [world * n] <- every rank's send [n], rank-major."""
+        if self.backend == "gloo" and send.is_cuda:
+            rc = recv.cpu()
+            dist.all_gather_into_tensor(rc, send.cpu(), group=self.group)
+            recv.copy_(rc)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        return recv
+
+    def broadcast_object(self, obj, src: int = 0):
+        box = [obj]
+        dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
+
+
+class ThreadComm:
+    """`world` ranks as threads of ONE process sharing one device (tests: a GPU box admits at most 6 processes on
+    its card, so the 8-rank shard ranges of Llama-3-70B are exercised in-process).  All ranks enqueue on the same
+    stream, so stream order = the order the barrier imposes: every rank's producer kernels are enqueued before rank
+    0 enqueues the reduction, and the result is copied back after it."""
+
+    class Shared:
+        def __init__(self, world: int):
+            import threading
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+            self.result = None
+
+    def __init__(self, shared: "ThreadComm.Shared", rank: int):
+        self.sh, self.rank, self.backend = shared, rank, "threads"
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        sh = self.sh
+        sh.slots[self.rank] = t
+        sh.barrier.wait()
+        if self.rank == 0:   # fixed rank order, fp32 accumulate, one rounding: what a one-shot all-reduce does
+            acc = sh.slots[0].float()
+            for r in range(1, sh.world):
+                acc = acc + sh.slots[r].float()
+            sh.result = acc.to(t.dtype)
+        sh.barrier.wait()
+        t.copy_(sh.result)
+        sh.barrier.wait()
+        return t
+
+    def all_gather(self, recv: torch.Tensor, send: torch.Tensor) -> torch.Tensor:
+        sh = self.sh
+        sh.slots[self.rank] = send
+        sh.barrier.wait()
+        n = send.numel()
+        flat = recv.view(-1)
+        for r in range(sh.world):
+            flat[r * n:(r + 1) * n].copy_(sh.slots[r].reshape(-1))
+        sh.barrier.wait()
+        return recv
+
+    def broadcast_object(self, obj, src: int = 0):
+        sh = self.sh
+        if self.rank == src:
+            sh.result = obj
+        sh.barrier.wait()
+        out = sh.result
+        sh.barrier.wait()
+        return out
+
+
 class TensorParallel:
-    def __init__(self, rank: int, world: int, group: Optional[dist.ProcessGroup] = None, shard_layers: bool = True):
+    def __init__(self, rank: int, world: int, group: Optional[dist.ProcessGroup] = None, shard_layers: bool = True,
+                 comm=None):
         self.rank, self.world, self.group = rank, world, group
-        self.backend = dist.get_backend(group) if world > 1 else "none"
+        if comm is None and world > 1:
+            comm = TorchDistComm(group)
+        self.comm = comm
+        self.backend = comm.backend if comm is not None else "none"
         # False: the decoder layers of the verify pass stay replicated (no collectives); lm_head stays vocab-parallel
         self.shard_layers = shard_layers
+        self._bufs = {}   # exchange buffers, allocated once per shape (nothing is allocated inside a captured cycle)
+
+    def _buf(self, key, shape, dtype, device):
+        k = (key, tuple(shape), dtype, str(device))
+        if k not in self._bufs:
+            self._bufs[k] = torch.empty(*shape, dtype=dtype, device=device)
+        return self._bufs[k]
 
     def k_range(self, K: int) -> Tuple[int, int]:
         """Row-parallel K range: multiples of 128 (one MFMA step of the W4A16 kernel)."""
@@ -82,34 +177,46 @@ class TensorParallel:
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             return t
-        if self.backend == "gloo" and t.is_cuda:
-            c = t.cpu()
-            dist.all_reduce(c, group=self.group)
-            t.copy_(c)
+        return self.comm.all_reduce(t)
+
+    def _all_gather_columns(self, full: torch.Tensor, n: int, align: int, key: str) -> torch.Tensor:
+        """full [T, n]: every rank has written its own column range (shard_range(n, world, rank, align)); on return
+        every rank holds all columns.  Moves 1/world of what an all-reduce of the zero-padded tensor would."""
+        T = full.shape[0]
+        ranges = [shard_range(n, self.world, r, align) for r in range(self.world)]
+        wmax = max(hi - lo for lo, hi in ranges)
+        lo, hi = ranges[self.rank]
+        send = self._buf(key + ".send", (T, wmax), full.dtype, full.device)
+        recv = self._buf(key + ".recv", (self.world, T, wmax), full.dtype, full.device)
+        send[:, :hi - lo].copy_(full[:, lo:hi])
+        self.comm.all_gather(recv.view(self.world * T, wmax), send)
+        if all(h - l == wmax for l, h in ranges):      # equal shards: one strided copy
+            full.view(T, self.world, wmax).copy_(recv.permute(1, 0, 2))
         else:
-            dist.all_reduce(t, group=self.group)
-        return t
+            for r, (l, h) in enumerate(ranges):
+                full[:, l:h].copy_(recv[r, :, :h - l])
+        return full
+
+    def all_gather_channels(self, act: torch.Tensor, I: int) -> torch.Tensor:
+        """Column-parallel gate_up: act [T, I] with this rank's channel_range written -> complete on every rank."""
+        if self.world == 1:
+            return act
+        return self._all_gather_columns(act, I, 32, "channels")
 
     def all_gather_vocab(self, local: torch.Tensor, out: torch.Tensor, V: int) -> torch.Tensor:
-        """local [T, V_r] (this rank's vocab range) -> out [T, V].  Ranges may differ by one 16-column tile, so the
-        shards travel zero-padded to the widest range and are cut back on arrival."""
+        """local [T, V_r] (this rank's vocab range) -> out [T, V] (logits_processor.py:104-107)."""
         if self.world == 1:
             out.copy_(local)
             return out
-        T = local.shape[0]
-        widths = [shard_range(V, self.world, r, 16) for r in range(self.world)]
-        wmax = max(hi - lo for lo, hi in widths)
-        send = local if local.shape[1] == wmax else torch.nn.functional.pad(local, (0, wmax - local.shape[1]))
-        recv = torch.empty(self.world * T, wmax, dtype=local.dtype, device=local.device)  # rank-major rows
-        if self.backend == "gloo" and local.is_cuda:
-            rc = recv.cpu()
-            dist.all_gather_into_tensor(rc, send.contiguous().cpu(), group=self.group)
-            recv.copy_(rc)
-        else:
-            dist.all_gather_into_tensor(recv, send.contiguous(), group=self.group)
-        for r, (lo, hi) in enumerate(widths):
-            out[:, lo:hi] = recv[r * T:(r + 1) * T, :hi - lo]
-        return out
+        lo, hi = self.vocab_range(V)
+        out[:, lo:hi].copy_(local)
+        return self._all_gather_columns(out, V, 16, "vocab")
+
+    def broadcast_object(self, obj, src: int = 0):
+        """Control plane (spec_decode_worker.py:524-538: broadcast_tensor_dict of the per-step control scalars)."""
+        if self.world == 1:
+            return obj
+        return self.comm.broadcast_object(obj, src)
 
 
 def init_from_env(device: str) -> TensorParallel:

@@ -1,0 +1,201 @@
+"""The draft pass's launches in EXACTLY the forms QuarotLlamaForCausalLM.forward issues them (qspec_amd/model.py,
+`ln_fused` branch), at the Llama-3-8B layer shapes, each compared bit for bit with the CPU oracle's op sequence
+(one hop: HIP launch -> oracle; no other HIP kernel in between).
+
+    ln_qkv_rope_linear(hid, None, None, ...)        N = 6144,  K = 4096   oracle: ln_quant_i4 -> gemm_w4a4 -> rope -> cache write
+    rowwise_scaled_linear_s4s4_residual (in place)  N = 4096,  K = 4096   oracle: gemm_w4a4 -> add_f16
+    ln_gate_up_silu_linear(hid, None, None, ...)    N = 28672, K = 4096   oracle: ln_quant_i4 -> gemm_w4a4 -> silu_mul
+    mlp_hadamard(act, had28, ..., q, scale)         I = 14336             oracle: mlp_hadamard -> rowabsmax_quant_i4
+    rowwise_scaled_linear_s4s4_residual (in place)  N = 4096,  K = 14336  oracle: gemm_w4a4 -> add_f16
+
+Reference op order: vllm/model_executor/models/quarot_llama.py:363-392 (decoder layer), :177-243 (attention block),
+:266-299 (MLP block).  M in {3, 4, 16} covers the every-workgroup-recomputes-the-norm form (M < 8) and the producer /
+hand-off form (M >= 8) of the norm prologue; the batch-32 forms (two token tiles, separate norm launch) follow below.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+H, I, NQ, NKV, D, BS = 4096, 14336, 32, 8, 128, 16
+NQKV = (NQ + 2 * NKV) * D
+EPS = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from qspec_amd import ops as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint16)
+
+
+def rand_hidden(rng, T, n, scale=1.0):
+    x = rng.standard_normal((T, n)) * scale
+    x[:, rng.integers(0, n, 8)] *= 20.0
+    return x.astype(np.float16)
+
+
+def rand_packed(rng, N, K):
+    return rng.integers(-128, 128, (N, K // 2)).astype(np.int8)     # every byte = two random int4
+
+
+def rand_scales(rng, N):
+    return (rng.random(N) * 0.01 + 0.001).astype(np.float16)
+
+
+def oracle_qkv(oracle, hid, wq, ws, pos, cs, slots, nblocks):
+    q, s, _ = oracle.ln_quant_i4(hid, EPS)
+    qkv = oracle.gemm_w4a4(q, s, wq, ws)
+    T = hid.shape[0]
+    qr, kr = oracle.rope_neox(pos, qkv[:, :NQ * D], qkv[:, NQ * D:(NQ + NKV) * D], cs, D)
+    v = qkv[:, (NQ + NKV) * D:]
+    kc = np.zeros((nblocks, BS, NKV, D), np.float16)
+    vc = np.zeros_like(kc)
+    oracle.reshape_and_cache_flash(kr.reshape(T, NKV, D), v.reshape(T, NKV, D), kc, vc, slots)
+    return np.concatenate([qr, kr, v], axis=1), kc, vc
+
+
+@pytest.mark.parametrize("M", [3, 4, 16])
+def test_ln_qkv_rope_linear_draft_form_vs_oracle(ops, oracle, M):
+    rng = np.random.default_rng(100 + M)
+    hid = rand_hidden(rng, M, H)
+    wq, ws = rand_packed(rng, NQKV, H), rand_scales(rng, NQKV)
+    cs = oracle.make_cos_sin_cache(D, 2048, 500000.0)
+    pos = rng.integers(0, 2048, M).astype(np.int64)
+    slots = rng.permutation(64 * BS)[:M].astype(np.int64)
+    ref, kc0, vc0 = oracle_qkv(oracle, hid, wq, ws, pos, cs, slots, 64)
+    hid_d = dev(hid)
+    before = hid_d.clone()
+    qkv = torch.empty(M, NQKV, dtype=torch.float16, device=DEV)
+    kc = torch.zeros(64, BS, NKV, D, dtype=torch.float16, device=DEV)
+    vc = torch.zeros_like(kc)
+    ops.ln_qkv_rope_linear(hid_d, None, None, EPS, dev(wq), dev(ws), qkv, dev(pos), dev(cs), kc, vc, dev(slots), NQ, NKV, D)
+    assert np.array_equal(bits(host(qkv)), bits(ref))
+    assert np.array_equal(bits(host(kc)), bits(kc0)) and np.array_equal(bits(host(vc)), bits(vc0))
+    assert torch.equal(hid_d.view(torch.int16), before.view(torch.int16))      # delta = None: the stream is read only
+
+
+@pytest.mark.parametrize("M", [3, 4, 16])
+def test_ln_gate_up_silu_linear_draft_form_vs_oracle(ops, oracle, M):
+    rng = np.random.default_rng(200 + M)
+    hid = rand_hidden(rng, M, H)
+    wg, wgs = rand_packed(rng, 2 * I, H), rand_scales(rng, 2 * I)
+    q, s, _ = oracle.ln_quant_i4(hid, EPS)
+    ref = oracle.silu_mul(oracle.gemm_w4a4(q, s, wg, wgs), I)
+    act = torch.empty(M, I, dtype=torch.float16, device=DEV)
+    ops.ln_gate_up_silu_linear(dev(hid), None, None, EPS, dev(wg), dev(wgs), act)
+    assert np.array_equal(bits(host(act)), bits(ref))
+
+
+@pytest.mark.parametrize("M", [3, 4, 16])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (4096, 14336)])
+def test_s4s4_residual_in_place_draft_form_vs_oracle(ops, oracle, M, N, K):
+    rng = np.random.default_rng(300 + M + K)
+    xq = oracle.pack_i4(rng.integers(-8, 8, (M, K)).astype(np.int8))
+    xs = (rng.random(M) * 0.1 + 0.01).astype(np.float16)
+    wq, ws = rand_packed(rng, N, K), rand_scales(rng, N)
+    resid = rand_hidden(rng, M, N)
+    ref = oracle.add_f16(resid, oracle.gemm_w4a4(xq, xs, wq, ws))
+    hid = dev(resid)
+    ops.rowwise_scaled_linear_s4s4_residual(dev(xq), dev(xs), dev(wq), dev(ws), hid, hid)     # in place, as the layer does
+    assert np.array_equal(bits(host(hid)), bits(ref))
+
+
+@pytest.mark.parametrize("M", [3, 4, 16, 32])
+def test_mlp_hadamard_quant_draft_form_vs_oracle(ops, oracle, golden_dir, M):
+    rng = np.random.default_rng(400 + M)
+    had = np.load(os.path.join(golden_dir, "hadamard.npz"))["had28"].astype(np.float16)
+    act = rand_hidden(rng, M, I, 0.5)
+    sc = oracle.rsqrt_scale(I)
+    q0, s0 = oracle.rowabsmax_quant_i4(oracle.mlp_hadamard(act, had, 28, sc), 1.0)
+    q = torch.empty(M, I // 2, dtype=torch.int8, device=DEV)
+    s = torch.empty(M, dtype=torch.float16, device=DEV)
+    ops.mlp_hadamard(dev(act), dev(had), 28, sc, q=q, scale=s)
+    assert np.array_equal(host(q), q0) and np.array_equal(bits(host(s)), bits(s0))
+
+
+def test_draft_mlp_block_chain_vs_oracle(ops, oracle, golden_dir):
+    """The four MLP-side launches of a draft layer chained on the device exactly as model.py does (no host round trip
+    in between), against the oracle chain: post-attention norm -> gate_up -> silu*up -> Hadamard -> quant -> down_proj
+    -> residual add (quarot_llama.py:380-392)."""
+    M = 4
+    rng = np.random.default_rng(77)
+    had = np.load(os.path.join(golden_dir, "hadamard.npz"))["had28"].astype(np.float16)
+    hid = rand_hidden(rng, M, H)
+    wg, wgs = rand_packed(rng, 2 * I, H), rand_scales(rng, 2 * I)
+    wd, wds = rand_packed(rng, H, I), rand_scales(rng, H)
+    sc = oracle.rsqrt_scale(I)
+    q, s, _ = oracle.ln_quant_i4(hid, EPS)
+    a = oracle.silu_mul(oracle.gemm_w4a4(q, s, wg, wgs), I)
+    q3, s3 = oracle.rowabsmax_quant_i4(oracle.mlp_hadamard(a, had, 28, sc), 1.0)
+    ref = oracle.add_f16(hid, oracle.gemm_w4a4(q3, s3, wd, wds))
+    hid_d = dev(hid)
+    act = torch.empty(M, I, dtype=torch.float16, device=DEV)
+    q3_d = torch.empty(M, I // 2, dtype=torch.int8, device=DEV)
+    s3_d = torch.empty(M, dtype=torch.float16, device=DEV)
+    ops.ln_gate_up_silu_linear(hid_d, None, None, EPS, dev(wg), dev(wgs), act)
+    ops.mlp_hadamard(act, dev(had), 28, sc, q=q3_d, scale=s3_d)
+    ops.rowwise_scaled_linear_s4s4_residual(q3_d, s3_d, dev(wd), dev(wds), hid_d, hid_d)
+    assert np.array_equal(host(q3_d), q3) and np.array_equal(bits(host(s3_d)), bits(s3))
+    assert np.array_equal(bits(host(hid_d)), bits(ref))
+
+
+# ------------------------------------------------------------------ batch 32 (config 3): separate norm + two token tiles
+
+@pytest.mark.parametrize("M", [32])
+def test_batch32_draft_forms_vs_oracle(ops, oracle, M):
+    """Config 3 (k = 5, bs = 32) takes the non-fused branch of model.forward: add_rms_norm_i4 -> qkv_rope_linear ->
+    ... -> rowwise_scaled_linear -> add_rms_norm_i4 -> gate_up_silu_linear -> ... -> rowwise_scaled_linear, with the
+    M > 16 (two token tiles) streaming GEMMs.  Each against the oracle directly at the full layer shapes."""
+    rng = np.random.default_rng(500 + M)
+    hid, delta = rand_hidden(rng, M, H), rand_hidden(rng, M, H, 0.3)
+    h0 = oracle.add_f16(hid, delta)
+    q0, s0, _ = oracle.ln_quant_i4(h0, EPS)
+    q = torch.empty(M, H // 2, dtype=torch.int8, device=DEV)
+    s = torch.empty(M, dtype=torch.float16, device=DEV)
+    hid_d = dev(hid)
+    ops.add_rms_norm_i4(q, s, hid_d, hid_d, dev(delta), EPS)
+    assert np.array_equal(host(q), q0) and np.array_equal(bits(host(s)), bits(s0))
+    assert np.array_equal(bits(host(hid_d)), bits(h0))
+    # qkv + rope + cache write
+    wq, ws = rand_packed(rng, NQKV, H), rand_scales(rng, NQKV)
+    cs = oracle.make_cos_sin_cache(D, 2048, 500000.0)
+    pos = rng.integers(0, 2048, M).astype(np.int64)
+    slots = rng.permutation(64 * BS)[:M].astype(np.int64)
+    ref, kc0, vc0 = oracle_qkv(oracle, h0, wq, ws, pos, cs, slots, 64)
+    qkv = torch.empty(M, NQKV, dtype=torch.float16, device=DEV)
+    kc = torch.zeros(64, BS, NKV, D, dtype=torch.float16, device=DEV)
+    vc = torch.zeros_like(kc)
+    ops.qkv_rope_linear(q, s, dev(wq), dev(ws), qkv, dev(pos), dev(cs), kc, vc, dev(slots), NQ, NKV, D)
+    assert np.array_equal(bits(host(qkv)), bits(ref))
+    assert np.array_equal(bits(host(kc)), bits(kc0)) and np.array_equal(bits(host(vc)), bits(vc0))
+    # gate_up + silu*up
+    wg, wgs = rand_packed(rng, 2 * I, H), rand_scales(rng, 2 * I)
+    act = torch.empty(M, I, dtype=torch.float16, device=DEV)
+    ops.gate_up_silu_linear(q, s, dev(wg), dev(wgs), act)
+    assert np.array_equal(bits(host(act)), bits(oracle.silu_mul(oracle.gemm_w4a4(q0, s0, wg, wgs), I)))
+    # o_proj / down_proj plain form
+    for K in (H, I):
+        xq = oracle.pack_i4(rng.integers(-8, 8, (M, K)).astype(np.int8))
+        xs = (rng.random(M) * 0.1 + 0.01).astype(np.float16)
+        w, wsc = rand_packed(rng, H, K), rand_scales(rng, H)
+        out = torch.empty(M, H, dtype=torch.float16, device=DEV)
+        ops.rowwise_scaled_linear_cutlass_s4s4_unified(dev(xq), dev(xs), dev(w), dev(wsc), None, out)
+        assert np.array_equal(bits(host(out)), bits(oracle.gemm_w4a4(xq, xs, w, wsc)))
