@@ -196,11 +196,16 @@ int qspec_prefetch(const void* p, size_t bytes, int workgroups, void* stream);
 /* Tensor-parallel views of the SAME buffers (no reference counterpart: the reference QSpec model has no TP).
  * _ksliced: row-parallel shard = a K range of x [M, *] (row stride ldx halves) and of wq [N, *] (row stride ldw_bytes);
  *           the caller all-reduces the partial outputs.
+ * _ksliced_raw: the same K range as raw fp32 sums part [M, N] (no channel scale, no rounding): reduced across ranks in
+ *           fp32 and finished (scale, one fp16 rounding, residual add, norm) by qspec_add_rms_norm_fp16_partial with
+ *           slices = 1, so that the sharded sum is rounded once, as on one GPU.  M <= 32.
  * _shard:   column-parallel shard of gate_up = intermediate channels [first_channel, first_channel + num_channels);
  *           act keeps its full [M, intermediate] layout, only the shard's columns are written. */
 int qspec_w4a16_linear_ksliced(const qspec_half* x, int64_t ldx, const int8_t* wq, int64_t ldw_bytes,
                                const qspec_half* ws, qspec_half* out, int M, int N, int K, void* workspace,
                                void* stream);
+int qspec_w4a16_linear_ksliced_raw(const qspec_half* x, int64_t ldx, const int8_t* wq, int64_t ldw_bytes, float* part,
+                                   int M, int N, int K, void* workspace, void* stream);
 int qspec_gate_up_silu_linear_w4a16_shard(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act,
                                           int M, int intermediate, int K, int first_channel, int num_channels,
                                           void* workspace, void* stream);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "qspec_w4a16_linear_partial": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "qspec_add_rms_norm_fp16_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _vp]),
     "qspec_w4a16_linear_ksliced": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "qspec_w4a16_linear_ksliced_raw": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _vp]),
     "qspec_gate_up_silu_linear_w4a16_shard": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "qspec_linear_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_dequant_w4": (_i, [_vp, _vp, _vp, _i, _i, _vp]),

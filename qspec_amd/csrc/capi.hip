@@ -447,6 +447,17 @@ int qspec_w4a16_linear_ksliced(const qspec_half* x, int64_t ldx, const int8_t* w
     }
     return finish(op, qspec::gemm_w4a16_strided(CH(x), ldx, wq, ldw_bytes, CH(ws), H(out), M, N, K, workspace, ST));
 }
+int qspec_w4a16_linear_ksliced_raw(const qspec_half* x, int64_t ldx, const int8_t* wq, int64_t ldw_bytes, float* part,
+                                   int M, int N, int K, void* workspace, void* stream) {
+    const char* op = "qspec_w4a16_linear_ksliced_raw";
+    if (M == 0 || N == 0) return 0;
+    NONNULL(op, x); NONNULL(op, wq); NONNULL(op, part);
+    if (M > 32) return fail("%s: M=%d > 32 (decode-sized verify batches only)", op, M);
+    if (N % 16 || K % 128 || ldw_bytes % 16 || ldx % 8) return fail("%s: need N%%16, K%%128, ldw%%16, ldx%%8 == 0", op);
+    if (use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K))
+        return finish(op, qspec::gemm_w4a16_stream_partial(CH(x), ldx, wq, ldw_bytes, part, M, N, K, 1, ST));
+    return finish(op, qspec::gemm_w4a16_strided_raw(CH(x), ldx, wq, ldw_bytes, part, M, N, K, workspace, ST));
+}
 int qspec_gate_up_silu_linear_w4a16_shard(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act,
                                           int M, int intermediate, int K, int first_channel, int num_channels,
                                           void* workspace, void* stream) {

@@ -52,7 +52,7 @@ __device__ __forceinline__ i32x4 widen_s4x16(u32 p0, u32 p1) {
 //              out[m, c] = h(h(silu(gate)) * up)   (quarot_llama.py:279-284), half the output bytes.
 // Rounding points are unchanged: the GEMM result is rounded to fp16 exactly where the reference's op returns
 // fp16, and only then rotated / activated.
-enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_GATEUP = 2 };
+enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_GATEUP = 2, EPI_RAW = 3 };   // RAW (W4A16 only): unscaled fp32 sums, out viewed as float [M, N]
 
 struct EpiArgs {
     const int64_t* positions;   // [M]
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_w4a4_kernel(const int8_t* __restrict
     const int t = threadIdx.x, el = t & 63, reg = t >> 6;
     const int c = el & 15;
     const int n = tile_row<EPI>(tb, c, ea);
-    const float swn = h2f(ws[n]);
+    const float swn = EPI == EPI_RAW ? 1.0f : h2f(ws[n]);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
         const int row16 = 4 * (el >> 4) + reg;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void gemm_w4a16_kernel(const f16* __restrict__
     const int t = threadIdx.x, el = t & 63, reg = t >> 6;
     const int c = el & 15;
     const int n = tile_row<EPI>(tb, c, ea);
-    const float swn = h2f(ws[n]);
+    const float swn = EPI == EPI_RAW ? 1.0f : h2f(ws[n]);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
         const int row16 = 4 * (el >> 4) + reg;
@@ -379,10 +379,15 @@ __global__ __launch_bounds__(256) void gemm_w4a16_kernel(const f16* __restrict__
         f16 hv = (f16)0.0f;
         if (valid) {
             float sum = ((red[0][mt][t] + red[1][mt][t]) + red[2][mt][t]) + red[3][mt][t];
+            if (EPI == EPI_RAW) {
+                reinterpret_cast<float*>(out)[(size_t)m * N + tb * 16 + c] = sum;
+                continue;
+            }
             float v = sum * swn;
             if (bias) v = v + h2f(bias[n]);
             hv = f2h(v);
         }
+        if (EPI == EPI_RAW) continue;
         epilogue_store<EPI>(hv, valid, m, c, tb, N, out, &ex[mt][0], row16 * 16 + c, ea);
     }
 }
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(256) void gemm_w4a16_2d_kernel(const f16* __restric
             }
     }
     const int n = tile_row<EPI>(tb, r, ea);
-    const float swn = h2f(ws[n]);
+    const float swn = EPI == EPI_RAW ? 1.0f : h2f(ws[n]);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -525,6 +530,10 @@ __global__ __launch_bounds__(256) void gemm_w4a16_2d_kernel(const f16* __restric
             const int row16 = 4 * g + reg;
             const int m = mt * 16 + row16;
             const bool valid = m < M;
+            if (EPI == EPI_RAW) {
+                if (valid) reinterpret_cast<float*>(out)[(size_t)m * N + tb * 16 + r] = acc[mt][reg];
+                continue;
+            }
             float v = acc[mt][reg] * swn;
             if (bias) v = v + h2f(bias[n]);
             epilogue_store<EPI>(f2h(v), valid, m, r, tb, N, out, &ex[wave][mt][0], row16 * 16 + r, ea);
@@ -583,6 +592,18 @@ int gemm_w4a16_strided(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw,
     ea.ldw = ldw;
     ea.ldx = ldx;
     return launch_w4a16<EPI_PLAIN>(x, wq, ws, nullptr, out, M, N, K, ea, wsp, st);
+}
+
+// Raw fp32 sums (no channel scale, no rounding) of a K range: part [M, N] float.  The row-parallel shard of the
+// tensor-parallel verify pass: partials are reduced across ranks in fp32 and rounded once, as on one GPU.
+int gemm_w4a16_strided_raw(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, float* part, int M, int N, int K,
+                           void* wsp, hipStream_t st) {
+    if (M == 0 || N == 0) return 0;
+    if (N % 16 || K % 128 || ldw % 16 || ldx % 8 || M > 32) return -1;
+    EpiArgs ea{};
+    ea.ldw = ldw;
+    ea.ldx = ldx;
+    return launch_w4a16<EPI_RAW>(x, wq, nullptr, nullptr, reinterpret_cast<f16*>(part), M, N, K, ea, wsp, st);
 }
 
 int gemm_w4a16_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,

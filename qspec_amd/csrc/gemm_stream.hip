@@ -1105,7 +1105,7 @@ int gemm_w4a16_stream_partial_slices(int M, int N, int K) {
 }
 int gemm_w4a16_stream_partial(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, float* part, int M, int N, int K,
                               int S, hipStream_t st) {
-    if (S < 2 || K % S || !gemm_w4a16_stream_supported(M, N, K / S) || !part) return -1;
+    if (S < 1 || K % S || !gemm_w4a16_stream_supported(M, N, K / S) || !part) return -1;
     StreamArgs a{};
     a.x = x; a.ldx = ldx ? ldx : K; a.ldw = ldw ? ldw : K / 2; a.wq = reinterpret_cast<const uint8_t*>(wq);
     a.M = M; a.N = N; a.K = K / S; a.ntiles = N / 16; a.part = part; a.nq = S;

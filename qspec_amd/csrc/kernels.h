@@ -46,6 +46,8 @@ int gemm_w4a4_gate_up_silu(const int8_t* xq, const f16* xs, const int8_t* wq, co
                            int K, hipStream_t st);
 int gemm_w4a16_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K, int ch0,
                             int nch, void* wsp, hipStream_t st);
+int gemm_w4a16_strided_raw(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, float* part, int M, int N, int K,
+                           void* wsp, hipStream_t st);
 int gemm_w4a16_strided(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, const f16* ws, f16* out, int M, int N,
                        int K, void* wsp, hipStream_t st);
 int gemm_f16(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st);

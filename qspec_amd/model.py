@@ -100,6 +100,7 @@ class Scratch:
         self.logits = e(T if logits_rows is None else logits_rows, cfg.vocab_size)
         # verify pass: raw fp32 K-slice sums of down_proj, finished inside the next norm (ops.w4a16_linear_partial)
         self.down_part = e(4, T, H, dtype=torch.float32) if T <= 16 else None
+        self.tp_part = e(1, min(T, 32), H, dtype=torch.float32)   # TP verify pass (T <= 32): fp32 row-parallel partials
         ws = ops.paged_attention_workspace_bytes(n_seqs * max_q_len, cfg.num_attention_heads, cfg.head_dim, n_splits)
         self.attn_ws = torch.zeros(ws, dtype=torch.uint8, device=device)   # ticket counters start at zero
 
@@ -267,13 +268,16 @@ class QuarotLlamaForCausalLM:
                 x, xs = q1, sc
             else:
                 self._attention_hadamard(qkv, row, kc, vc, md, T, s, attn, None, None, had)
-                if tp_on:   # row-parallel o_proj over this rank's K range of the shared buffer, then all-reduce
+                if tp_on:   # row-parallel o_proj over this rank's K range of the shared buffer: raw fp32 sums,
+                    # all-reduce in fp32, then scale + ONE fp16 rounding + residual add inside the norm (as on one GPU)
                     k0, k1 = self.tp.k_range(cfg.hidden_size)
-                    ops.w4a16_linear_ksliced(had, layer.o_proj.weight, layer.o_proj._scales(), o, k0, k1)
-                    self.tp.all_reduce(o)
+                    part = s.tp_part[:, :T]
+                    ops.w4a16_linear_ksliced_raw(had, layer.o_proj.weight, part[0], k0, k1)
+                    self.tp.all_reduce(part)
+                    ops.add_rms_norm_fp16_partial(normed, hidden, hidden, part, layer.o_proj._scales(), 1, eps)
                 else:
                     self._w4a16(had, layer.o_proj, o)
-                ops.add_rms_norm_fp16(normed, hidden, hidden, o, eps)
+                    ops.add_rms_norm_fp16(normed, hidden, hidden, o, eps)
                 x, xs = normed, None
             # gate_up -> silu*up -> online hadamard (+ quant) -> down_proj                              :266-299
             if fuse:
@@ -298,10 +302,13 @@ class QuarotLlamaForCausalLM:
                     had_mlp_in = had_mlp
             if w4a4:
                 ops.rowwise_scaled_linear_cutlass_s4s4_unified(q3, sc, layer.down_proj.weight, layer.down_proj._scales(), None, o)
-            elif tp_on:     # row-parallel down_proj
+            elif tp_on:     # row-parallel down_proj: raw fp32 sums, finished by the next norm
                 k0, k1 = self.tp.k_range(cfg.intermediate_size)
-                ops.w4a16_linear_ksliced(had_mlp_in, layer.down_proj.weight, layer.down_proj._scales(), o, k0, k1)
-                self.tp.all_reduce(o)
+                part = s.tp_part[:, :T]
+                ops.w4a16_linear_ksliced_raw(had_mlp_in, layer.down_proj.weight, part[0], k0, k1)
+                self.tp.all_reduce(part)
+                delta = ("partial", part, layer.down_proj._scales(), 1)
+                continue
             else:
                 S = 0
                 if fuse and s.down_part is not None:   # long K at decode-sized M: K slices, finished by the next norm

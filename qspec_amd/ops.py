@@ -331,6 +331,17 @@ def w4a16_linear_ksliced(x, wq, w_scale, out, k0: int, k1: int):
     return out
 
 
+def w4a16_linear_ksliced_raw(x, wq, part, k0: int, k1: int):
+    """Row-parallel shard as raw fp32 sums: part [M, N] = x[:, k0:k1] @ dequant(wq)[:, k0:k1]^T (no scale, no
+    rounding); reduced across ranks in fp32, finished by add_rms_norm_fp16_partial(..., slices=1)."""
+    M, K = x.shape
+    N = wq.shape[0]
+    _chk(x, "x", _F16); _chk(wq, "wq", (_I8, _U8))
+    _call("qspec_w4a16_linear_ksliced_raw", x.data_ptr() + 2 * k0, K, wq.data_ptr() + k0 // 2, K // 2,
+          _chk(part, "part", _F32), M, N, k1 - k0, w4a16_workspace(x.device).data_ptr(), _stream())
+    return part
+
+
 def gate_up_silu_linear_shard(x, wq, w_scale, act, ch0: int, nch: int):
     """Column-parallel shard of the fused gate_up + silu*up: writes act[:, ch0:ch0+nch] (act is the full [M, I])."""
     M = x.shape[0]

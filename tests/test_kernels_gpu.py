@@ -828,6 +828,37 @@ def test_w4a16_ksliced_partials_sum_to_full(ops, oracle, M, N, K, world):
     assert torch.equal(one.view(torch.int16), full.view(torch.int16))
 
 
+@pytest.mark.parametrize("M,N,K,world", [(16, 4096, 4096, 8), (16, 4096, 14336, 8), (16, 4096, 14336, 2), (4, 1024, 3584, 2),
+                                         (16, 5120, 13824, 2), (32, 8192, 28672, 8), (32, 8192, 8192, 8)])
+def test_w4a16_ksliced_raw_partials_reduce_to_the_oracle(ops, oracle, M, N, K, world):
+    """Row-parallel shards as raw fp32 sums (the TP verify pass): summed over the ranks in fp32, then scale + ONE fp16
+    rounding + residual add + norm in qspec_add_rms_norm_fp16_partial -- against the oracle's GEMM / add / norm."""
+    from qspec_amd.parallel import shard_range
+    rng = np.random.default_rng(K + world + 1)
+    x = rand_hidden(rng, M, K)
+    wq = oracle.pack_i4(rand_w4(rng, N, K))
+    ws = (rng.random(N) * 0.002 + 0.0005).astype(np.float16)
+    resid = rand_hidden(rng, M, N)
+    xd, wd = dev(x), dev(wq)
+    acc = torch.zeros(1, M, N, dtype=torch.float32, device=DEV)
+    for r in range(world):
+        k0, k1 = shard_range(K, world, r, 128)
+        part = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+        ops.w4a16_linear_ksliced_raw(xd, wd, part, k0, k1)
+        acc[0] += part
+    ref = oracle.gemm_w4a16(x, wq, ws)
+    got = (acc[0] * dev(ws).float()[None, :]).half()
+    assert_close_1e3(host(got), ref)
+    if N % 1024 == 0:
+        normed = torch.empty(M, N, dtype=torch.float16, device=DEV); hid = torch.empty_like(normed)
+        ops.add_rms_norm_fp16_partial(normed, hid, dev(resid), acc, dev(ws), 1, 1e-5)
+        h_ref = oracle.add_f16(resid, ref).astype(np.float64)
+        err = np.abs(host(hid).astype(np.float64) - h_ref)
+        # 1e-3 of the GEMM result (its one fp16 rounding may flip) + 1e-3 of the sum (the add's own rounding)
+        bar = 1e-3 * (np.maximum(1.0, np.abs(ref.astype(np.float64))) + np.maximum(1.0, np.abs(h_ref)))
+        assert (err <= bar).all(), (err / bar).max()
+
+
 @pytest.mark.parametrize("M,I,K,world", [(16, 14336, 4096, 2), (16, 14336, 4096, 8), (4, 3584, 1024, 2)])
 def test_gate_up_shards_concatenate_to_full(ops, oracle, M, I, K, world):
     from qspec_amd.parallel import shard_range
@@ -847,15 +878,45 @@ def test_gate_up_shards_concatenate_to_full(ops, oracle, M, I, K, world):
     assert (host(act) != 0).mean() > 0.99   # every channel range was written
 
 
-def test_tensor_parallel_engine_two_ranks():
-    """2 gloo ranks on this GPU: TP verify path vs single-GPU engine (tests/tp_check.py)."""
+def _run_tp_check(args, nproc):
     import subprocess, sys, socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "tp_check.py")],
-                       capture_output=True, text=True, timeout=600, cwd=root)
+    script = os.path.join(root, "tests", "tp_check.py")
+    if nproc:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), script] + args
+    else:
+        cmd = [sys.executable, script] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    if "TP_OK" not in r.stdout:   # the full output of the ranks, for the post-mortem (pytest truncates long reprs)
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "tp_check_%s.log" % "_".join(a.strip("-") for a in args)), "w") as f:
+            f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
     assert "TP_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    print(r.stdout.strip().splitlines()[-1])
+
+
+def test_tensor_parallel_engine_two_ranks():
+    """2 gloo ranks (processes) on this GPU: TP verify path vs single-GPU path + engine cycles (tests/tp_check.py)."""
+    _run_tp_check(["--family", "tiny"], 2)
+
+
+def test_tensor_parallel_llama2_13b_width_two_ranks():
+    """BASELINE.json configs[3] in its TP form: one full-width Llama-2-13B layer (40 heads = had40 on the head axis,
+    I = 13824 = had108 x 128; K ranges of 5120 / 13824), 2 gloo ranks."""
+    _run_tp_check(["--family", "llama-2-13b"], 2)
+
+
+def test_tensor_parallel_llama3_70b_width_eight_ranks():
+    """configs[4] in its TP form: one full-width Llama-3-70B layer, bs = 8, eight ranks (threads of one process: the
+    GPU box admits at most 6 processes on its card)."""
+    _run_tp_check(["--family", "llama-3-70b", "--threads", "8"], 0)
+
+
+def test_tensor_parallel_llama3_70b_width_four_process_ranks():
+    """The same layer with 4 gloo ranks as processes (host-staged collectives)."""
+    _run_tp_check(["--family", "llama-3-70b"], 4)
 
 
 # ------------------------------------------------------------------ W4A16, prefill-sized M (M-tiled kernel)
