@@ -99,9 +99,15 @@ int qspec_silu_mul_hadamard(const qspec_half* gate_up, const qspec_half* hadK, q
                             void* stream);
 
 /* The Hadamard + quantiser tail of qspec_silu_mul_hadamard on an input that is ALREADY silu(gate)*up
- * (act [tokens, I], produced by qspec_gate_up_silu_linear_*). */
+ * (act [tokens, I], produced by qspec_gate_up_silu_linear_*).
+ *   workspace: NULL, or qspec_xwg_workspace_bytes() bytes ZERO-FILLED once before first use (never reset afterwards)
+ *   and used by ONE stream at a time: lets a token's transform spread over several workgroups (each mixes a block of
+ *   columns; the quantiser's row maximum is exchanged through the workspace).  Same bytes out either way.
+ *   Word 0 of the workspace is a sticky error flag: non-zero = an exchange timed out (results of that launch invalid). */
+size_t qspec_xwg_workspace_bytes(void);
 int qspec_mlp_hadamard(const qspec_half* act, const qspec_half* hadK, qspec_half* out_f16, int8_t* q, qspec_half* scale,
-                       float had_scale, float clip_ratio, int tokens, int intermediate, int K, void* stream);
+                       float had_scale, float clip_ratio, int tokens, int intermediate, int K, void* workspace,
+                       void* stream);
 
 /* ---- linear layers over the shared packed-int4 weight buffer --------------------------------- */
 

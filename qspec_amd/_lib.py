@@ -32,7 +32,8 @@ SIGNATURES = {
     "qspec_heads_hadamard_mix": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     "qspec_silu_mul": (_i, [_vp, _vp, _i, _i, _vp]),
     "qspec_silu_mul_hadamard": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
-    "qspec_mlp_hadamard": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
+    "qspec_xwg_workspace_bytes": (_sz, []),
+    "qspec_mlp_hadamard": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp]),
     "qspec_qkv_rope_linear_s4s4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "qspec_qkv_rope_linear_w4a16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp,
                                          _vp]),

@@ -52,7 +52,7 @@ static int tiled_min_m() {
 
 extern "C" {
 
-int qspec_abi_version(void) { return 1; }
+int qspec_abi_version(void) { return 2; }
 const char* qspec_last_error(void) { return g_err; }
 
 int qspec_rms_norm_general_fuse_sum_i4(int8_t* out_q, const qspec_half* x, qspec_half* input_sum, qspec_half* scaling,
@@ -155,7 +155,7 @@ int qspec_silu_mul_hadamard(const qspec_half* gate_up, const qspec_half* hadK, q
     if (K > 1) NONNULL(op, hadK);
     if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
     if (intermediate % 8) return fail("%s: intermediate %% 8 != 0", op);
-    return finish(op, qspec::silu_mul_hadamard(CH(gate_up), CH(hadK), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, intermediate, K, 0, ST));
+    return finish(op, qspec::silu_mul_hadamard(CH(gate_up), CH(hadK), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, intermediate, K, 0, nullptr, ST));
 }
 int qspec_rowwise_scaled_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
                                      const qspec_half* bias, qspec_half* out, int M, int N, int K, void* stream) {
@@ -354,8 +354,10 @@ int qspec_spec_commit(int batch, int k, const int64_t* out_tokens, int32_t* seq_
     return finish(op, qspec::spec_commit(batch, k, out_tokens, seq_lens, last_token, gen_tokens, gen_lens, gen_capacity, ST));
 }
 
+size_t qspec_xwg_workspace_bytes(void) { return qspec::xwg_workspace_bytes(); }
 int qspec_mlp_hadamard(const qspec_half* act, const qspec_half* hadK, qspec_half* out_f16, int8_t* q, qspec_half* scale,
-                       float had_scale, float clip_ratio, int tokens, int intermediate, int K, void* stream) {
+                       float had_scale, float clip_ratio, int tokens, int intermediate, int K, void* workspace,
+                       void* stream) {
     const char* op = "qspec_mlp_hadamard";
     if (tokens < 0) return fail("%s: tokens < 0", op);
     if (tokens == 0) return 0;
@@ -363,7 +365,7 @@ int qspec_mlp_hadamard(const qspec_half* act, const qspec_half* hadK, qspec_half
     if (K > 1) NONNULL(op, hadK);
     if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
     if (intermediate % 8) return fail("%s: intermediate %% 8 != 0", op);
-    return finish(op, qspec::silu_mul_hadamard(CH(act), CH(hadK), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, intermediate, K, 1, ST));
+    return finish(op, qspec::silu_mul_hadamard(CH(act), CH(hadK), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, intermediate, K, 1, workspace, ST));
 }
 int qspec_qkv_rope_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
                                qspec_half* qkv, int M, int N, int K, const int64_t* positions,

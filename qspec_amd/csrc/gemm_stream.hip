@@ -26,6 +26,18 @@
 
 namespace qspec {
 
+// Weight loads.  Non-temporal loads (`global_load_dwordx4 ... nt`, -DQS_NT_WEIGHTS) were measured on the register
+// refill ring of these kernels and lost: cycle 8.66 -> 8.90 ms, gate_up 15.6 -> 16.1 us, down 8.4 -> 8.8 us (round 2;
+// the guide's gain is for LDS-DMA loader rings).  Default cache policy it is.
+template <typename T>
+__device__ __forceinline__ T wload(const void* p) {
+#ifdef QS_NT_WEIGHTS
+    return __builtin_nontemporal_load(reinterpret_cast<const T*>(p));
+#else
+    return *reinterpret_cast<const T*>(p);
+#endif
+}
+
 enum { SEPI_PLAIN = 0, SEPI_QKV = 1, SEPI_GATEUP = 2, SEPI_RESID = 3, SEPI_PARTIAL = 4 };   // RESID: plain + fp16 residual add
 enum { PRO_Q = 0, PRO_LN = 1, PRO_LNH = 2, PRO_LN1 = 3 };   // LN1: norm of hidden_in alone (no delta, no write-back)  // LNH: LN by a few producer workgroups, handed to the rest through L2
 
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
             if (tid == 0) __hip_atomic_store(&flags[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
-        for (int u = 0; u < UB; u++) w[u] = *reinterpret_cast<const u32x4*>(wp0 + step_off<NW, UB>(wave, u));
+        for (int u = 0; u < UB; u++) w[u] = wload<u32x4>(wp0 + step_off<NW, UB>(wave, u));
         load_pre(pre, tile);
         QS_SSTAMP(1);
         if (tid == 0) {
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
         ln_load<NI, NG, RB, HASD>(a, 0, rg);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < UB; u++) w[u] = *reinterpret_cast<const u32x4*>(wp0 + step_off<NW, UB>(wave, u));
+        for (int u = 0; u < UB; u++) w[u] = wload<u32x4>(wp0 + step_off<NW, UB>(wave, u));
         load_pre(pre, tile);
         __builtin_amdgcn_sched_barrier(0);
         const bool wh = blockIdx.x == 0 && a.hidden_out != nullptr;
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
         const f16 xsh = a.xs[mc];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < UB; u++) w[u] = *reinterpret_cast<const u32x4*>(wp0 + step_off<NW, UB>(wave, u));
+        for (int u = 0; u < UB; u++) w[u] = wload<u32x4>(wp0 + step_off<NW, UB>(wave, u));
         load_pre(pre, tile);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
             // pin the refill right behind its consumer: left alone, the scheduler sinks all UB loads below the last
             // use and the stream drains every unit
             __builtin_amdgcn_sched_barrier(0);
-            w[u] = *reinterpret_cast<const u32x4*>(wp + step_off<NW, UB>(wave, u));
+            w[u] = wload<u32x4>(wp + step_off<NW, UB>(wave, u));
             __builtin_amdgcn_sched_barrier(0);
         }
         if (b == NB - 1) {
@@ -688,7 +700,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
     {
         const uint8_t* wp0 = wptr(tile);
 #pragma unroll
-        for (int u = 0; u < UB; u++) w[u] = *reinterpret_cast<const u32x4*>(wp0 + step_off<NW, UB>(wave, u));
+        for (int u = 0; u < UB; u++) w[u] = wload<u32x4>(wp0 + step_off<NW, UB>(wave, u));
         load_pre(pre, tile);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -776,7 +788,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
         for (int u = 0; u < UB; u++) {
             use(w[u], u);
             __builtin_amdgcn_sched_barrier(0);
-            w[u] = *reinterpret_cast<const u32x4*>(wp + step_off<NW, UB>(wave, u));
+            w[u] = wload<u32x4>(wp + step_off<NW, UB>(wave, u));
             __builtin_amdgcn_sched_barrier(0);
         }
         finish(tile, par, pre);
@@ -848,7 +860,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_f16_stream_kernel(const f16* __r
     {
         const unsigned char* wp0 = wptr(tile);
 #pragma unroll
-        for (int u = 0; u < UB; u++) w[u] = *reinterpret_cast<const f16x8*>(wp0 + step_off<NW, UB>(wave, u));
+        for (int u = 0; u < UB; u++) w[u] = wload<f16x8>(wp0 + step_off<NW, UB>(wave, u));
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -872,7 +884,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_f16_stream_kernel(const f16* __r
         for (int u = 0; u < UB; u++) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u], w[u], acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            w[u] = *reinterpret_cast<const f16x8*>(wp + step_off<NW, UB>(wave, u));
+            w[u] = wload<f16x8>(wp + step_off<NW, UB>(wave, u));
             __builtin_amdgcn_sched_barrier(0);
         }
         finish(tile, par);

@@ -554,13 +554,72 @@ int silu_mul(const f16* gate_up, f16* out, int T, int I, hipStream_t st) {
 //   draft: row-absmax int4 of z (index i*P + j); verify: fp16 z.
 // One 256-thread workgroup per token.  LDS: y fp16 [K][P], z fp16 [K][P], hadK fp32 [K][K].
 #define QS_SMH_THREADS 1024
-template <int EPL, int KH, bool PREACT>  // EPL = elements per lane in the FWHT phase = P / 64; KH = K if specialised, else 0
+
+// Row abs-max across the NB workgroups that share a token (the spread forms below), without atomics or fences:
+// data-tagged 8-byte granules {amax, tag} (MI355X_MICROARCH.md price list, handoff-1to1: one naturally aligned 8-byte
+// sc1 store per producer, sc1 polling loads; observed untorn).  Workspace per token: a generation word gen[t] and NB
+// granules.  Every workgroup of token t reads g = gen[t] when it starts (latency hidden under the transform), publishes
+// {its maximum, g + 1}, and polls the token's NB granules until every tag reads g + 1.  Workgroup 0 of the token then
+// stores gen[t] = g + 1: by then every workgroup of the token has published, hence has read gen[t] -- and the next
+// launch starts behind a kernel boundary.  Zero-filled ONCE, never reset; tags only ever compare equal, so the
+// generation may wrap.  All NB workgroups of a token must be resident together: the host launches at most one
+// workgroup per CU.  A poll that exceeds its guard raises the workspace's sticky error word (read by the host once per
+// cycle) instead of hanging; the result is then this workgroup's own maximum.
+#define QS_XWG_ERR_WORD 0          // uint32 [0]: sticky error flag; gen[] from word 16, granules behind them
+#define QS_XWG_MAX_TOKENS 256
+#define QS_XWG_MAX_NB 16
+__device__ __forceinline__ uint32_t xwg_read_gen(const uint32_t* ws, int t) {
+    return __hip_atomic_load(ws + 16 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Call from every thread of the workgroup BEHIND the barrier that made wave_max[0 .. nwaves) (the waves' maxima, LDS)
+// visible; gen uniform over the workgroup; lds_slot: one float of LDS that nothing else touches until the next barrier.
+// One barrier inside; only wave 0 reduces, publishes and polls.
+__device__ __forceinline__ float xwg_row_amax(const float* wave_max, int nwaves, uint32_t gen, int t, int b, int nb,
+                                              uint32_t* ws, float* lds_slot) {
+    unsigned long long* gran = reinterpret_cast<unsigned long long*>(ws + 16 + QS_XWG_MAX_TOKENS) + (size_t)t * QS_XWG_MAX_NB;
+    if (threadIdx.x < 64) {   // wave 0
+        const int lane = threadIdx.x;
+        const uint32_t tag = gen + 1u;
+        const float wg_amax = wave_max_f(lane < nwaves ? wave_max[lane] : 0.0f);
+        if (lane == 0)
+            __hip_atomic_store(gran + b, ((unsigned long long)tag << 32) | __builtin_bit_cast(uint32_t, wg_amax),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float m = wg_amax;
+        int guard = 0;
+        while (true) {
+            unsigned long long v = ((unsigned long long)tag << 32);
+            if (lane < nb) v = __hip_atomic_load(gran + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool ok = (uint32_t)(v >> 32) == tag;
+            if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) {
+                m = lane < nb ? __builtin_bit_cast(float, (uint32_t)v) : 0.0f;
+                break;
+            }
+            if (++guard > (1 << 20)) {
+                if (lane == 0) __hip_atomic_store(ws + QS_XWG_ERR_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        m = wave_max_f(m);
+        if (lane == 0) {
+            *lds_slot = m;
+            if (b == 0) __hip_atomic_store(ws + 16 + t, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    return *lds_slot;
+}
+
+// NB > 1 (KH > 0, PREACT): NB workgroups per token.  Each repeats the cheap FWHT phase for the whole token and mixes /
+// quantises only its block of P / NB columns of every hadK row (the mix is what bounds the one-workgroup form: 6.3 k
+// cycles of v_pk_fma on ONE CU); the row maximum of the quantiser is exchanged through xwg_row_amax.
+template <int EPL, int KH, bool PREACT, int NB = 1>  // EPL = elements per lane in the FWHT phase = P / 64; KH = K if specialised, else 0
 __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const f16* __restrict__ gate_up,
                                                                             const f16* __restrict__ hadK,
                                                                             f16* __restrict__ out16,
                                                                             int8_t* __restrict__ q,
                                                                             f16* __restrict__ scale, float had_scale,
-                                                                            float clip, int I, int K) {
+                                                                            float clip, int I, int K, uint32_t* xws) {
     constexpr bool pre_activated = PREACT;   // the input is already g = silu(gate)*up, [T, I] (gate_up GEMM epilogue)
     constexpr int P = EPL * 64;
     constexpr int NT = QS_SMH_THREADS, NW = NT / 64;
@@ -570,10 +629,12 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
     f16* ylds = reinterpret_cast<f16*>(smem_raw + 64);
     f16* zlds = ylds + (size_t)K * P;
     float* had = reinterpret_cast<float*>(zlds + (K > 1 ? (size_t)K * P : 0));
-    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = NB > 1 ? blockIdx.x / NB : blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // pre_activated: the input is already g = silu(gate)*up, [T, I] (fused into the gate_up GEMM epilogue)
     const f16* up = gate_up + (size_t)t * (pre_activated ? I : 2 * I);
     const f16* gate = up + I;
+    uint32_t xgen = 0;
+    if (NB > 1 && q != nullptr) xgen = xwg_read_gen(xws, t);   // consumed at the exchange, far behind this load
     // hadK -> LDS AFTER phase A (it is only read in phase B): staged here it would put an L2 round trip in front of
     // the first activation load (results return in issue order).
 
@@ -684,6 +745,65 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
     QS_ST2(1);
     __syncthreads();
     QS_ST2(2);
+    if constexpr (NB > 1) {
+        static_assert(KH > 0 && KH % 4 == 0 && (P / NB) % 8 == 0, "spread form");
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr int CB = P / NB, PAIRS = CB / 2;            // this workgroup's columns of every row
+        constexpr int ITEMS = KH * PAIRS;                     // (row, column pair) items, one per thread
+        static_assert(ITEMS <= NT, "one item per thread");
+        const int b = blockIdx.x % NB;
+        const int row = tid / PAIRS, jp = tid % PAIRS;
+        const bool active = tid < ITEMS;
+        f32x2 a = {0.0f, 0.0f};
+        if (active) {
+            const f16* ycol = ylds + b * CB + 2 * jp;
+            const float* hrow = had + row * KH;
+#pragma unroll
+            for (int kq = 0; kq < KH / 4; kq++) {
+                const float4 h = *reinterpret_cast<const float4*>(hrow + 4 * kq);
+                f32x2 y[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const f16x2 yy = *reinterpret_cast<const f16x2*>(ycol + (size_t)(4 * kq + kk) * P);
+                    y[kk] = f32x2{h2f(yy[0]), h2f(yy[1])};
+                }
+                a = __builtin_elementwise_fma(f32x2{h.x, h.x}, y[0], a);   // the k-ordered fp32 chain of the oracle
+                a = __builtin_elementwise_fma(f32x2{h.y, h.y}, y[1], a);
+                a = __builtin_elementwise_fma(f32x2{h.z, h.z}, y[2], a);
+                a = __builtin_elementwise_fma(f32x2{h.w, h.w}, y[3], a);
+            }
+        }
+        const f16x2 zz = {f2h(a[0]), f2h(a[1])};
+        const size_t e0 = (size_t)row * P + b * CB + 2 * jp;  // element index inside the token's row of I
+        if (q == nullptr) {
+            if (active) *reinterpret_cast<f16x2*>(out16 + (size_t)t * I + e0) = zz;
+            return;
+        }
+        float amax = active ? fmaxf(__builtin_fabsf(h2f(zz[0])), __builtin_fabsf(h2f(zz[1]))) : 0.0f;
+        amax = wave_max_f(amax);
+        if (lane == 0) red[wave] = amax;
+        __syncthreads();
+        amax = xwg_row_amax(red, NW, xgen, t, b, NB, xws, reinterpret_cast<float*>(zlds) + 1024);
+        const f16 sc = f2h(h2f(f2h(amax / 7.0f)) * h2f(f2h(clip)));
+        const float scf = h2f(sc);
+        const float rcf = 1.0f / scf;
+        if (tid == 0 && b == 0) scale[t] = sc;
+        // one byte per thread -> LDS -> 16-byte stores (a row's block is CB / 2 contiguous bytes of the packed row)
+        unsigned char* qb = reinterpret_cast<unsigned char*>(zlds);
+        if (active) {
+            const int v0 = rni_sat(h2f(f2h(div3_h(h2f(zz[0]), rcf, scf))), -8, 7);
+            const int v1 = rni_sat(h2f(f2h(div3_h(h2f(zz[1]), rcf, scf))), -8, 7);
+            qb[row * PAIRS + jp] = (unsigned char)pack_nib(v0, v1);
+        }
+        __syncthreads();
+        constexpr int V16 = PAIRS / 16;                        // 16-byte pieces per row block
+        if (tid < KH * V16) {
+            const int r2 = tid / V16, pc = tid % V16;
+            *reinterpret_cast<u32x4*>(q + (size_t)t * (I / 2) + ((size_t)r2 * P + b * CB) / 2 + 16 * pc) =
+                *reinterpret_cast<const u32x4*>(qb + r2 * PAIRS + 16 * pc);
+        }
+        return;
+    }
 
     // phase B: hadK mix.  KH > 0: a thread owns a column pair and KH/IQ output rows; the column pair lives in
     // registers and the k loop is fully unrolled with 16-byte broadcast reads of hadK (a naive loop is LDS
@@ -825,14 +945,35 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
 #endif
 }
 
+size_t xwg_workspace_bytes() { return (16 + QS_XWG_MAX_TOKENS) * 4 + (size_t)QS_XWG_MAX_TOKENS * QS_XWG_MAX_NB * 8; }
+
+// Workgroups per token of the spread form for this shape (1 = the one-workgroup form).
+static int smh_spread(int T, int P, int K, int pre_activated, const void* xws) {
+    if (!xws || !pre_activated || K != 28 || T > QS_XWG_MAX_TOKENS) return 1;
+    const int nb = P == 512 ? 8 : (P == 1024 ? 16 : 1);
+    return T * nb <= 256 ? nb : 1;     // every workgroup of a token resident: at most one workgroup per CU
+}
+
 int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,
-                      float clip, int T, int I, int K, int pre_activated, hipStream_t st) {
+                      float clip, int T, int I, int K, int pre_activated, void* xws, hipStream_t st) {
     if (T == 0) return 0;
     if (K < 1 || K > 172 || I % K) return -1;
     const int P = I / K;
     if (P & (P - 1)) return -1;
     size_t lds = 64 + (size_t)I * 2 * (K > 1 ? 2 : 1) + (K > 1 ? (size_t)K * K * 4 : 0);
     if (lds > 160 * 1024 - 64) return -2;
+    const int nb = smh_spread(T, P, K, pre_activated, xws);
+#define QS_SMH_SPREAD(EPLV, NBV)                                                                                 \
+    if (nb == NBV && P == EPLV * 64) {                                                                           \
+        if (lds > 64 * 1024)                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&silu_mul_hadamard_kernel<EPLV, 28, true, NBV>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+        hipLaunchKernelGGL((silu_mul_hadamard_kernel<EPLV, 28, true, NBV>), dim3(T * NBV), dim3(QS_SMH_THREADS), lds, st, \
+                           gate_up, hadK, out_f16, q, scale, had_scale, clip, I, K, reinterpret_cast<uint32_t*>(xws)); \
+        return 0;                                                                                                \
+    }
+    QS_SMH_SPREAD(8, 8) QS_SMH_SPREAD(16, 16)
+#undef QS_SMH_SPREAD
 #define QS_SMH2(EPLV, KHV)                                                                                      \
     {                                                                                                            \
         if (pre_activated) QS_SMH3(EPLV, KHV, true)                                                              \
@@ -844,7 +985,7 @@ int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t*
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&silu_mul_hadamard_kernel<EPLV, KHV, PAV>),  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
         hipLaunchKernelGGL((silu_mul_hadamard_kernel<EPLV, KHV, PAV>), dim3(T), dim3(QS_SMH_THREADS), lds, st, gate_up, \
-                           hadK, out_f16, q, scale, had_scale, clip, I, K);                                      \
+                           hadK, out_f16, q, scale, had_scale, clip, I, K, (uint32_t*)nullptr);                  \
         return 0;                                                                                                \
     }
 #define QS_SMH(EPLV)                                                                                            \

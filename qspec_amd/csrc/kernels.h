@@ -28,7 +28,8 @@ int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out
                          float had_scale, float clip, int T, int heads, int d, hipStream_t st);
 int silu_mul(const f16* gate_up, f16* out, int T, int I, hipStream_t st);
 int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,
-                      float clip, int T, int I, int K, int pre_activated, hipStream_t st);
+                      float clip, int T, int I, int K, int pre_activated, void* xws, hipStream_t st);
+size_t xwg_workspace_bytes();
 
 // gemm.hip
 int gemm_w4a4(const int8_t* xq, const f16* xs, const int8_t* wq, const f16* ws, const f16* bias, f16* out, int M,

@@ -148,11 +148,37 @@ def silu_mul_hadamard(gate_up, hadK, K: int, had_scale: float, out_f16=None, q=N
           float(clip_ratio), T, two_i // 2, K, _stream())
 
 
-def mlp_hadamard(act, hadK, K: int, had_scale: float, out_f16=None, q=None, scale=None, clip_ratio: float = 1.0):
+_xwg_ws = {}
+XWG_SPREAD = os.environ.get("QSPEC_XWG_SPREAD", "1") != "0"   # False: one workgroup per token (no workspace)
+
+
+def xwg_workspace(device):
+    """Exchange workspace of the kernels that spread one token over several workgroups (mlp_hadamard,
+    heads_hadamard_merged): zero-filled once, never reset; one per (device, stream) -- launches on one stream are
+    serialised, two streams must not share its counters.  Word 0 is a sticky error flag (xwg_error)."""
+    if not XWG_SPREAD:
+        return None
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _xwg_ws:
+        _xwg_ws[key] = torch.zeros(int(_lib.load().qspec_xwg_workspace_bytes()) // 4, dtype=torch.int32, device=device)
+    return _xwg_ws[key]
+
+
+def xwg_error_word(device):
+    """int32 view [1] of the sticky error flag of the current stream's exchange workspace (None if never used)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _xwg_ws.get(key)
+    return None if ws is None else ws[:1]
+
+
+def mlp_hadamard(act, hadK, K: int, had_scale: float, out_f16=None, q=None, scale=None, clip_ratio: float = 1.0,
+                 workspace="auto"):
     """Hadamard (+ quantiser) tail of silu_mul_hadamard on act = silu(gate)*up, [T, I]."""
     T, I = act.shape
+    ws = xwg_workspace(act.device) if isinstance(workspace, str) else workspace
     _call("qspec_mlp_hadamard", _chk(act, "act", _F16), _opt(hadK, "hadK", _F16), _opt(out_f16, "out_f16", _F16),
-          _opt(q, "q", _I8), _opt(scale, "scale", _F16), float(had_scale), float(clip_ratio), T, I, K, _stream())
+          _opt(q, "q", _I8), _opt(scale, "scale", _F16), float(had_scale), float(clip_ratio), T, I, K,
+          None if ws is None else ws.data_ptr(), _stream())
 
 
 # ------------------------------------------------------------------ linear

@@ -21,6 +21,8 @@ for T in (4, 16):
     had = hadamard_tables.get_hadK(I)[0].half().to(dev)
     q = torch.empty(T, I // 2, dtype=torch.int8, device=dev); sc = torch.zeros(1024, dtype=torch.float16, device=dev)
     o16 = torch.empty(T, I, dtype=torch.float16, device=dev)
+    t0 = timeit(lambda: ops.mlp_hadamard(act, had, 28, 0.00835, q=q, scale=sc, workspace=None))
+    print(f"T={T}: mlp_hadamard quant, one workgroup per token {t0:.2f} us", flush=True)
     t1 = timeit(lambda: ops.mlp_hadamard(act, had, 28, 0.00835, q=q, scale=sc))
     st = sc[64:64 + 20].view(torch.int64).cpu().tolist()
     t2 = timeit(lambda: ops.mlp_hadamard(act, had, 28, 0.00835, out_f16=o16))

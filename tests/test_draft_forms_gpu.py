@@ -119,13 +119,39 @@ def test_s4s4_residual_in_place_draft_form_vs_oracle(ops, oracle, M, N, K):
 
 
 @pytest.mark.parametrize("M", [3, 4, 16, 32])
-def test_mlp_hadamard_quant_draft_form_vs_oracle(ops, oracle, golden_dir, M):
+@pytest.mark.parametrize("spread", [True, False])
+def test_mlp_hadamard_quant_draft_form_vs_oracle(ops, oracle, golden_dir, M, spread):
+    """spread: a token over 8 workgroups with the row maximum exchanged through the workspace (what the engine runs
+    up to 32 tokens); else one workgroup per token.  Same bytes; repeated launches reuse the never-reset counters."""
     rng = np.random.default_rng(400 + M)
     had = np.load(os.path.join(golden_dir, "hadamard.npz"))["had28"].astype(np.float16)
     act = rand_hidden(rng, M, I, 0.5)
     sc = oracle.rsqrt_scale(I)
     q0, s0 = oracle.rowabsmax_quant_i4(oracle.mlp_hadamard(act, had, 28, sc), 1.0)
     q = torch.empty(M, I // 2, dtype=torch.int8, device=DEV)
+    s = torch.empty(M, dtype=torch.float16, device=DEV)
+    ws = "auto" if spread else None
+    for rep in range(3):          # the exchange counters are monotonic: every launch must find them consistent
+        q.fill_(0); s.fill_(0)
+        ops.mlp_hadamard(dev(act), dev(had), 28, sc, q=q, scale=s, workspace=ws)
+        assert np.array_equal(host(q), q0) and np.array_equal(bits(host(s)), bits(s0)), rep
+    z0 = oracle.mlp_hadamard(act, had, 28, sc)
+    z = torch.empty(M, I, dtype=torch.float16, device=DEV)
+    ops.mlp_hadamard(dev(act), dev(had), 28, sc, out_f16=z, workspace=ws)
+    assert np.array_equal(bits(host(z)), bits(z0))
+    if spread:
+        assert int(ops.xwg_error_word(torch.device(DEV)).item()) == 0
+
+
+def test_mlp_hadamard_spread_70b_width_vs_oracle(ops, oracle, golden_dir):
+    """I = 28672 = had28 x H1024 (Llama-3-70B): 16 workgroups per token."""
+    rng = np.random.default_rng(41)
+    had = np.load(os.path.join(golden_dir, "hadamard.npz"))["had28"].astype(np.float16)
+    M, I2 = 8, 28672
+    act = rand_hidden(rng, M, I2, 0.5)
+    sc = oracle.rsqrt_scale(I2)
+    q0, s0 = oracle.rowabsmax_quant_i4(oracle.mlp_hadamard(act, had, 28, sc), 1.0)
+    q = torch.empty(M, I2 // 2, dtype=torch.int8, device=DEV)
     s = torch.empty(M, dtype=torch.float16, device=DEV)
     ops.mlp_hadamard(dev(act), dev(had), 28, sc, q=q, scale=s)
     assert np.array_equal(host(q), q0) and np.array_equal(bits(host(s)), bits(s0))
