@@ -10,9 +10,16 @@ k+1 tokens per sequence + rejection sampling + commit (one hipGraph replay).  Wo
 configs[1]: Llama-3-8B QSpec, k=3, bs=4, synthetic weights and prompts.  Prefill is outside
 the timed region (inputs resident in HBM when timing starts).
 
-One JSON line on rank 0: metric/value (accepted = emitted tokens per second, whole job), plus
+One JSON line on rank 0.  The hardware quantity is `ms_per_step` (one cycle; identical with the synthetic knob on or
+off).  `value` = emitted tokens per second of the whole job at the SYNTHETIC draft/target agreement named in
+`config.agreement` (random int4 weights agree ~1-4 %; the reference's trained checkpoint 0.96; SURVEY.md 8d
+sanctions the controlled-agreement mode) -- the same cycles at the weights' own agreement are under `natural_agreement`,
+and `e2e_incl_prefill` is the demo.py:139-160 figure (prompt pass + decode to max_tokens, tokens / wall time).  Plus
   roofline      dominant kernel (the W4A4 weight-streaming GEMM): algorithmic bytes / measured launch time
   cpu_baseline  the CPU oracle ("port" of the reference arithmetic) timed on this host's cores on a bounded sample
+
+The agreement knob is bench-only code: BenchEngine below + bench_kernels/libqspec_bench.so; nothing of it is in the
+product library or its header.
 """
 import argparse
 import json
@@ -44,8 +51,39 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--cpu-layers", type=int, default=4, help="layers of the model the CPU baseline sample runs")
-    p.add_argument("--cpu-cycles", type=int, default=2)
+    p.add_argument("--cpu-cycles", type=int, default=5, help="timed CPU cycles (median), after --cpu-warmup untimed ones")
+    p.add_argument("--cpu-warmup", type=int, default=2)
+    p.add_argument("--e2e-max-tokens", type=int, default=256, help="max_tokens of the end-to-end (prefill included) run; 0 = skip")
     return p.parse_args()
+
+
+def make_bench_engine_class():
+    """QSpecEngine + the synthetic-agreement knob (bench only; see module docstring)."""
+    import ctypes
+    from qspec_amd.spec_decode import QSpecEngine
+    path = os.path.join(ROOT, "bench_kernels", "libqspec_bench.so")
+    if not os.path.exists(path):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "bench_kernels"), "-s", "libqspec_bench.so"])
+    lib = ctypes.CDLL(path)
+    fn = lib.qspec_bench_force_agreement
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p,
+                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+
+    class BenchEngine(QSpecEngine):
+        def set_agreement(self, rho):
+            if rho is None:
+                self._post_logits_hook = None
+                return
+
+            def hook(logits, draft_ids):
+                B, k = draft_ids.shape
+                rc = fn(logits.data_ptr(), draft_ids.data_ptr(), draft_ids.stride(0), draft_ids.stride(1), float(rho),
+                        self.sampler.rng_state.data_ptr(), B, k, logits.shape[-1], torch.cuda.current_stream().cuda_stream)
+                assert rc == 0
+            self._post_logits_hook = hook
+    return BenchEngine
 
 
 def dist_setup(n):
@@ -175,27 +213,34 @@ def measure_dominant_kernel(model, engine, reps=5):
     return tot_b, tot_t, launches, res
 
 
-def pmc_traffic_per_launch():
+def pmc_traffic_per_launch(model_name, batch, k):
     """HBM read bytes per launch of the dominant kernel from the PMC pass committed under profiles/ (a separate
-    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` run of scripts/profile_cycle.py, same workload; FETCH_SIZE KiB x 1024
-    x 2 = the gfx950 correction for wide streaming reads, MI355X_MICROARCH.md).  Average over the kernel's launches
-    in a cycle (the four decoder shapes in equal numbers).  None if the summary is not there."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` run of scripts/profile_cycle.py; FETCH_SIZE KiB x 1024 x 2 = the gfx950
+    correction for wide streaming reads, MI355X_MICROARCH.md).  The summary is keyed by workload: a number is returned
+    only when its (model, batch, k) match this run, else None."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_fetch_size.json")
     try:
         d = json.load(open(path))
     except OSError:
         return None
+    wl = d.get("workload", {})
+    if (wl.get("model"), wl.get("batch"), wl.get("k")) != (model_name, batch, k):
+        return None
     tot = n = 0
-    for name, v in d.items():
+    for name, v in d.get("kernels", {}).items():
         if "gemm_w4a4_stream_kernel" in name:
             tot += v["hbm_read_bytes_per_launch_corrected"] * v["launches"]
             n += v["launches"]
     return int(tot / n) if n else None
 
 
-def cpu_baseline(model, args):
-    """The CPU oracle (port of the reference arithmetic) on this host: `cpu_layers` full-width layers + lm_head,
-    same k / batch, short prompts; layer time extrapolated to the full depth."""
+def cpu_baseline(model, args, rho):
+    """The CPU oracle (port of the reference arithmetic) on this host, as BASELINE.md section 3 plans it: same k / batch,
+    the same decode state as the GPU's timed region (prompt_len tokens of context per sequence: the KV cache is
+    filled directly, the CPU prompt pass itself is not part of the sample), `cpu_warmup` untimed cycles, then the
+    MEDIAN of `cpu_cycles` timed ones.  Bounded: `cpu_layers` full-width layers + lm_head; the layer share of a cycle
+    is scaled to the full depth (the lm_head / sampler share is measured separately and not scaled)."""
+    import copy
     import numpy as np
     import oracle as O
     from oracle.model import OracleEngine, OracleModel
@@ -203,35 +248,46 @@ def cpu_baseline(model, args):
     cfg = model.config
     L = min(args.cpu_layers, cfg.num_hidden_layers)
     om = OracleModel.from_torch_model(model, 16, max_layers=L)
-    import copy
     om.cfg = copy.copy(cfg)
     om.cfg.num_hidden_layers = L
     rng = np.random.default_rng(0)
     cores = os.cpu_count() or 1
-    eng = OracleEngine(om, args.k, args.batch, 64, 16)
-    eng.agreement_rho = None if args.agreement.lower() == "none" else float(args.agreement)
-    prompts = [rng.integers(0, cfg.vocab_size, 8).tolist() for _ in range(args.batch)]
-    eng.add_sequences(prompts)
+    n_cyc = args.cpu_warmup + args.cpu_cycles
+    ctx = args.prompt_len
+    eng = OracleEngine(om, args.k, args.batch, ctx + (n_cyc + 1) * (args.k + 1) + 16, 16)
+    eng.agreement_rho = rho
+    for kc, vc in eng.kv:
+        kc[...] = (rng.standard_normal(kc.shape) * 0.5).astype(np.float16)
+        vc[...] = (rng.standard_normal(vc.shape) * 0.5).astype(np.float16)
+    eng.seq_lens[:] = ctx + 1
+    eng.last_token[:] = rng.integers(0, cfg.vocab_size, args.batch)
     V = cfg.vocab_size
-    # time the lm_head + sampler share separately so that only the layer share is scaled by depth
-    t0 = time.perf_counter()
-    emitted0 = sum(len(g) for g in eng.generated)
-    for _ in range(args.cpu_cycles):
-        eng.step(rng.random((args.batch, args.k)).astype(np.float32),
-                 rng.exponential(1.0, (args.batch, args.k, V)).astype(np.float32))
-    dt = (time.perf_counter() - t0) / args.cpu_cycles
-    emitted = (sum(len(g) for g in eng.generated) - emitted0) / args.cpu_cycles
+    times, emitted = [], []
+    for c in range(n_cyc):
+        U = rng.random((args.batch, args.k)).astype(np.float32)
+        E = rng.exponential(1.0, (args.batch, args.k, V)).astype(np.float32)
+        n0 = sum(len(g) for g in eng.generated)
+        t0 = time.perf_counter()
+        eng.step(U, E)
+        dt = time.perf_counter() - t0
+        if c >= args.cpu_warmup:
+            times.append(dt)
+            emitted.append(sum(len(g) for g in eng.generated) - n0)
+    dt = float(np.median(times))
     x = (rng.standard_normal((args.batch, cfg.hidden_size))).astype(np.float16)
+    O.softmax_argmax(om.logits(x))
     t1 = time.perf_counter()
     O.softmax_argmax(om.logits(x))
     head = time.perf_counter() - t1
     head_cycle = head * (args.k + (args.k + 1))          # k draft heads at T=B, one verify head at T=B(k+1)
     layers_cycle = max(dt - head_cycle, 0.0)
     full = layers_cycle * cfg.num_hidden_layers / L + head_cycle
-    return {"value": round(emitted / full, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"{args.cpu_cycles} cycles of the CPU oracle on {L}/{cfg.num_hidden_layers} full-width layers + lm_head, "
-                      f"k={args.k} bs={args.batch}, 8-token prompts; layer time x{cfg.num_hidden_layers // L} "
-                      f"extrapolated ({dt:.2f} s/cycle measured -> {full:.2f} s/cycle full depth), OpenMP {cores} threads"}
+    return {"value": round(float(np.mean(emitted)) / full, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "ms_per_step": round(full * 1e3, 1),
+            "sample": f"median of {args.cpu_cycles} cycles after {args.cpu_warmup} warm-ups of the CPU oracle on {L}/{cfg.num_hidden_layers} "
+                      f"full-width layers + lm_head, k={args.k} bs={args.batch}, {ctx}-token context per sequence (KV filled "
+                      f"directly, prompt pass not sampled); layer share x{cfg.num_hidden_layers / L:g} extrapolated ({dt:.2f} s/cycle "
+                      f"measured -> {full:.2f} s/cycle full depth), OpenMP {cores} threads"}
 
 
 def main():
@@ -240,7 +296,7 @@ def main():
     dev = f"cuda:{local}"
     torch.cuda.set_device(dev)
     from qspec_amd.model import CONFIGS, QuarotLlamaForCausalLM
-    from qspec_amd.spec_decode import QSpecEngine
+    QSpecEngine = make_bench_engine_class()
     cfg = CONFIGS[args.model]
     if world > 1:
         from qspec_amd import parallel
@@ -255,7 +311,7 @@ def main():
         total = warmup + steps + 2
         eng = QSpecEngine(model, args.k, args.batch, max_model_len=args.prompt_len + total * (args.k + 1) + 32,
                           block_size=16, max_new_tokens=total * (args.k + 1) + 8, use_graph=True, seed=args.seed)
-        eng.agreement_rho = agreement
+        eng.set_agreement(agreement)
         eng.add_sequences(prompts)               # prefill (W4A16), untimed: inputs are resident when timing starts
         for _ in range(warmup):
             eng.step()
@@ -273,7 +329,37 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         acc, emit, draft = (int(v) for v in (eng.sampler.counters - c0).tolist())
+        assert eng.error_flag() == 0, "a device-side hand-off timed out"
         return eng, dt, acc, emit, draft
+
+    def run_e2e(agreement, max_tokens):
+        """demo.py:139-160: prompt pass + decode until every request has max_tokens tokens; tokens / wall time.  The
+        host reads the batch's emitted counts once per cycle, as the worker does."""
+        n_cyc = max_tokens + 4            # worst case: one token per cycle
+        eng = QSpecEngine(model, args.k, args.batch, max_model_len=args.prompt_len + n_cyc * (args.k + 1) + 32,
+                          block_size=16, max_new_tokens=max_tokens + 2 * (args.k + 1) + 8, use_graph=True, seed=args.seed)
+        eng.set_agreement(agreement)
+        eng.add_sequences(prompts); eng.step(); eng.sync_lens()     # capture outside the timed region ...
+        for b in range(args.batch):
+            eng.free_slot(b)                                        # ... then start over from empty slots
+        barrier(world)
+        t0 = time.perf_counter()
+        eng.add_sequences(prompts)
+        t_prefill = time.perf_counter() - t0
+        cycles, done = 0, {}
+        while len(done) < args.batch:
+            eng.step()
+            cycles += 1
+            lens = eng.gen_lens.tolist()                            # the per-cycle host read
+            eng.sync_lens()
+            for b, n in enumerate(lens):                            # a request at max_tokens leaves the batch
+                if b not in done and n >= max_tokens:
+                    done[b] = max_tokens
+                    eng.free_slot(b)
+        barrier(world)
+        dt = time.perf_counter() - t0
+        total = sum(done.values())
+        return total / dt, t_prefill, cycles, dt
 
     eng, dt, acc, emit, draft = run(rho, args.warmup, args.steps)
     rate = acc / draft if draft else float("nan")
@@ -283,7 +369,8 @@ def main():
     flops_cycle = 2.0 * macs_per_token * args.batch * (2 * args.k + 1)
     agree_txt = "weights' own agreement" if rho is None else f"synthetic draft/target agreement {rho}"
     out = {
-        "metric": "accepted_tokens_per_s", "value": round(emit / dt, 2), "unit": "tokens/s", "n_gpus": world,
+        "metric": "accepted_tokens_per_s" if rho is None else f"accepted_tokens_per_s_at_synthetic_agreement_{rho:g}",
+        "value": round(emit / dt, 2), "unit": "tokens/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "w4a4: s4 x s4 -> i32 (i8 MFMA); w4a16: f16 x s4 -> f32 (f16 MFMA)", "data": "synthetic",
@@ -296,7 +383,9 @@ def main():
                                 if model.tp.shard_layers else
                                 "verify pass: vocab-parallel lm_head + all-gather; decoder layers replicated (their collectives "
                                 "would cost more than the weight stream they save at this size); draft pass replicated")),
-                   "agreement": rho},
+                   "agreement": rho,
+                   "capture": ("graph" if eng._graph is not None else
+                               ("draft-graph+eager-verify" if eng._graph_draft is not None else "eager"))},
         "draft_acceptance_rate": round(rate, 4), "system_efficiency": round(eff, 4),
         "accepted_tokens": acc, "emitted_tokens": emit, "draft_tokens": draft,
         "cycle_hbm_GBps_algorithmic": round(alg_bytes_cycle / (dt / args.steps) / 1e9, 1),
@@ -312,18 +401,25 @@ def main():
                                     "ms_per_step": round(dt2 / args.natural_steps * 1e3, 4),
                                     "draft_acceptance_rate": round(acc2 / draft2, 4) if draft2 else None,
                                     "system_efficiency": round(emit2 / ((draft2 // args.k) * (args.k + 1)), 4) if draft2 else None}
+    if args.e2e_max_tokens > 0:
+        tps, t_pre, cycles, wall = run_e2e(rho, args.e2e_max_tokens)
+        out["e2e_incl_prefill"] = {"value": round(tps, 2), "unit": "tokens/s", "max_tokens": args.e2e_max_tokens,
+                                   "prompt_tokens": args.batch * args.prompt_len, "prefill_ms": round(t_pre * 1e3, 2),
+                                   "cycles": cycles, "wall_s": round(wall, 4),
+                                   "what": "demo.py:139-160: generated tokens / (prompt pass + decode) wall time, requests "
+                                           "leave the batch at max_tokens"}
     if rank == 0 and not args.no_roofline:   # the draft pass is replicated under TP: rank 0's launches are every rank's
         tot_b, tot_t, n, per_shape = measure_dominant_kernel(model, eng)
         achieved = tot_b / tot_t / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic_per_launch(),
+                           "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic_per_launch(cfg.name, args.batch, args.k),
                            "kernel": "qspec::gemm_w4a4_stream_kernel (the four decoder GEMM launches of a draft forward, M = batch, in "
                                      "the forms the cycle launches for this shape: LN+int4-quant prologue -> qkv+RoPE+KV-write / "
                                      "gate_up+silu*up and o_proj / down_proj + residual add where built, the plain (xq, xs) forms otherwise)",
                            "launches": n, "avg_launch_us": round(tot_t / n * 1e6, 2),
                            "bytes_per_launch_avg": int(tot_b / n), "per_shape": per_shape}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model, args)
+        out["cpu_baseline"] = cpu_baseline(model, args, rho)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

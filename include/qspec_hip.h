@@ -302,7 +302,7 @@ int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* 
                            int k, int vocab, int64_t dp_stride_b, int64_t dp_stride_k, int64_t ids_stride_b,
                            int64_t ids_stride_k, int64_t bonus_stride,
                            int64_t* out_tokens, uint8_t* accepted, int64_t* recovered, int64_t* counters,
-                           void* workspace, void* stream);
+                           const int32_t* active_lens, void* workspace, void* stream);
 
 /* ops.advance_step_flashattn(num_seqs, num_queries, block_size, input_tokens, sampled_token_ids,
  *   input_positions, seq_lens, slot_mapping, block_tables)   csrc/prepare_inputs/advance_step.cu:14-64,192
@@ -314,16 +314,28 @@ int qspec_advance_step_flashattn(int num_seqs, int block_size, int64_t* input_to
 
 /* ---- spec-decode cycle glue (input assembly + bookkeeping kept on the GPU) -------------------- */
 /* Sequence state: seq_lens[b] = L known tokens (KV valid below L-1), last_token[b] = token at L-1.
+ * seq_lens[b] <= 0 marks an EMPTY batch slot (request finished / not admitted yet): it runs through the cycle as a
+ * dummy (token 0, position 0, slot -1: nothing written to the KV cache), emits nothing and is not counted
+ * (qspec_rejection_sample's active_lens).  max_blocks_per_seq: entries of a block-table row; a position beyond it
+ * gets slot -1 (no write) instead of an out-of-row lookup -- the host refuses such a step beforehand; 0 = unchecked.
 
  * First draft-step inputs (TP1DraftModelRunner.execute_model, vllm/spec_decode/draft_model_runner.py:169-262):
  *   token = last_token, position = L-1, ctx_len = L, slot from the block table. */
-int qspec_spec_prepare_draft(int batch, int block_size, const int64_t* last_token, const int32_t* seq_lens,
-                             const int32_t* block_tables, int64_t block_tables_stride, int64_t* input_tokens,
-                             int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens, void* stream);
+int qspec_spec_prepare_draft(int batch, int block_size, int max_blocks_per_seq, const int64_t* last_token,
+                             const int32_t* seq_lens, const int32_t* block_tables, int64_t block_tables_stride,
+                             int64_t* input_tokens, int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens,
+                             void* stream);
+
+/* _gpu_advance_step between two draft steps (vllm/spec_decode/draft_model_runner.py:78-135) = qspec_advance_step_flashattn
+ * with the two engine rules: a row whose slot is -1 stays put; a new position beyond the block table freezes the row. */
+int qspec_spec_advance_draft(int batch, int block_size, int max_blocks_per_seq, int64_t* input_tokens,
+                             const int64_t* sampled_token_ids, int64_t* positions, int32_t* ctx_lens,
+                             int64_t* slot_mapping, const int32_t* block_tables, int64_t block_tables_stride,
+                             void* stream);
 
 /* MQAScorer.score_proposals (vllm/spec_decode/mqa_scorer.py:12-76): per sequence the k+1 query tokens
  * [last_token, d_1..d_k] at positions L-1..L-1+k over the SAME block table (verify KV overwrites draft KV). */
-int qspec_spec_prepare_verify(int batch, int k, int block_size, const int64_t* last_token,
+int qspec_spec_prepare_verify(int batch, int k, int block_size, int max_blocks_per_seq, const int64_t* last_token,
                               const int64_t* draft_token_ids, int64_t ids_stride_b, int64_t ids_stride_k,
                               const int32_t* seq_lens, const int32_t* block_tables,
                               int64_t block_tables_stride, int64_t* tokens, int64_t* positions, int64_t* slot_mapping,
@@ -334,13 +346,6 @@ int qspec_spec_prepare_verify(int batch, int k, int block_size, const int64_t* l
  * last_token = last emitted token. */
 int qspec_spec_commit(int batch, int k, const int64_t* out_tokens, int32_t* seq_lens, int64_t* last_token,
                       int64_t* gen_tokens, int32_t* gen_lens, int gen_capacity, void* stream);
-
-/* Synthetic-workload knob for bench.py only (no reference counterpart): with probability rho raise the target logit of
- * the proposed token (verify logits [batch*(k+1), vocab]) so that random weights reproduce a chosen draft/target
- * agreement; the kernels of the cycle run unchanged. */
-int qspec_bench_force_agreement(qspec_half* target_logits, const int64_t* draft_token_ids, int64_t ids_stride_b,
-                                int64_t ids_stride_k, float rho, const uint64_t* rng_state, int batch, int k, int vocab,
-                                void* stream);
 
 #ifdef __cplusplus
 }

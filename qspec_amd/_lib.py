@@ -69,11 +69,11 @@ SIGNATURES = {
     "qspec_sampler_workspace_bytes": (_sz, [_i]),
     "qspec_softmax_argmax": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "qspec_rejection_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _i, _i64, _i64, _i64, _i64,
-                                    _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                    _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qspec_advance_step_flashattn": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "qspec_bench_force_agreement": (_i, [_vp, _vp, _i64, _i64, _f, _vp, _i, _i, _i, _vp]),
-    "qspec_spec_prepare_draft": (_i, [_i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "qspec_spec_prepare_verify": (_i, [_i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "qspec_spec_prepare_draft": (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "qspec_spec_advance_draft": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "qspec_spec_prepare_verify": (_i, [_i, _i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "qspec_spec_commit": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
 }
 

@@ -304,7 +304,7 @@ int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* 
                            int k, int vocab, int64_t dp_stride_b, int64_t dp_stride_k, int64_t ids_stride_b,
                            int64_t ids_stride_k, int64_t bonus_stride,
                            int64_t* out_tokens, uint8_t* accepted, int64_t* recovered, int64_t* counters,
-                           void* workspace, void* stream) {
+                           const int32_t* active_lens, void* workspace, void* stream) {
     const char* op = "qspec_rejection_sample";
     if (batch == 0) return 0;
     NONNULL(op, target_with_bonus_probs); NONNULL(op, bonus_token_ids); NONNULL(op, draft_probs);
@@ -312,7 +312,7 @@ int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* 
     NONNULL(op, workspace);
     if (batch * k > 4096) return fail("%s: batch*k=%d too large", op, batch * k);
     if (k < 1) return fail("%s: k=%d must be >= 1", op, k);
-    return finish(op, qspec::rejection_sample(target_with_bonus_probs, draft_probs, draft_token_ids, bonus_token_ids, uniform, exponential, seed, offset, rng_state, batch, k, vocab, dp_stride_b, dp_stride_k, ids_stride_b, ids_stride_k, bonus_stride, out_tokens, accepted, recovered, counters, workspace, ST));
+    return finish(op, qspec::rejection_sample(target_with_bonus_probs, draft_probs, draft_token_ids, bonus_token_ids, uniform, exponential, seed, offset, rng_state, batch, k, vocab, dp_stride_b, dp_stride_k, ids_stride_b, ids_stride_k, bonus_stride, out_tokens, accepted, recovered, counters, active_lens, workspace, ST));
 }
 int qspec_advance_step_flashattn(int num_seqs, int block_size, int64_t* input_tokens,
                                  const int64_t* sampled_token_ids, int64_t* input_positions, int32_t* seq_lens,
@@ -325,16 +325,27 @@ int qspec_advance_step_flashattn(int num_seqs, int block_size, int64_t* input_to
     return finish(op, qspec::advance_step(num_seqs, block_size, input_tokens, sampled_token_ids, input_positions, seq_lens, slot_mapping, block_tables, block_tables_stride, ST));
 }
 
-int qspec_spec_prepare_draft(int batch, int block_size, const int64_t* last_token, const int32_t* seq_lens,
-                             const int32_t* block_tables, int64_t block_tables_stride, int64_t* input_tokens,
-                             int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens, void* stream) {
+int qspec_spec_advance_draft(int batch, int block_size, int max_blocks_per_seq, int64_t* input_tokens,
+                             const int64_t* sampled_token_ids, int64_t* positions, int32_t* ctx_lens,
+                             int64_t* slot_mapping, const int32_t* block_tables, int64_t block_tables_stride,
+                             void* stream) {
+    const char* op = "qspec_spec_advance_draft";
+    if (batch == 0) return 0;
+    NONNULL(op, input_tokens); NONNULL(op, sampled_token_ids); NONNULL(op, positions); NONNULL(op, ctx_lens);
+    NONNULL(op, slot_mapping); NONNULL(op, block_tables);
+    return finish(op, qspec::spec_advance_draft(batch, block_size, max_blocks_per_seq, input_tokens, sampled_token_ids, positions, ctx_lens, slot_mapping, block_tables, block_tables_stride, ST));
+}
+int qspec_spec_prepare_draft(int batch, int block_size, int max_blocks_per_seq, const int64_t* last_token,
+                             const int32_t* seq_lens, const int32_t* block_tables, int64_t block_tables_stride,
+                             int64_t* input_tokens, int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens,
+                             void* stream) {
     const char* op = "qspec_spec_prepare_draft";
     if (batch == 0) return 0;
     NONNULL(op, last_token); NONNULL(op, seq_lens); NONNULL(op, block_tables); NONNULL(op, input_tokens);
     NONNULL(op, positions); NONNULL(op, slot_mapping); NONNULL(op, ctx_lens);
-    return finish(op, qspec::spec_prepare_draft(batch, block_size, last_token, seq_lens, block_tables, block_tables_stride, input_tokens, positions, slot_mapping, ctx_lens, ST));
+    return finish(op, qspec::spec_prepare_draft(batch, block_size, max_blocks_per_seq, last_token, seq_lens, block_tables, block_tables_stride, input_tokens, positions, slot_mapping, ctx_lens, ST));
 }
-int qspec_spec_prepare_verify(int batch, int k, int block_size, const int64_t* last_token,
+int qspec_spec_prepare_verify(int batch, int k, int block_size, int max_blocks_per_seq, const int64_t* last_token,
                               const int64_t* draft_token_ids, int64_t ids_stride_b, int64_t ids_stride_k,
                               const int32_t* seq_lens, const int32_t* block_tables,
                               int64_t block_tables_stride, int64_t* tokens, int64_t* positions, int64_t* slot_mapping,
@@ -343,7 +354,7 @@ int qspec_spec_prepare_verify(int batch, int k, int block_size, const int64_t* l
     if (batch == 0) return 0;
     NONNULL(op, last_token); NONNULL(op, draft_token_ids); NONNULL(op, seq_lens); NONNULL(op, block_tables);
     NONNULL(op, tokens); NONNULL(op, positions); NONNULL(op, slot_mapping); NONNULL(op, ctx_lens);
-    return finish(op, qspec::spec_prepare_verify(batch, k, block_size, last_token, draft_token_ids, ids_stride_b, ids_stride_k, seq_lens, block_tables, block_tables_stride, tokens, positions, slot_mapping, ctx_lens, ST));
+    return finish(op, qspec::spec_prepare_verify(batch, k, block_size, max_blocks_per_seq, last_token, draft_token_ids, ids_stride_b, ids_stride_k, seq_lens, block_tables, block_tables_stride, tokens, positions, slot_mapping, ctx_lens, ST));
 }
 int qspec_spec_commit(int batch, int k, const int64_t* out_tokens, int32_t* seq_lens, int64_t* last_token,
                       int64_t* gen_tokens, int32_t* gen_lens, int gen_capacity, void* stream) {
@@ -418,15 +429,6 @@ int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const
     if (use_stream() && qspec::gemm_w4a16_stream_supported(M, 2 * intermediate, K))
         return finish(op, qspec::gemm_w4a16_stream_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, 0, intermediate, ST));
     return finish(op, qspec::gemm_w4a16_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, 0, intermediate, workspace, ST));
-}
-
-int qspec_bench_force_agreement(qspec_half* target_logits, const int64_t* draft_token_ids, int64_t ids_stride_b,
-                                int64_t ids_stride_k, float rho, const uint64_t* rng_state, int batch, int k, int vocab,
-                                void* stream) {
-    const char* op = "qspec_bench_force_agreement";
-    if (batch == 0) return 0;
-    NONNULL(op, target_logits); NONNULL(op, draft_token_ids); NONNULL(op, rng_state);
-    return finish(op, qspec::spec_force_agreement(H(target_logits), draft_token_ids, ids_stride_b, ids_stride_k, rho, rng_state, batch, k, vocab, ST));
 }
 
 int qspec_w4a16_linear_ksliced(const qspec_half* x, int64_t ldx, const int8_t* wq, int64_t ldw_bytes,

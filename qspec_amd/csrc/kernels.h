@@ -129,16 +129,17 @@ int rejection_sample(const float* target_probs, const float* draft_probs, const 
                      const int64_t* bonus_ids, const float* uniform, const float* exponential, uint64_t seed,
                      uint64_t offset, uint64_t* rng_state, int B, int k, int V, int64_t dp_sb, int64_t dp_sk,
                      int64_t di_sb, int64_t di_sk, int64_t bonus_stride, int64_t* out_tokens, uint8_t* accepted,
-                     int64_t* recovered, int64_t* counters, void* ws, hipStream_t st);
+                     int64_t* recovered, int64_t* counters, const int32_t* active_lens, void* ws, hipStream_t st);
 int advance_step(int n, int block_size, int64_t* input_tokens, const int64_t* sampled, int64_t* positions,
                  int32_t* seq_lens, int64_t* slot_mapping, const int32_t* block_tables, int64_t bt_stride,
                  hipStream_t st);
-int spec_force_agreement(f16* logits, const int64_t* draft_ids, int64_t di_sb, int64_t di_sk, float rho,
-                         const uint64_t* rng_state, int B, int k, int V, hipStream_t st);
-int spec_prepare_draft(int B, int block_size, const int64_t* last_token, const int32_t* seq_lens,
+int spec_advance_draft(int n, int block_size, int max_blocks, int64_t* input_tokens, const int64_t* sampled,
+                       int64_t* positions, int32_t* ctx_lens, int64_t* slot_mapping, const int32_t* block_tables,
+                       int64_t bt_stride, hipStream_t st);
+int spec_prepare_draft(int B, int block_size, int max_blocks, const int64_t* last_token, const int32_t* seq_lens,
                        const int32_t* block_tables, int64_t bt_stride, int64_t* input_tokens, int64_t* positions,
                        int64_t* slot_mapping, int32_t* ctx_lens, hipStream_t st);
-int spec_prepare_verify(int B, int k, int block_size, const int64_t* last_token, const int64_t* draft_ids,
+int spec_prepare_verify(int B, int k, int block_size, int max_blocks, const int64_t* last_token, const int64_t* draft_ids,
                         int64_t di_sb, int64_t di_sk, const int32_t* seq_lens, const int32_t* block_tables, int64_t bt_stride, int64_t* v_tokens,
                         int64_t* v_positions, int64_t* v_slots, int32_t* v_ctx_lens, hipStream_t st);
 int spec_commit(int B, int k, const int64_t* out_tokens, int32_t* seq_lens, int64_t* last_token, int64_t* gen_tokens,

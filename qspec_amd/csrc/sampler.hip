@@ -246,7 +246,10 @@ __global__ __launch_bounds__(1024) void rejection_output_kernel(
     const int64_t* __restrict__ draft_ids, const int64_t* __restrict__ bonus_ids, const float* __restrict__ uniform,
     uint64_t seed, uint64_t offset, uint64_t* __restrict__ rng_state, const SmPartA* part_a, int B, int k, int V,
     int64_t dp_sb, int64_t dp_sk, int64_t di_sb, int64_t di_sk, int64_t bonus_stride, uint8_t* __restrict__ accepted,
-    int64_t* __restrict__ recovered, int64_t* __restrict__ out, int64_t* __restrict__ counters) {
+    int64_t* __restrict__ recovered, int64_t* __restrict__ out, int64_t* __restrict__ counters,
+    const int32_t* __restrict__ active_lens) {
+    // active_lens (may be NULL): row b takes part iff active_lens[b] > 0 (an empty batch slot of the engine emits
+    // nothing and is not counted: the reference only ever sees the sequences that are scheduled)
     if (rng_state) {
         seed = rng_state[0];
         offset = rng_state[1];
@@ -272,12 +275,18 @@ __global__ __launch_bounds__(1024) void rejection_output_kernel(
         const float px = draft_probs[b * dp_sb + i * dp_sk + x];
         const float rq = qx / px;
         // torch.minimum propagates NaN (0/0) and `u < NaN` is false: such a token is rejected
-        accepted[bk] = ((rq == rq) && (u < fminf(rq, 1.0f))) ? 1 : 0;
+        const bool row_on = !active_lens || active_lens[b] > 0;
+        accepted[bk] = (row_on && (rq == rq) && (u < fminf(rq, 1.0f))) ? 1 : 0;
         recovered[bk] = am.i == 0x7fffffff ? 0 : am.i;
     }
     __syncthreads();
-    int acc_cnt = 0, emit_cnt = 0;
+    int acc_cnt = 0, emit_cnt = 0, rows_on = 0;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        if (active_lens && active_lens[b] <= 0) {
+            for (int i = 0; i <= k; i++) out[b * (k + 1) + i] = -1;
+            continue;
+        }
+        rows_on++;
         int limit = k;
         for (int i = 0; i < k; i++) {
             if (accepted[b * k + i]) acc_cnt++;
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(1024) void rejection_output_kernel(
     if (counters) {
         if (acc_cnt) atomicAdd(reinterpret_cast<unsigned long long*>(counters), (unsigned long long)acc_cnt);
         if (emit_cnt) atomicAdd(reinterpret_cast<unsigned long long*>(counters + 1), (unsigned long long)emit_cnt);
-        if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(counters + 2), (unsigned long long)B * k);
+        if (rows_on) atomicAdd(reinterpret_cast<unsigned long long*>(counters + 2), (unsigned long long)rows_on * k);
     }
     if (rng_state && threadIdx.x == 0) rng_state[1] = offset + 1;  // after every draw of this call
 }
@@ -304,7 +313,7 @@ int rejection_sample(const float* target_probs, const float* draft_probs, const 
                      const int64_t* bonus_ids, const float* uniform, const float* exponential, uint64_t seed,
                      uint64_t offset, uint64_t* rng_state, int B, int k, int V, int64_t dp_sb, int64_t dp_sk,
                      int64_t di_sb, int64_t di_sk, int64_t bonus_stride, int64_t* out_tokens, uint8_t* accepted,
-                     int64_t* recovered, int64_t* counters, void* ws, hipStream_t st) {
+                     int64_t* recovered, int64_t* counters, const int32_t* active_lens, void* ws, hipStream_t st) {
     if (B == 0) return 0;
     if (k < 1) return -1;
     SmPartA* part_a = reinterpret_cast<SmPartA*>(ws);
@@ -315,7 +324,7 @@ int rejection_sample(const float* target_probs, const float* draft_probs, const 
                        exponential, seed, offset, rng_state, k, V, dp_sb, dp_sk, part_s, part_a);
     hipLaunchKernelGGL(rejection_output_kernel, dim3(1), dim3(1024), 0, st, target_probs, draft_probs, draft_ids,
                        bonus_ids, uniform, seed, offset, rng_state, part_a, B, k, V, dp_sb, dp_sk, di_sb, di_sk,
-                       bonus_stride, accepted, recovered, out_tokens, counters);
+                       bonus_stride, accepted, recovered, out_tokens, counters, active_lens);
     return 0;
 }
 
@@ -350,7 +359,17 @@ int advance_step(int n, int block_size, int64_t* input_tokens, const int64_t* sa
 //  SpecDecodeWorker._create_output_sampler_list bookkeeping, spec_decode_worker.py:972-1063)
 // kept on the GPU so that a whole draft+verify+accept cycle is one graph with no host sync.
 // Sequence state: seq_lens[b] = L tokens known, KV valid for positions < L-1, last_token[b] = token L-1.
-__global__ void spec_prepare_draft_kernel(int B, int block_size, const int64_t* __restrict__ last_token,
+// Empty batch slots (seq_lens[b] <= 0: a finished / not yet admitted request) run through the captured cycle as a
+// harmless dummy: token 0 at position 0, context of one key, slot -1 (nothing is written to the cache), no output.
+// A position beyond the sequence's block table (max_blocks entries) also gets slot -1 instead of reading past the row:
+// the host refuses such a step beforehand (QSpecEngine.step), this is the in-kernel safety net.
+__device__ __forceinline__ int64_t spec_slot(const int32_t* block_tables, int64_t bt_stride, int b, int pos,
+                                             int block_size, int max_blocks) {
+    const int blk = pos / block_size;
+    if (pos < 0 || (max_blocks > 0 && blk >= max_blocks)) return -1;
+    return (int64_t)block_tables[bt_stride * b + blk] * block_size + pos % block_size;
+}
+__global__ void spec_prepare_draft_kernel(int B, int block_size, int max_blocks, const int64_t* __restrict__ last_token,
                                           const int32_t* __restrict__ seq_lens,
                                           const int32_t* __restrict__ block_tables, int64_t bt_stride,
                                           int64_t* __restrict__ input_tokens, int64_t* __restrict__ positions,
@@ -358,13 +377,41 @@ __global__ void spec_prepare_draft_kernel(int B, int block_size, const int64_t* 
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int L = seq_lens[b], pos = L - 1;
+    if (L <= 0) {
+        input_tokens[b] = 0;
+        positions[b] = 0;
+        ctx_lens[b] = 1;
+        slot_mapping[b] = -1;
+        return;
+    }
     input_tokens[b] = last_token[b];
     positions[b] = pos;
     ctx_lens[b] = L;
-    slot_mapping[b] = (int64_t)block_tables[bt_stride * b + pos / block_size] * block_size + pos % block_size;
+    slot_mapping[b] = spec_slot(block_tables, bt_stride, b, pos, block_size, max_blocks);
+}
+// _gpu_advance_step between two draft steps (draft_model_runner.py:78-135) with the two engine rules above: a row
+// whose slot is -1 (empty, or out of blocks) stays put; a new position beyond the block table gets slot -1.
+__global__ void spec_advance_draft_kernel(int n, int block_size, int max_blocks, int64_t* __restrict__ input_tokens,
+                                          const int64_t* __restrict__ sampled, int64_t* __restrict__ positions,
+                                          int32_t* __restrict__ ctx_lens, int64_t* __restrict__ slot_mapping,
+                                          const int32_t* __restrict__ block_tables, int64_t bt_stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (slot_mapping[i] < 0) return;
+    input_tokens[i] = sampled[i];
+    const int next_len = ctx_lens[i] + 1;
+    const int pos = next_len - 1;
+    const int64_t slot = spec_slot(block_tables, bt_stride, i, pos, block_size, max_blocks);
+    if (slot < 0) {   // out of blocks: freeze the row (its remaining draft steps recompute the same token)
+        slot_mapping[i] = -1;
+        return;
+    }
+    ctx_lens[i] = next_len;
+    positions[i] = pos;
+    slot_mapping[i] = slot;
 }
 // verify query of sequence b = [last_token, d_1 .. d_k] at positions L-1 .. L-1+k (mqa_scorer.py:42-60)
-__global__ void spec_prepare_verify_kernel(int B, int k, int block_size, const int64_t* __restrict__ last_token,
+__global__ void spec_prepare_verify_kernel(int B, int k, int block_size, int max_blocks, const int64_t* __restrict__ last_token,
                                            const int64_t* __restrict__ draft_ids, int64_t di_sb, int64_t di_sk,
                                            const int32_t* __restrict__ seq_lens,
                                            const int32_t* __restrict__ block_tables, int64_t bt_stride,
@@ -374,9 +421,16 @@ __global__ void spec_prepare_verify_kernel(int B, int k, int block_size, const i
     if (i >= B * (k + 1)) return;
     const int b = i / (k + 1), j = i % (k + 1);
     const int L = seq_lens[b], pos = L - 1 + j;
+    if (L <= 0) {   // empty slot: k + 1 dummy queries over the first k + 1 keys of the row, nothing written
+        v_tokens[i] = 0;
+        v_positions[i] = j;
+        v_slots[i] = -1;
+        if (j == 0) v_ctx_lens[b] = k + 1;
+        return;
+    }
     v_tokens[i] = j == 0 ? last_token[b] : draft_ids[b * di_sb + (j - 1) * di_sk];
     v_positions[i] = pos;
-    v_slots[i] = (int64_t)block_tables[bt_stride * b + pos / block_size] * block_size + pos % block_size;
+    v_slots[i] = spec_slot(block_tables, bt_stride, b, pos, block_size, max_blocks);
     if (j == 0) v_ctx_lens[b] = L + k;
 }
 // append the emitted tokens (out != -1, a prefix of the row) and advance the sequence state
@@ -398,44 +452,28 @@ __global__ void spec_commit_kernel(int B, int k, const int64_t* __restrict__ out
         if (gen_lens) gen_lens[b] += n;
     }
 }
-// Synthetic-workload knob (bench only): random int4 weights give a draft/target agreement near zero, a trained QSpec
-// checkpoint ~0.96.  With probability rho the target logit of the proposed token is raised to the fp16
-// maximum, so the verify pass "agrees" with the draft at a controlled rate.  Every kernel of the cycle still runs
-// on the same shapes; only the token values change.  Philox keyed by rng_state, offset bumped by 1<<32 lanes apart.
-__global__ void spec_force_agreement_kernel(f16* __restrict__ logits, const int64_t* __restrict__ draft_ids,
-                                            int64_t di_sb, int64_t di_sk, float rho,
-                                            const uint64_t* __restrict__ rng_state, int B, int k, int V) {
-    const int bk = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bk >= B * k) return;
-    const int b = bk / k, i = bk % k;
-    uint32_t r[4];
-    philox4x32(0xA5A5A5A5u, (uint32_t)bk, (uint32_t)rng_state[1], (uint32_t)(rng_state[1] >> 32), (uint32_t)rng_state[0],
-               (uint32_t)(rng_state[0] >> 32) ^ 0x51ED27u, r);
-    if ((float)(r[0] >> 8) * (1.0f / 16777216.0f) < rho)
-        logits[((size_t)b * (k + 1) + i) * V + draft_ids[b * di_sb + i * di_sk]] = (f16)60000.0f;
-}
-int spec_force_agreement(f16* logits, const int64_t* draft_ids, int64_t di_sb, int64_t di_sk, float rho,
-                         const uint64_t* rng_state, int B, int k, int V, hipStream_t st) {
-    if (B == 0) return 0;
-    hipLaunchKernelGGL(spec_force_agreement_kernel, dim3((B * k + 63) / 64), dim3(64), 0, st, logits, draft_ids, di_sb,
-                       di_sk, rho, rng_state, B, k, V);
-    return 0;
-}
-
-int spec_prepare_draft(int B, int block_size, const int64_t* last_token, const int32_t* seq_lens,
+int spec_prepare_draft(int B, int block_size, int max_blocks, const int64_t* last_token, const int32_t* seq_lens,
                        const int32_t* block_tables, int64_t bt_stride, int64_t* input_tokens, int64_t* positions,
                        int64_t* slot_mapping, int32_t* ctx_lens, hipStream_t st) {
     if (B == 0) return 0;
-    hipLaunchKernelGGL(spec_prepare_draft_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, block_size, last_token,
-                       seq_lens, block_tables, bt_stride, input_tokens, positions, slot_mapping, ctx_lens);
+    hipLaunchKernelGGL(spec_prepare_draft_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, block_size, max_blocks,
+                       last_token, seq_lens, block_tables, bt_stride, input_tokens, positions, slot_mapping, ctx_lens);
     return 0;
 }
-int spec_prepare_verify(int B, int k, int block_size, const int64_t* last_token, const int64_t* draft_ids,
+int spec_advance_draft(int n, int block_size, int max_blocks, int64_t* input_tokens, const int64_t* sampled,
+                       int64_t* positions, int32_t* ctx_lens, int64_t* slot_mapping, const int32_t* block_tables,
+                       int64_t bt_stride, hipStream_t st) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(spec_advance_draft_kernel, dim3((n + 63) / 64), dim3(64), 0, st, n, block_size, max_blocks,
+                       input_tokens, sampled, positions, ctx_lens, slot_mapping, block_tables, bt_stride);
+    return 0;
+}
+int spec_prepare_verify(int B, int k, int block_size, int max_blocks, const int64_t* last_token, const int64_t* draft_ids,
                         int64_t di_sb, int64_t di_sk, const int32_t* seq_lens, const int32_t* block_tables, int64_t bt_stride, int64_t* v_tokens,
                         int64_t* v_positions, int64_t* v_slots, int32_t* v_ctx_lens, hipStream_t st) {
     if (B == 0) return 0;
     const int n = B * (k + 1);
-    hipLaunchKernelGGL(spec_prepare_verify_kernel, dim3((n + 63) / 64), dim3(64), 0, st, B, k, block_size, last_token,
+    hipLaunchKernelGGL(spec_prepare_verify_kernel, dim3((n + 63) / 64), dim3(64), 0, st, B, k, block_size, max_blocks, last_token,
                        draft_ids, di_sb, di_sk, seq_lens, block_tables, bt_stride, v_tokens, v_positions, v_slots, v_ctx_lens);
     return 0;
 }

@@ -482,7 +482,7 @@ def softmax_argmax(logits, probs, token, workspace=None):
 
 def rejection_sample(target_with_bonus_probs, bonus_token_ids, draft_probs, draft_token_ids, out_tokens, accepted,
                      recovered, counters=None, uniform=None, exponential=None, seed: int = 0, offset: int = 0,
-                     rng_state=None, workspace=None):
+                     rng_state=None, workspace=None, active_lens=None):
     B, k, V = draft_probs.shape
     # draft_probs / draft_token_ids / bonus_token_ids may be strided views (step-major draft buffers)
     if draft_probs.stride(2) != 1 or draft_probs.dtype != _F32 or draft_token_ids.dtype != _I64 \
@@ -495,7 +495,7 @@ def rejection_sample(target_with_bonus_probs, bonus_token_ids, draft_probs, draf
           draft_token_ids.stride(0), draft_token_ids.stride(1),
           bonus_token_ids.stride(0) if bonus_token_ids.numel() > 1 else 1, _chk(out_tokens, "out_tokens", _I64),
           _chk(accepted, "accepted", _U8), _chk(recovered, "recovered", _I64), _opt(counters, "counters", _I64),
-          _sampler_ws(B * k, draft_probs.device, workspace).data_ptr(), _stream())
+          _opt(active_lens, "active_lens", _I32), _sampler_ws(B * k, draft_probs.device, workspace).data_ptr(), _stream())
 
 
 def advance_step_flashattn(num_seqs, num_queries, block_size, input_tokens, sampled_token_ids, input_positions,
@@ -511,10 +511,20 @@ def advance_step_flashattn(num_seqs, num_queries, block_size, input_tokens, samp
 
 # ------------------------------------------------------------------ spec-decode cycle glue
 
+def spec_advance_draft(block_size, input_tokens, sampled_token_ids, positions, ctx_lens, slot_mapping, block_tables):
+    """_gpu_advance_step between two draft steps (draft_model_runner.py:78-135) with the engine's empty-slot and
+    out-of-blocks rules (include/qspec_hip.h)."""
+    B = ctx_lens.numel()
+    _call("qspec_spec_advance_draft", B, block_size, block_tables.shape[1], _chk(input_tokens, "input_tokens", _I64),
+          _chk(sampled_token_ids, "sampled_token_ids", _I64), _chk(positions, "positions", _I64),
+          _chk(ctx_lens, "ctx_lens", _I32), _chk(slot_mapping, "slot_mapping", _I64),
+          _chk(block_tables, "block_tables", _I32), block_tables.stride(0), _stream())
+
+
 def spec_prepare_draft(last_token, seq_lens, block_tables, block_size, input_tokens, positions, slot_mapping,
                        ctx_lens):
     B = seq_lens.numel()
-    _call("qspec_spec_prepare_draft", B, block_size, _chk(last_token, "last_token", _I64),
+    _call("qspec_spec_prepare_draft", B, block_size, block_tables.shape[1], _chk(last_token, "last_token", _I64),
           _chk(seq_lens, "seq_lens", _I32), _chk(block_tables, "block_tables", _I32), block_tables.stride(0),
           _chk(input_tokens, "input_tokens", _I64), _chk(positions, "positions", _I64),
           _chk(slot_mapping, "slot_mapping", _I64), _chk(ctx_lens, "ctx_lens", _I32), _stream())
@@ -523,7 +533,7 @@ def spec_prepare_draft(last_token, seq_lens, block_tables, block_size, input_tok
 def spec_prepare_verify(last_token, draft_token_ids, seq_lens, block_tables, block_size, tokens, positions,
                         slot_mapping, ctx_lens):
     B, k = draft_token_ids.shape
-    _call("qspec_spec_prepare_verify", B, k, block_size, _chk(last_token, "last_token", _I64),
+    _call("qspec_spec_prepare_verify", B, k, block_size, block_tables.shape[1], _chk(last_token, "last_token", _I64),
           draft_token_ids.data_ptr(), draft_token_ids.stride(0), draft_token_ids.stride(1),
           _chk(seq_lens, "seq_lens", _I32),
           _chk(block_tables, "block_tables", _I32), block_tables.stride(0), _chk(tokens, "tokens", _I64),
@@ -537,12 +547,3 @@ def spec_commit(out_tokens, seq_lens, last_token, gen_tokens=None, gen_lens=None
     _call("qspec_spec_commit", B, k1 - 1, _chk(out_tokens, "out_tokens", _I64), _chk(seq_lens, "seq_lens", _I32),
           _chk(last_token, "last_token", _I64), _opt(gen_tokens, "gen_tokens", _I64),
           _opt(gen_lens, "gen_lens", _I32), cap, _stream())
-
-
-def bench_force_agreement(target_logits, draft_token_ids, rho: float, rng_state):
-    """bench.py only: raise the target logit of the proposed token with probability rho (synthetic agreement)."""
-    B, k = draft_token_ids.shape
-    V = target_logits.shape[-1]
-    _call("qspec_bench_force_agreement", _chk(target_logits, "target_logits", _F16), draft_token_ids.data_ptr(),
-          draft_token_ids.stride(0), draft_token_ids.stride(1), float(rho), _chk(rng_state, "rng_state", _I64), B, k, V,
-          _stream())

@@ -13,6 +13,15 @@ The draft and the verify pass share one packed-int4 weight buffer per layer and 
 (spec_decode_worker.py:339-345,421-444; vllm/worker/worker.py:309-327); the verify pass rewrites the
 k+1 KV slots the draft pass wrote (mqa_scorer.py:42-60), which is also why no bonus-token batch
 expansion is needed (multi_step_worker.py:74-80).
+
+Batch membership: the graph is captured for `max_batch` SLOTS; a slot is empty while seq_lens[slot] == 0 and then
+runs through the cycle as a dummy that writes nothing and emits nothing (include/qspec_hip.h, spec-decode glue), so
+requests join (`add_sequence`) and leave (`free_slot`) between replays without re-capturing.  Block tables are per
+slot and may be set from the scheduler's tables (`set_block_table`); by default slot b owns a contiguous range.
+
+Capacity is part of the contract: `step()` refuses (ValueError, nothing enqueued) a cycle that could write beyond a
+sequence's block table / max_model_len / output buffer, from a host-side upper bound of every sequence length that is
+exact after `sync_lens()` (the worker syncs once per cycle anyway) and grows by k+1 per unsynced step otherwise.
 """
 from __future__ import annotations
 
@@ -63,12 +72,21 @@ class QSpecEngine:
         self.kv_caches = [(torch.zeros(shape, dtype=torch.float16, device=dev),
                            torch.zeros(shape, dtype=torch.float16, device=dev)) for _ in range(cfg.num_hidden_layers)]
         self.block_tables = torch.arange(self.num_blocks, dtype=i32, device=dev).view(B, self.blocks_per_seq).contiguous()
-        # ---- sequence state
+        self._capacity = [self.blocks_per_seq * block_size] * B    # tokens the slot's block table covers (host)
+        self._len_ub = [0] * B                                     # host upper bound of seq_lens (0 = empty slot)
+        self._gen_ub = [0] * B                                     # host upper bound of gen_lens
+        # ---- sequence state (seq_lens[b] == 0: empty slot)
         self.seq_lens = torch.zeros(B, dtype=i32, device=dev)      # L: tokens known (KV valid below L-1)
         self.last_token = torch.zeros(B, dtype=i64, device=dev)
         self.gen_tokens = torch.full((B, max_new_tokens + k + 1), -1, dtype=i64, device=dev)
         self.gen_lens = torch.zeros(B, dtype=i32, device=dev)
         self.n_active = 0
+        # sequences taking part in the next step (the scheduler may leave a running request out of a step): the cycle
+        # works on eff_lens = seq_lens * step_mask, so a request that sits out looks like an empty slot and keeps its state
+        self.step_mask = torch.ones(B, dtype=i32, device=dev)
+        self.eff_lens = torch.zeros(B, dtype=i32, device=dev)
+        self._mask_host = [1] * B
+        self._len_before, self._gen_before = [0] * B, [0] * B
         # ---- per-cycle buffers
         V = cfg.vocab_size
         n_splits = n_splits_for(max_model_len, B * cfg.num_key_value_heads)
@@ -102,39 +120,109 @@ class QSpecEngine:
         self.inject_uniform: Optional[torch.Tensor] = None
         self.inject_exponential: Optional[torch.Tensor] = None
         self._prefill_scratch: Optional[Scratch] = None
-        # bench-only synthetic agreement between draft and target (None = the weights' own agreement)
-        self.agreement_rho: Optional[float] = None
+        self._post_logits_hook = None   # verify logits -> None, inside the captured cycle (bench.py's BenchEngine only)
 
     # ------------------------------------------------------------------ prefill (_run_no_spec, :666-720)
     @torch.no_grad()
     def add_sequences(self, prompts: Sequence[Sequence[int]]):
-        """Prompt pass: scorer only, W4A16 (the proposer never runs on prefill, spec_decode_worker.py:699);
-        the first generated token is the target's greedy token."""
-        assert len(prompts) == self.B, "the cycle graph is captured for a fixed batch"
-        cfg, dev = self.cfg, self.device
+        """Prompt pass for slots 0 .. len(prompts)-1 (a full batch in the benchmarks and most tests)."""
+        assert len(prompts) <= self.B
         for b, prompt in enumerate(prompts):
-            T = len(prompt)
-            assert 0 < T + self.k + 2 <= self.max_model_len
-            if self._prefill_scratch is None or self._prefill_scratch.T < T:
-                self._prefill_scratch = Scratch(cfg, T, 1, T, n_splits_for(T), dev, logits_rows=1)
-            s = self._prefill_scratch
-            ids = torch.tensor(prompt, dtype=torch.int64, device=dev)
-            pos = torch.arange(T, dtype=torch.int64, device=dev)
-            slots = self._slots_for(b, pos)
-            md = AttentionMetadata(slots, self.block_tables[b:b + 1].contiguous(),
-                                   torch.tensor([T], dtype=torch.int32, device=dev),
-                                   torch.tensor([0, T], dtype=torch.int32, device=dev), T, n_splits_for(T))
-            hs = self.model.forward(ids, pos, self.kv_caches, md, s, w4a4=False)
-            logits = self.model.compute_logits(hs[T - 1:T], s)
-            probs = torch.empty(1, cfg.vocab_size, dtype=torch.float32, device=dev)
-            tok = torch.empty(1, dtype=torch.int64, device=dev)
-            ops.softmax_argmax(logits, probs, tok)
-            self.seq_lens[b] = T + 1
-            self.last_token[b] = tok[0]
-            self.gen_tokens[b, 0] = tok[0]
-            self.gen_lens[b] = 1
-        self.n_active = self.B
+            self.add_sequence(b, prompt, sync=False)
         torch.cuda.synchronize()
+
+    @torch.no_grad()
+    def add_sequence(self, slot: int, prompt: Sequence[int], block_table: Optional[Sequence[int]] = None,
+                     sync: bool = True) -> None:
+        """Admit a request into an empty slot: scorer-only W4A16 prompt pass (the proposer never runs on prefill,
+        spec_decode_worker.py:699); the first generated token is the target's greedy token."""
+        cfg, dev, b = self.cfg, self.device, slot
+        if not 0 <= b < self.B:
+            raise ValueError(f"slot {b} outside the captured batch of {self.B}")
+        if self._len_ub[b] != 0:
+            raise ValueError(f"slot {b} is occupied; free_slot() it first")
+        if block_table is not None:
+            self.set_block_table(b, block_table)
+        T = len(prompt)
+        if T < 1 or T + 1 > min(self._capacity[b], self.max_model_len):
+            raise ValueError(f"prompt of {T} tokens does not fit slot {b} (capacity {self._capacity[b]}, "
+                             f"max_model_len {self.max_model_len})")
+        if self._prefill_scratch is None or self._prefill_scratch.T < T:
+            self._prefill_scratch = Scratch(cfg, T, 1, T, n_splits_for(T), dev, logits_rows=1)
+        s = self._prefill_scratch
+        ids = torch.tensor(prompt, dtype=torch.int64, device=dev)
+        pos = torch.arange(T, dtype=torch.int64, device=dev)
+        slots = self._slots_for(b, pos)
+        md = AttentionMetadata(slots, self.block_tables[b:b + 1].contiguous(),
+                               torch.tensor([T], dtype=torch.int32, device=dev),
+                               torch.tensor([0, T], dtype=torch.int32, device=dev), T, n_splits_for(T))
+        hs = self.model.forward(ids, pos, self.kv_caches, md, s, w4a4=False)
+        logits = self.model.compute_logits(hs[T - 1:T], s)
+        probs = torch.empty(1, cfg.vocab_size, dtype=torch.float32, device=dev)
+        tok = torch.empty(1, dtype=torch.int64, device=dev)
+        ops.softmax_argmax(logits, probs, tok)
+        self.seq_lens[b] = T + 1
+        self.last_token[b] = tok[0]
+        self.gen_tokens[b].fill_(-1)
+        self.gen_tokens[b, 0] = tok[0]
+        self.gen_lens[b] = 1
+        self._len_ub[b] = T + 1
+        self._gen_ub[b] = 1
+        self.n_active = sum(1 for v in self._len_ub if v > 0)
+        if sync:
+            torch.cuda.synchronize()
+
+    def free_slot(self, slot: int) -> None:
+        """The request in `slot` has finished (EOS / max_tokens / aborted): the slot goes back to empty."""
+        self.seq_lens[slot] = 0
+        self.gen_lens[slot] = 0
+        self._len_ub[slot] = 0
+        self._gen_ub[slot] = 0
+        self.n_active = sum(1 for v in self._len_ub if v > 0)
+
+    def set_block_table(self, slot: int, blocks: Sequence[int]) -> None:
+        """The scheduler's block table of the request in `slot` (vLLM SequenceGroupMetadata.block_tables); it must
+        cover every position a cycle can touch (vLLM allocates them as num_lookahead_slots)."""
+        n = len(blocks)
+        if n > self.blocks_per_seq:
+            raise ValueError(f"{n} blocks > {self.blocks_per_seq} per sequence (max_model_len {self.max_model_len})")
+        if n and (min(blocks) < 0 or max(blocks) >= self.num_blocks):
+            raise ValueError("block id outside the KV cache")
+        row = torch.zeros(self.blocks_per_seq, dtype=torch.int32)
+        row[:n] = torch.tensor(list(blocks), dtype=torch.int32)
+        self.block_tables[slot].copy_(row.to(self.device))
+        self._capacity[slot] = n * self.block_size
+
+    def active_slots(self) -> List[int]:
+        return [b for b in range(self.B) if self._len_ub[b] > 0]
+
+    def sync_lens(self) -> None:
+        """Make the host-side length bounds exact (one small device read)."""
+        lens, gens = self.seq_lens.tolist(), self.gen_lens.tolist()
+        for b in range(self.B):
+            if self._len_ub[b] > 0:
+                self._len_ub[b], self._gen_ub[b] = int(lens[b]), int(gens[b])
+
+    def note_emitted(self, emitted: Sequence[int]) -> None:
+        """Exact bookkeeping from a cycle's output the caller has already read (the worker's one host read)."""
+        for b in range(self.B):
+            if self._len_before[b] > 0 and self._len_ub[b] > 0:
+                self._len_ub[b] = self._len_before[b] + int(emitted[b])
+                self._gen_ub[b] = self._gen_before[b] + int(emitted[b])
+
+    def _check_capacity(self, per_step: int, slots: Optional[Sequence[int]] = None) -> None:
+        cap_out = self.gen_tokens.shape[1]
+        for b in (range(self.B) if slots is None else slots):
+            L = self._len_ub[b]
+            if L <= 0:
+                continue
+            # the cycle writes KV at positions L-1 .. L-1+k and then knows up to L+k+1 tokens
+            if L - 1 + per_step > min(self._capacity[b], self.max_model_len):
+                raise ValueError(f"slot {b}: a cycle from length {L} (upper bound) needs positions up to {L - 1 + per_step - 1} "
+                                 f"but the sequence holds {min(self._capacity[b], self.max_model_len)} "
+                                 "(block table / max_model_len): finish the request or extend its block table")
+            if self._gen_ub[b] + per_step > cap_out:
+                raise ValueError(f"slot {b}: output buffer of {cap_out} tokens is full (max_new_tokens)")
 
     def _slots_for(self, b: int, pos: torch.Tensor) -> torch.Tensor:
         bt = self.block_tables[b].to(torch.int64)
@@ -148,53 +236,76 @@ class QSpecEngine:
     def _draft_body(self):
         m, k, B, bs = self.model, self.k, self.B, self.block_size
         # proposer: k draft steps, W4A4  (execute_model_req.w4a4 = True, :799)
-        ops.spec_prepare_draft(self.last_token, self.seq_lens, self.block_tables, bs, self.d_tokens, self.d_pos,
+        torch.mul(self.seq_lens, self.step_mask, out=self.eff_lens)
+        ops.spec_prepare_draft(self.last_token, self.eff_lens, self.block_tables, bs, self.d_tokens, self.d_pos,
                                self.d_slots, self.d_ctx)
         for i in range(k):
             hs = m.forward(self.d_tokens, self.d_pos, self.kv_caches, self.md_draft, self.scratch_draft, w4a4=True)
             logits = m.compute_logits(hs, self.scratch_draft)
             ops.softmax_argmax(logits, self.draft_probs_kbv[i], self.draft_ids_kb[i])
             if i != k - 1:  # _gpu_advance_step (draft_model_runner.py:78-135)
-                ops.advance_step_flashattn(B, B, bs, self.d_tokens, self.draft_ids_kb[i], self.d_pos, self.d_ctx,
-                                           self.d_slots, self.block_tables)
+                ops.spec_advance_draft(bs, self.d_tokens, self.draft_ids_kb[i], self.d_pos, self.d_ctx, self.d_slots,
+                                       self.block_tables)
 
     def _verify_body(self):
         m, k, B, bs = self.model, self.k, self.B, self.block_size
         # scorer: one W4A16 pass over [last, d_1..d_k] per sequence  (w4a4 = False, :812; mqa_scorer.py)
         draft_ids = self.draft_ids_kb.transpose(0, 1)            # [B,k] view
         draft_probs = self.draft_probs_kbv.transpose(0, 1)       # [B,k,V] view
-        ops.spec_prepare_verify(self.last_token, draft_ids, self.seq_lens, self.block_tables, bs, self.v_tokens,
+        ops.spec_prepare_verify(self.last_token, draft_ids, self.eff_lens, self.block_tables, bs, self.v_tokens,
                                 self.v_pos, self.v_slots, self.v_ctx)
         hs = m.forward(self.v_tokens, self.v_pos, self.kv_caches, self.md_verify, self.scratch_verify, w4a4=False)
         logits = m.compute_logits(hs, self.scratch_verify, shard_vocab=True)
-        if self.agreement_rho is not None:
-            ops.bench_force_agreement(logits, draft_ids, self.agreement_rho, self.sampler.rng_state)
+        if self._post_logits_hook is not None:
+            self._post_logits_hook(logits, draft_ids)
         ops.softmax_argmax(logits, self.target_probs.view(B * (k + 1), -1), self.target_tokens.view(-1))
         # _verify_tokens (:861-970): bonus = the target's own token at the last position
         self.sampler.forward(self.target_probs, self.target_tokens[:, k], draft_probs, draft_ids, out=self.out_tokens,
                              accepted=self.accepted, recovered=self.recovered, uniform=self.inject_uniform,
-                             exponential=self.inject_exponential)
+                             exponential=self.inject_exponential, active_lens=self.eff_lens)
         # _create_output_sampler_list bookkeeping (:972-1063)
         ops.spec_commit(self.out_tokens, self.seq_lens, self.last_token, self.gen_tokens, self.gen_lens)
 
     @torch.no_grad()
-    def step_no_spec(self):
+    def _set_participants(self, participants: Optional[Sequence[int]]) -> List[int]:
+        want = [1] * self.B if participants is None else [1 if b in participants else 0 for b in range(self.B)]
+        if want != self._mask_host:
+            self.step_mask.copy_(torch.tensor(want, dtype=torch.int32), non_blocking=False)
+            self._mask_host = want
+        return [b for b in range(self.B) if want[b] and self._len_ub[b] > 0]
+
+    def step_no_spec(self, participants: Optional[Sequence[int]] = None):
         """One NON-speculative decode step (spec_decode_worker.py:666-720 on a decode batch: the scorer alone, W4A16,
         one token per sequence): taken when speculation is disabled for a step (`num_lookahead_slots == 0`,
         `speculative_disable_by_batch_size`).  Eager: it is the rare path, the captured graph is the cycle's."""
         m, bs = self.model, self.block_size
-        ops.spec_prepare_draft(self.last_token, self.seq_lens, self.block_tables, bs, self.d_tokens, self.d_pos,
+        on = self._set_participants(participants)
+        self._check_capacity(1, on)
+        self._len_before, self._gen_before = list(self._len_ub), list(self._gen_ub)
+        torch.mul(self.seq_lens, self.step_mask, out=self.eff_lens)
+        ops.spec_prepare_draft(self.last_token, self.eff_lens, self.block_tables, bs, self.d_tokens, self.d_pos,
                                self.d_slots, self.d_ctx)                   # [last token] at position seq_len - 1
         hs = m.forward(self.d_tokens, self.d_pos, self.kv_caches, self.md_draft, self.scratch_draft, w4a4=False)
         logits = m.compute_logits(hs, self.scratch_draft)
         ops.softmax_argmax(logits, self.draft_probs_kbv[0], self.draft_ids_kb[0])
         self.out_tokens.fill_(-1)
-        self.out_tokens[:, 0] = self.draft_ids_kb[0]
+        self.out_tokens[:, 0] = torch.where(self.eff_lens > 0, self.draft_ids_kb[0], torch.full_like(self.draft_ids_kb[0], -1))
         ops.spec_commit(self.out_tokens, self.seq_lens, self.last_token, self.gen_tokens, self.gen_lens)
+        for b in on:
+            self._len_ub[b] += 1
+            self._gen_ub[b] += 1
 
     @torch.no_grad()
-    def step(self):
-        """Enqueue one cycle on the current stream (graph replay after the first call)."""
+    def step(self, participants: Optional[Sequence[int]] = None):
+        """Enqueue one cycle on the current stream (graph replay after the first call).  Raises ValueError -- before
+        anything is enqueued -- if a sequence could outgrow its block table, max_model_len or the output buffer.
+        participants: the slots taking part (default: every occupied slot); the others keep their state."""
+        on = self._set_participants(participants)
+        self._check_capacity(self.k + 1, on)
+        self._len_before, self._gen_before = list(self._len_ub), list(self._gen_ub)
+        for b in on:                       # until the caller reports / syncs the real numbers: the worst case
+            self._len_ub[b] += self.k + 1
+            self._gen_ub[b] += self.k + 1
         if not self.use_graph:
             self._cycle_body()
             return
@@ -264,8 +375,16 @@ class QSpecEngine:
         return metrics_from_counters(a, e, d, self.k)
 
     def max_cycles_left(self) -> int:
-        """Cycles that can still run before the longest sequence could overflow its blocks / output buffer."""
-        L = int(self.seq_lens.max().item())
-        room_ctx = (self.max_model_len - L - 1) // (self.k + 1)
-        room_out = (self.gen_tokens.shape[1] - int(self.gen_lens.max().item())) // (self.k + 1) - 1
-        return max(0, min(room_ctx, room_out))
+        """Cycles that can still run before step() would refuse (exact lengths: syncs)."""
+        self.sync_lens()
+        room = []
+        for b in self.active_slots():
+            cap = min(self._capacity[b], self.max_model_len)
+            room.append((cap - self._len_ub[b] + 1) // (self.k + 1))
+            room.append((self.gen_tokens.shape[1] - self._gen_ub[b]) // (self.k + 1))
+        return max(0, min(room)) if room else 0
+
+    def error_flag(self) -> int:
+        """Sticky device-side error word of the kernels that hand data between workgroups (0 = fine)."""
+        w = ops.xwg_error_word(self.device)
+        return 0 if w is None else int(w.item())

@@ -55,7 +55,8 @@ class AsyncMetricsCollector:
 
     def init_gpu_tensors(self, rank: int) -> None:
         self._rank = rank
-        self._copy_stream = torch.cuda.Stream()
+        # off CUDA-alike platforms the reference skips the collection altogether (vllm/spec_decode/metrics.py:96-98)
+        self._copy_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
 
     def maybe_collect_rejsample_metrics(self, k: int) -> Optional[SpecDecodeWorkerMetrics]:
         if self._in_flight_copy is not None:
@@ -66,7 +67,7 @@ class AsyncMetricsCollector:
         return None
 
     def _should_collect_rejsample_metrics(self, now: float) -> bool:
-        if self._rank != 0:
+        if self._rank != 0 or self._copy_stream is None:
             return False
         return now - self._last_metrics_collect_time >= self._rejsample_metrics_collect_interval_s
 

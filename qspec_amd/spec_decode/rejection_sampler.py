@@ -57,12 +57,23 @@ class RejectionSampler:
                 draft_probs: torch.Tensor, draft_token_ids: torch.Tensor,
                 seeded_seqs: Optional[Dict[int, torch.Generator]] = None, *, out: Optional[torch.Tensor] = None,
                 accepted: Optional[torch.Tensor] = None, recovered: Optional[torch.Tensor] = None,
-                uniform: Optional[torch.Tensor] = None, exponential: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """-> output_token_ids [B, k+1] (int64; -1 = no token)."""
-        if seeded_seqs:
-            raise NotImplementedError("per-request torch.Generator seeding is not on the QSpec path (greedy requests)")
+                uniform: Optional[torch.Tensor] = None, exponential: Optional[torch.Tensor] = None,
+                active_lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """-> output_token_ids [B, k+1] (int64; -1 = no token).
+        seeded_seqs {row: torch.Generator} (rejection_sampler.py:60-67,229-250,387-399): those rows draw their
+        uniforms and exponentials from their own generator, the others from the default stream -- done with torch on
+        the slow (eager) path and handed to the kernels as injected draws.
+        active_lens [B] int32 (engine): rows with active_lens <= 0 are empty batch slots -- no output, not counted."""
         B, k, V = draft_probs.shape
         dev = draft_probs.device
+        if seeded_seqs:
+            if uniform is not None or exponential is not None:
+                raise ValueError("seeded_seqs and injected draws are mutually exclusive")
+            uniform = torch.rand(B, k, device=dev, dtype=torch.float32)
+            exponential = torch.empty(B, k, V, device=dev, dtype=torch.float32).exponential_(1.0)
+            for row, gen in seeded_seqs.items():
+                uniform[row] = torch.rand(1, k, device=dev, dtype=torch.float32, generator=gen)
+                exponential[row] = torch.empty(k, V, device=dev, dtype=torch.float32).exponential_(1.0, generator=gen)
         if self._strict_mode:
             self._raise_if_incorrect_input(target_with_bonus_probs, draft_token_ids, bonus_token_ids, draft_probs)
         if B == 0:
@@ -73,7 +84,7 @@ class RejectionSampler:
         bonus = bonus_token_ids.squeeze(-1) if bonus_token_ids.dim() == 2 else bonus_token_ids  # a view, never a copy
         ops.rejection_sample(target_with_bonus_probs, bonus, draft_probs, draft_token_ids, out,
                              accepted, recovered, self.counters, uniform=uniform, exponential=exponential,
-                             rng_state=self.rng_state)
+                             rng_state=self.rng_state, active_lens=active_lens)
         return out
 
     __call__ = forward

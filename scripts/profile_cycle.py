@@ -27,14 +27,16 @@ def main():
     p.add_argument("--eager", action="store_true")
     a = p.parse_args()
     from qspec_amd.model import CONFIGS, QuarotLlamaForCausalLM
-    from qspec_amd.spec_decode import QSpecEngine
+    sys.path.insert(0, ROOT)
+    import bench
+    QSpecEngine = bench.make_bench_engine_class()
     dev = "cuda:0"
     cfg = CONFIGS[a.model]
     model = QuarotLlamaForCausalLM(cfg, dev).init_synthetic(0, 0.02)
     total = a.steps + 8
     eng = QSpecEngine(model, a.k, a.batch, max_model_len=a.ctx + total * (a.k + 1) + 32, block_size=16,
                       max_new_tokens=total * (a.k + 1) + 8, use_graph=not a.eager, seed=0)
-    eng.agreement_rho = a.agreement
+    eng.set_agreement(a.agreement)
     g = torch.Generator(device=dev).manual_seed(1)
     for kc, vc in eng.kv_caches:
         kc.copy_((torch.randn(kc.shape, generator=g, device=dev) * 0.5).half())
@@ -42,6 +44,8 @@ def main():
     eng.seq_lens.fill_(a.ctx + 1)
     eng.last_token.copy_(torch.randint(0, cfg.vocab_size, (a.batch,), generator=g, device=dev))
     eng.gen_lens.fill_(1)
+    eng._len_ub = [a.ctx + 1] * a.batch
+    eng._gen_ub = [1] * a.batch
     eng.n_active = a.batch
     for _ in range(3):
         eng.step()

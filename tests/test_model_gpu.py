@@ -544,3 +544,174 @@ def test_verify_layer_stagewise_teacher_forced(oracle, B, q_len):
         r = err / (1e-3 * np.maximum(1.0, np.maximum(np.abs(a), np.abs(b))))
         print(f"B={B} down_proj slices -> residual add in the norm: max err/1e-3 {r.max():.3f}")
         assert r.max() <= 1.0, r.max()
+
+
+# ------------------------------------------------------------------ batch membership, capacity, the worker on the GPU
+
+def _inject(eng, rng, B, k, V):
+    U = rng.random((B, k)).astype(np.float32)
+    E = rng.exponential(1.0, (B, k, V)).astype(np.float32)
+    eng.inject_uniform, eng.inject_exponential = torch.from_numpy(U).to(DEV), torch.from_numpy(E).to(DEV)
+
+
+def test_engine_slots_are_independent_and_empty_slots_are_inert(tiny):
+    """A sequence's cycle does not depend on what the other slots hold: with the same injected draws, slots {0, 2} of a
+    half-empty batch produce exactly the tokens they produce in a full batch; the empty slots write no KV, emit nothing
+    and are not counted (the reference only ever sees scheduled sequences: spec_decode_base_sampler.py:127-129)."""
+    from qspec_amd.spec_decode import QSpecEngine
+    k, B, V = 3, 4, tiny.config.vocab_size
+    prng = np.random.default_rng(21)
+    prompts = [prng.integers(0, V, n).tolist() for n in (17, 33, 64, 5)]
+    full = QSpecEngine(tiny, k, B, max_model_len=256, block_size=16, max_new_tokens=64, use_graph=False, seed=0)
+    half = QSpecEngine(tiny, k, B, max_model_len=256, block_size=16, max_new_tokens=64, use_graph=False, seed=0)
+    full.add_sequences(prompts)
+    half.add_sequence(0, prompts[0])
+    half.add_sequence(2, prompts[2])
+    assert half.active_slots() == [0, 2]
+    for cyc in range(3):
+        rng = np.random.default_rng(100 + cyc)
+        _inject(full, rng, B, k, V)
+        half.inject_uniform, half.inject_exponential = full.inject_uniform, full.inject_exponential
+        full.step(); half.step()
+        torch.cuda.synchronize()
+        of, oh = full.out_tokens.cpu(), half.out_tokens.cpu()
+        assert torch.equal(of[[0, 2]], oh[[0, 2]]), cyc
+        assert (oh[[1, 3]] == -1).all()
+    assert torch.equal(full.seq_lens[[0, 2]], half.seq_lens[[0, 2]]) and half.seq_lens[[1, 3]].tolist() == [0, 0]
+    for kc, vc in half.kv_caches:          # blocks of the empty slots: never written
+        for b in (1, 3):
+            rows = half.block_tables[b].long()
+            assert not kc[rows].any() and not vc[rows].any()
+    m = half.metrics()
+    assert m.draft_tokens == 3 * 2 * k                       # two sequences, three cycles
+    g_f, g_h = full.generated(), half.generated()
+    assert g_f[0] == g_h[0] and g_f[2] == g_h[2] and g_h[1] == [] and g_h[3] == []
+
+
+def test_engine_requests_join_and_leave_between_graph_replays(tiny):
+    """The captured cycle serves a changing batch: a request leaves (free_slot), another joins (add_sequence) and one
+    sits a step out (participants) between replays of the SAME graph; tokens equal the eager engine's."""
+    from qspec_amd.spec_decode import QSpecEngine
+    k, B, V = 3, 4, tiny.config.vocab_size
+    prng = np.random.default_rng(22)
+    prompts = [prng.integers(0, V, n).tolist() for n in (20, 9, 31, 12)]
+    streams = []
+    for use_graph in (False, True):
+        eng = QSpecEngine(tiny, k, B, max_model_len=256, block_size=16, max_new_tokens=64, use_graph=use_graph, seed=7)
+        eng.add_sequence(0, prompts[0]); eng.add_sequence(2, prompts[2])
+        hist = {}
+        eng.step(); eng.step()
+        graph0 = eng._graph
+        hist["req2"] = eng.generated()[2]
+        eng.free_slot(2)                                  # request in slot 2 finished
+        eng.add_sequence(3, prompts[3])                   # a new one joins in slot 3
+        eng.step()
+        eng.add_sequence(1, prompts[1])
+        len0 = int(eng.seq_lens[0])
+        eng.step(participants=[1, 3])                     # slot 0 sits this step out
+        torch.cuda.synchronize()
+        assert int(eng.seq_lens[0]) == len0
+        eng.step()
+        assert eng._graph is graph0                       # never re-captured
+        gen = eng.generated()
+        hist.update(req0=gen[0], req1=gen[1], req3=gen[3])
+        assert gen[2] == []
+        streams.append(hist)
+        eng.sync_lens()
+        assert eng._len_ub == eng.seq_lens.tolist()
+    assert streams[0] == streams[1]
+    assert all(len(v) >= 2 for v in streams[0].values())
+
+
+def test_engine_capacity_guard_refuses_cleanly(tiny):
+    """A cycle that could write beyond a sequence's block table / max_model_len is refused on the host before anything is
+    enqueued (ValueError), and the kernels themselves drop such a write (slot -1) instead of walking off the block-table
+    row into the neighbour's blocks."""
+    from qspec_amd import ops
+    from qspec_amd.spec_decode import QSpecEngine
+    k, B, V = 3, 2, tiny.config.vocab_size
+    prng = np.random.default_rng(23)
+    eng = QSpecEngine(tiny, k, B, max_model_len=48, block_size=16, max_new_tokens=64, use_graph=True, seed=1)
+    eng.add_sequence(0, prng.integers(0, V, 30).tolist())
+    eng.add_sequence(1, prng.integers(0, V, 8).tolist())
+    with pytest.raises(ValueError):
+        eng.add_sequence(1, [1, 2, 3])                    # occupied
+    n = 0
+    with pytest.raises(ValueError, match="slot 0"):
+        for _ in range(20):
+            eng.step()
+            eng.sync_lens()                               # exact lengths, as the worker has them
+            n += 1
+    assert 3 <= n <= 16                                   # 1 .. k+1 tokens per cycle from length 31 to the 48-token limit
+    torch.cuda.synchronize()
+    lens = eng.seq_lens.tolist()
+    assert lens[0] + k <= 48 + k and lens[0] <= 48        # nothing ran past the guard
+    snap = [(kc.clone(), vc.clone()) for kc, vc in eng.kv_caches]
+    with pytest.raises(ValueError):
+        eng.step()                                        # still refused, still nothing enqueued
+    torch.cuda.synchronize()
+    assert eng.seq_lens.tolist() == lens
+    for (kc, vc), (k0, v0) in zip(eng.kv_caches, snap):
+        assert torch.equal(kc, k0) and torch.equal(vc, v0)
+    # the in-kernel safety net: a length beyond the row's blocks gives slot -1, not the next row's block
+    bt = eng.block_tables
+    seq_lens = torch.tensor([bt.shape[1] * 16 + 5, 10], dtype=torch.int32, device=DEV)
+    last = torch.zeros(2, dtype=torch.int64, device=DEV)
+    tok = torch.zeros(2, dtype=torch.int64, device=DEV); pos = torch.zeros_like(tok); slots = torch.zeros_like(tok)
+    ctx = torch.zeros(2, dtype=torch.int32, device=DEV)
+    ops.spec_prepare_draft(last, seq_lens, bt, 16, tok, pos, slots, ctx)
+    torch.cuda.synchronize()
+    assert slots.tolist()[0] == -1 and slots.tolist()[1] == int(bt[1, 0]) * 16 + 9
+    eng.free_slot(0)                                      # the long request finishes: the other one carries on
+    eng.step()
+    torch.cuda.synchronize()
+    assert eng.out_tokens[0].tolist() == [-1] * (k + 1) and int(eng.out_tokens[1, 0]) != -1
+
+
+def test_worker_variable_batch_on_the_gpu(tiny):
+    """execute_model with a changing seq_group_metadata_list: prompts admitted while others decode, a finished request
+    leaves, order shuffled; every output row belongs to the request named beside it and the worker's view of the
+    lengths equals the GPU's after every call (spec_decode_worker.py:461-560,972-1063)."""
+    from qspec_amd.spec_decode import ExecuteModelRequest, SequenceGroupMetadata, create_spec_worker
+    from qspec_amd.spec_decode.worker import SequenceData, SpeculativeConfig
+    rng = np.random.default_rng(24)
+    w = create_spec_worker(model_config=tiny.config, model=tiny, speculative_config=SpeculativeConfig(3),
+                           max_num_seqs=4, max_model_len=256, block_size=16, device=DEV)
+    w.init_device()
+    nb, _ = w.determine_num_available_blocks()
+    w.initialize_cache(nb, 0)
+    eng = w.engine
+    toks = {}
+
+    def mk(rid, n):
+        return SequenceGroupMetadata(rid, True, {hash(rid) % 1000: SequenceData(rng.integers(0, 2048, n).tolist())})
+
+    def absorb(outs):
+        for o in outs:
+            for rid, t in zip(o.request_ids, o.sampled_token_ids.tolist()):
+                if t != -1:
+                    toks.setdefault(rid, []).append(t)
+        torch.cuda.synchronize()
+        assert eng._len_ub == eng.seq_lens.tolist()
+
+    a, b, c = mk("a", 12), mk("b", 30), mk("c", 7)
+    absorb(w.execute_model(ExecuteModelRequest([a, b], num_lookahead_slots=0)))
+    for s in (a, b):
+        s.is_prompt = False
+    absorb(w.execute_model(ExecuteModelRequest([b, a], num_lookahead_slots=3)))
+    absorb(w.execute_model(ExecuteModelRequest([c], num_lookahead_slots=0)))                  # joins while a, b wait
+    c.is_prompt = False
+    absorb(w.execute_model(ExecuteModelRequest([a, c, b], num_lookahead_slots=3)))
+    absorb(w.execute_model(ExecuteModelRequest([c, b], num_lookahead_slots=3, finished_requests_ids=["a"])))
+    assert "a" not in w._slots and sorted(w._slots) == ["b", "c"]
+    d = mk("d", 20)
+    absorb(w.execute_model(ExecuteModelRequest([d], num_lookahead_slots=0)))                  # takes a's slot
+    d.is_prompt = False
+    assert w._slots["d"] == 0
+    absorb(w.execute_model(ExecuteModelRequest([d, b, c], num_lookahead_slots=3)))
+    # the tokens reported per request are the tokens the engine holds for the request's slot
+    gen = eng.generated()
+    for rid in ("b", "c", "d"):
+        assert toks[rid] == gen[w._slots[rid]], rid
+    assert len(toks["a"]) >= 3
+    assert w.execute_model(None) == []

@@ -109,6 +109,7 @@ def run_rank(rank, world, comm, family, model_full, results):
         eng.step()
     gen = eng.generated()
     assert all(len(x) >= 4 for x in gen)
+    assert eng.error_flag() == 0, "a device-side hand-off timed out"
     results[rank] = ([t for x in gen for t in x[:4]], float(rh.max()), float((rh > 1).mean()), float(rl.max()))
 
 
@@ -147,6 +148,11 @@ def main():
         return
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    # Ranks as PROCESSES share one GPU here, so their kernels compete for its CUs: that voids the residency the
+    # kernels that spread a token over several workgroups rely on (at most one workgroup per CU of an otherwise idle
+    # GPU: all partners of a token resident while they wait for each other).  A TP deployment gives every rank its own
+    # GPU; for this host-staged rehearsal the one-workgroup-per-token forms are used (same bytes, tested elsewhere).
+    os.environ.setdefault("QSPEC_XWG_SPREAD", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     results = {}
     run_rank(rank, world, None, a.family, build_model(a.family), results)
