@@ -8,7 +8,7 @@ import json
 import sys
 
 
-def main(path, out_json=None):
+def main(path, out_json=None, model=None, batch=None, k=None):
     rows = list(csv.DictReader(open(path)))
     acc = collections.defaultdict(lambda: [0, 0.0])
     for r in rows:
@@ -23,9 +23,10 @@ def main(path, out_json=None):
         kib = v / n
         res[name] = {"launches": n, "fetch_size_kib_per_launch": round(kib, 1), "hbm_read_bytes_per_launch_corrected": int(kib * 1024 * 2)}
         print(f"{name[:70]:70s} {n:8d} {kib:22.1f} {kib * 1024 * 2 / 1e6:20.2f}")
-    if out_json:
-        json.dump(res, open(out_json, "w"), indent=1)
+    if out_json:   # keyed by workload: bench.py reports `traffic` only for the (model, batch, k) the pass was run on
+        json.dump({"workload": {"model": model, "batch": int(batch) if batch else None, "k": int(k) if k else None},
+                   "kernels": res}, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    main(*sys.argv[1:6])

@@ -715,3 +715,101 @@ def test_worker_variable_batch_on_the_gpu(tiny):
         assert toks[rid] == gen[w._slots[rid]], rid
     assert len(toks["a"]) >= 3
     assert w.execute_model(None) == []
+
+
+# ------------------------------------------------------------------ checkpoint on disk -> HIP path
+
+def test_reference_format_checkpoint_runs_on_the_hip_path(oracle, tmp_path):
+    """A checkpoint written the way the reference's exporter writes it -- per projection `int = clamp(round(W / scale),
+    -8, 7)`, `pack_i4`, `weight_scales` [N, 1], Sequential indices in the o_proj / down_proj names, separate q / k / v
+    and up / gate tensors, two safetensors shards (third-party/QuaRot/e2e/checkpoint_utils/quantize_llama_checkpoint.py:
+    87-119) -- is read by the loader (vllm/worker/model_runner.py:1132-1148 + fuse_qkv / fuse_gate_up,
+    quarot_llama.py:152-173,301-314) and runs both passes on the GPU; the oracle consumes the SAME raw tensors with the
+    fusion done here in numpy, so a wrong row order / rename / nibble convention in the loader cannot cancel out.
+    (No reference checkpoint is reachable offline: the files are made here; parity of the file format is unpinned.)"""
+    from safetensors.torch import save_file
+    from oracle.model import OracleModel
+    from qspec_amd import checkpoint, hadamard_tables
+    from qspec_amd.model import QuarotLlamaForCausalLM, Scratch
+    cfg = tiny_cfg()
+    H, I, L, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.vocab_size
+    q_sz, kv_sz = cfg.q_size, cfg.kv_size
+    rng = np.random.default_rng(33)
+    had28 = hadamard_tables.get_hadK(I)[0].to(torch.float16)
+    disk, raw = {}, []
+
+    def export(name, n, kdim):   # the exporter's arithmetic on an fp16 weight with a per-channel scale
+        w = (rng.standard_normal((n, kdim)) * 0.05).astype(np.float16)
+        scale = (np.abs(w.astype(np.float32)).max(axis=1, keepdims=True) / 7.0).astype(np.float16)
+        q = np.clip(np.round(w.astype(np.float32) / scale.astype(np.float32)), -8, 7).astype(np.int8)
+        packed = oracle.pack_i4(q)
+        disk[f"{name}.weight"] = torch.from_numpy(packed.view(np.uint8).copy())
+        disk[f"{name}.weight_scales"] = torch.from_numpy(scale.copy())
+        return packed, scale.reshape(-1)
+
+    for i in range(L):
+        p = f"model.layers.{i}"
+        qw, kw, vw = (export(f"{p}.self_attn.{n}_proj", sz, H) for n, sz in (("q", q_sz), ("k", kv_sz), ("v", kv_sz)))
+        ow = export(f"{p}.self_attn.o_proj.1", H, H)
+        uw, gw = export(f"{p}.mlp.up_proj", I, H), export(f"{p}.mlp.gate_proj", I, H)
+        dw = export(f"{p}.mlp.down_proj.2", H, I)
+        disk[f"{p}.mlp.down_proj.0.had_rem_dim"] = had28.clone()
+        raw.append(dict(qkv_w=np.concatenate([qw[0], kw[0], vw[0]]), qkv_s=np.concatenate([qw[1], kw[1], vw[1]]),
+                        o_w=ow[0], o_s=ow[1], gate_up_w=np.concatenate([uw[0], gw[0]]),
+                        gate_up_s=np.concatenate([uw[1], gw[1]]), down_w=dw[0], down_s=dw[1]))
+    embed = (rng.standard_normal((V, H)) * 0.02).astype(np.float16)
+    head = (rng.standard_normal((V, H)) * 0.05).astype(np.float16)
+    disk["model.embed_tokens.weight"], disk["lm_head.weight"] = torch.from_numpy(embed.copy()), torch.from_numpy(head.copy())
+    keys = sorted(disk)
+    save_file({k: disk[k] for k in keys[::2]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({k: disk[k] for k in keys[1::2]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+
+    model = QuarotLlamaForCausalLM(cfg, DEV)
+    checkpoint.load_qspec_checkpoint(model, str(tmp_path))
+    om = OracleModel(cfg, raw, embed, head, had28.numpy(), model.had_K, model.cos_sin_cache.cpu().numpy(), 16)
+    for w4a4, q_len in ((True, 1), (False, 3)):
+        irng = np.random.default_rng(5)
+        inp = make_inputs(model, irng, [40, 130, 9], q_len)
+        kv_np = [(k.copy(), v.copy()) for k, v in inp["kv_np"]]
+        ref = om.forward(inp["ids"], inp["pos"], kv_np, inp["slots"], inp["bt"], inp["ctx"], inp["q_start"], w4a4)
+        s = Scratch(cfg, inp["T"], 3, q_len, inp["n_splits"], DEV)
+        out = model.forward(inp["ids_t"], inp["pos_t"], inp["kv_t"], inp["md"], s, w4a4=w4a4)
+        torch.cuda.synchronize()
+        diff = np.abs(out.cpu().numpy().astype(np.float64) - ref.astype(np.float64))
+        if w4a4:   # first layer up to attention: bit-exact KV (norm, int4 GEMM over the loaded q/k/v rows, RoPE)
+            assert np.array_equal(inp["kv_t"][0][0].cpu().numpy().view(np.uint16), kv_np[0][0].view(np.uint16))
+            assert np.array_equal(inp["kv_t"][0][1].cpu().numpy().view(np.uint16), kv_np[0][1].view(np.uint16))
+            assert np.median(diff) < 1e-3 and np.quantile(diff, 0.99) < 0.1, (np.median(diff), np.quantile(diff, 0.99))
+        else:
+            assert diff.max() < 2e-2 and np.median(diff) < 1e-3, (np.median(diff), diff.max())
+        logits = model.compute_logits(out, s).cpu().numpy().astype(np.float64)
+        assert np.quantile(np.abs(logits - om.logits(ref).astype(np.float64)), 0.99) < (0.1 if w4a4 else 3e-2)
+
+
+def test_structured_weights_draft_tracks_target():
+    """Acceptance earned, not injected: a model whose next-token distribution is well conditioned -- tied lm_head =
+    embedding (each token predicts itself with a wide margin), decoder layers acting as a ~10 % perturbation of the
+    residual stream -- makes the W4A4 draft and the W4A16 target agree, and the rejection sampler accepts nearly
+    every proposal (the reference reports 0.961 on its trained checkpoint, figs/image-1.png).  With the random weights
+    of the benchmarks the same code accepts ~1-4 %: that is a property of random weights, not of the draft path."""
+    from qspec_amd.model import QuarotLlamaForCausalLM
+    from qspec_amd.spec_decode import QSpecEngine
+    cfg = tiny_cfg()
+    model = QuarotLlamaForCausalLM(cfg, DEV).init_synthetic(seed=11, lm_head_std=0.02)
+    with torch.no_grad():
+        for layer in model.layers:
+            for lin in layer.linears():
+                lin.weight_scales.mul_(2e-3)
+        model.lm_head.copy_(model.embed_tokens)
+    k, B, V = 3, 4, cfg.vocab_size
+    rng = np.random.default_rng(12)
+    eng = QSpecEngine(model, k, B, max_model_len=256, block_size=16, max_new_tokens=128, use_graph=True, seed=3)
+    eng.add_sequences([rng.integers(0, V, n).tolist() for n in (9, 20, 33, 14)])
+    for _ in range(10):
+        eng.step()
+    m = eng.metrics()
+    assert m.draft_tokens == 10 * B * k
+    assert m.draft_acceptance_rate > 0.9 and m.system_efficiency > 0.85, m
+    # the draft's distribution is close to the target's where it matters: total variation at the verified positions
+    tv = 0.5 * (eng.draft_probs_kbv.transpose(0, 1) - eng.target_probs[:, :k]).abs().sum(-1)
+    assert float(tv.max()) < 0.1, tv
