@@ -286,6 +286,17 @@ size_t qspec_sampler_workspace_bytes(int rows);   /* rows = tokens (softmax) or 
 int qspec_softmax_argmax(const qspec_half* logits, float* probs, int64_t* token, int tokens, int vocab,
                          void* workspace, void* stream);
 
+/* lm_head + Sampler front end in one call (logits_processor.py:92-97 + sampler.py:270-287): the lm_head
+ * launch leaves, next to the fp16 logits, every workgroup's row maxima, so the softmax needs no pass of its own to
+ * find them and probs is written ONCE: two more launches read the (cache-resident) fp16 logits twice -- the
+ * denominator in fp64, then p = qexp(l - max) / sum -- instead of writing and re-reading an fp32 array.  Same bits as
+ * qspec_linear_f16 + qspec_softmax_argmax.  tokens <= 16 (_supported says); logits [tokens, vocab] is scratch the
+ * caller provides; workspace: qspec_lm_head_sampler_workspace_bytes(tokens). */
+size_t qspec_lm_head_sampler_workspace_bytes(int rows);
+int qspec_lm_head_softmax_argmax_supported(int tokens, int vocab, int K);
+int qspec_lm_head_softmax_argmax(const qspec_half* hidden, const qspec_half* lm_head, qspec_half* logits, float* probs,
+                                 int64_t* token, int tokens, int vocab, int K, void* workspace, void* stream);
+
 /* RejectionSampler.forward(target_with_bonus_probs, bonus_token_ids, draft_probs, draft_token_ids)
  *   vllm/model_executor/layers/rejection_sampler.py:60-154 + spec_decode_base_sampler.py:69-131.
  *   uniform [B,k] / exponential [B,k,V] fp32: injected random draws (tests); NULL -> Philox(seed, offset).

@@ -68,6 +68,9 @@ SIGNATURES = {
     "qspec_embedding": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_sampler_workspace_bytes": (_sz, [_i]),
     "qspec_softmax_argmax": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "qspec_lm_head_sampler_workspace_bytes": (_sz, [_i]),
+    "qspec_lm_head_softmax_argmax_supported": (_i, [_i, _i, _i]),
+    "qspec_lm_head_softmax_argmax": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "qspec_rejection_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _i, _i64, _i64, _i64, _i64,
                                     _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qspec_advance_step_flashattn": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -218,7 +218,7 @@ int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, 
     NONNULL(op, x); NONNULL(op, w); NONNULL(op, out);
     if (K % 32 || K <= 0) return fail("%s: need K %% 32 == 0 (K=%d)", op, K);
     if (use_stream() && qspec::gemm_f16_stream_supported(M, N, K))
-        return finish(op, qspec::gemm_f16_stream(CH(x), CH(w), H(out), M, N, K, ST));
+        return finish(op, qspec::gemm_f16_stream(CH(x), CH(w), H(out), M, N, K, nullptr, ST));
     if (M > 16 && tiled_min_m() < (1 << 30) && qspec::gemm_f16_tiled_supported(M, N, K))   // prefill / large-batch logits
         return finish(op, qspec::gemm_f16_tiled(CH(x), CH(w), H(out), M, N, K, ST));
     return finish(op, qspec::gemm_f16(CH(x), CH(w), H(out), M, N, K, ST));
@@ -297,6 +297,26 @@ int qspec_softmax_argmax(const qspec_half* logits, float* probs, int64_t* token,
     if (tokens == 0) return 0;
     NONNULL(op, logits); NONNULL(op, probs); NONNULL(op, token); NONNULL(op, workspace);
     return finish(op, qspec::softmax_argmax(CH(logits), probs, token, tokens, vocab, workspace, ST));
+}
+size_t qspec_lm_head_sampler_workspace_bytes(int rows) { return qspec::head_softmax_ws_bytes(rows); }
+int qspec_lm_head_softmax_argmax(const qspec_half* hidden, const qspec_half* lm_head, qspec_half* logits, float* probs,
+                                 int64_t* token, int tokens, int vocab, int K, void* workspace, void* stream) {
+    const char* op = "qspec_lm_head_softmax_argmax";
+    if (tokens == 0) return 0;
+    NONNULL(op, hidden); NONNULL(op, lm_head); NONNULL(op, logits); NONNULL(op, probs); NONNULL(op, token);
+    NONNULL(op, workspace);
+    if (!(use_stream() && qspec::gemm_f16_stream_supported(tokens, vocab, K)))
+        return fail("%s: (tokens=%d vocab=%d K=%d) is not a streaming lm_head shape (tokens <= 16, vocab %% 16 == 0); "
+                    "use qspec_linear_f16 + qspec_softmax_argmax", op, tokens, vocab, K);
+    int rc = qspec::gemm_f16_stream(CH(hidden), CH(lm_head), H(logits), tokens, vocab, K,
+                                    qspec::head_softmax_part_max(workspace, tokens), ST);
+    if (rc == 0)
+        rc = qspec::head_softmax_argmax(CH(logits), probs, token, tokens, vocab, qspec::gemm_f16_stream_grid(vocab),
+                                        workspace, ST);
+    return finish(op, rc);
+}
+int qspec_lm_head_softmax_argmax_supported(int tokens, int vocab, int K) {
+    return use_stream() && qspec::gemm_f16_stream_supported(tokens, vocab, K) ? 1 : 0;
 }
 int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* bonus_token_ids,
                            const float* draft_probs, const int64_t* draft_token_ids, const float* uniform,

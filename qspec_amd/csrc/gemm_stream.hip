@@ -831,10 +831,17 @@ int prefetch_l2(const void* p, size_t bytes, int workgroups, hipStream_t st) {
 // out[m,n] = h( sum_k f(x[m,k]) f(w[n,k]) ), fp32 accumulate  (nn.Linear lm_head, logits_processor.py:92-97).
 // K = 32 * NW * UB: a wave keeps UB loads (UB KiB) of the 1 GB vocabulary matrix in flight and its activation
 // fragments in registers; a workgroup walks over its tiles with the refill-behind-use pipeline of the kernels above.
+// part_max (may be NULL; the sampler front end, sampler.hip): every workgroup also leaves, per token row, the largest
+// fp16 logit among ITS tiles and the first column holding it -- part_max[m * gridDim.x + blockIdx.x] = {value, column}
+// -- so that the softmax that follows does not have to read the logits once more just to find the row maximum.
+struct HeadMax {
+    float v;
+    int i;
+};
 template <int NW, int UB>
 __global__ __launch_bounds__(NW * 64) void gemm_f16_stream_kernel(const f16* __restrict__ x, const f16* __restrict__ wt,
                                                                   f16* __restrict__ out, int M, int N, int K,
-                                                                  int ntiles) {
+                                                                  int ntiles, HeadMax* __restrict__ part_max) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* red = reinterpret_cast<float*>(smem);   // [2][NW][256]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -864,6 +871,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_f16_stream_kernel(const f16* __r
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float best_v = -__builtin_inff();
+    int best_i = 0x7fffffff;
     auto finish = [&](int t, int par) {
         float* rb = red + par * NW * 256;
 #pragma unroll
@@ -874,7 +883,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_f16_stream_kernel(const f16* __r
             float sum = rb[ridx];
 #pragma unroll
             for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[w2 * 256 + ridx];
-            out[(size_t)m * N + t * 16 + c] = f2h(sum);
+            const f16 hv = f2h(sum);
+            out[(size_t)m * N + t * 16 + c] = hv;
+            const float fv = h2f(hv);
+            if (fv > best_v) {          // tiles come in increasing column order: a tie keeps the first column
+                best_v = fv;
+                best_i = t * 16 + c;
+            }
         }
     };
     for (int q = 0; q < my_tiles - 1; q++) {
@@ -894,12 +909,34 @@ __global__ __launch_bounds__(NW * 64) void gemm_f16_stream_kernel(const f16* __r
 #pragma unroll
     for (int u = 0; u < UB; u++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u], w[u], acc, 0, 0, 0);
     finish(tile, par);
+    if (part_max) {   // the 16 columns of a row sit in 16 consecutive lanes: larger value, then smaller column, wins
+#pragma unroll
+        for (int mk = 1; mk < 16; mk <<= 1) {
+            const float ov = __shfl_xor(best_v, mk, 64);
+            const int oi = __shfl_xor(best_i, mk, 64);
+            if (ov > best_v || (ov == best_v && oi < best_i)) {
+                best_v = ov;
+                best_i = oi;
+            }
+        }
+        if (ethread && c == 0) part_max[(size_t)m * gridDim.x + blockIdx.x] = HeadMax{best_v, best_i};
+    }
 }
 
 bool gemm_f16_stream_supported(int M, int N, int K) {
     return M >= 1 && M <= 16 && N % 16 == 0 && (K == 1024 || K == 2048 || K == 4096 || K == 5120);
 }
-int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st) {
+int gemm_f16_stream_grid(int N) {
+    const int ntiles = N / 16;
+    int grid = ntiles;
+    if (grid > 256) {
+        const int per = (ntiles + 255) / 256;
+        grid = (ntiles + per - 1) / per;
+    }
+    return grid;
+}
+// part_max != NULL: the grid is gemm_f16_stream_grid(N) (<= 256) and part_max holds [M][grid] {float, int} pairs.
+int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, void* part_max, hipStream_t st) {
     if (!gemm_f16_stream_supported(M, N, K)) return -1;
     const int ntiles = N / 16;
     static int cap = 0;
@@ -909,11 +946,14 @@ int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, h
         if (cap < 1) cap = 256;
     }
     int grid = ntiles;
-    if (grid > cap) {
+    if (part_max) {
+        grid = gemm_f16_stream_grid(N);
+    } else if (grid > cap) {
         const int per = (ntiles + cap - 1) / cap;
         grid = (ntiles + per - 1) / per;
     }
-#define QS_F16S(NWV, UBV) hipLaunchKernelGGL((gemm_f16_stream_kernel<NWV, UBV>), dim3(grid), dim3(NWV * 64), (size_t)2 * NWV * 1024, st, x, w, out, M, N, K, ntiles)
+    HeadMax* pm = reinterpret_cast<HeadMax*>(part_max);
+#define QS_F16S(NWV, UBV) hipLaunchKernelGGL((gemm_f16_stream_kernel<NWV, UBV>), dim3(grid), dim3(NWV * 64), (size_t)2 * NWV * 1024, st, x, w, out, M, N, K, ntiles, pm)
     if (K == 4096) QS_F16S(8, 16);
     else if (K == 2048) QS_F16S(8, 8);
     else if (K == 1024) QS_F16S(4, 8);

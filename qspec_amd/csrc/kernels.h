@@ -102,7 +102,8 @@ bool gemm_f16_tiled_supported(int M, int N, int K);
 int gemm_f16_tiled(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st);
 
 bool gemm_f16_stream_supported(int M, int N, int K);
-int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, hipStream_t st);
+int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, void* part_max, hipStream_t st);
+int gemm_f16_stream_grid(int N);
 int prefetch_l2(const void* p, size_t bytes, int workgroups, hipStream_t st);
 
 // attention.hip
@@ -125,6 +126,10 @@ size_t paged_attention_ws_ml_offset(int Tmax, int nq, int d, int n_splits);
 int embedding(const int64_t* ids, const f16* table, f16* out, int T, int H, int V, hipStream_t st);
 size_t sampler_ws_bytes(int rows);
 int softmax_argmax(const f16* logits, float* probs, int64_t* token, int T, int V, void* ws, hipStream_t st);
+// sampler front end behind an lm_head launch that left per-workgroup row maxima (gemm_f16_stream, part_max)
+size_t head_softmax_ws_bytes(int rows);
+void* head_softmax_part_max(void* ws, int rows);
+int head_softmax_argmax(const f16* logits, float* probs, int64_t* token, int T, int V, int nparts, void* ws, hipStream_t st);
 int rejection_sample(const float* target_probs, const float* draft_probs, const int64_t* draft_ids,
                      const int64_t* bonus_ids, const float* uniform, const float* exponential, uint64_t seed,
                      uint64_t offset, uint64_t* rng_state, int B, int k, int V, int64_t dp_sb, int64_t dp_sk,

@@ -111,40 +111,49 @@ __device__ __forceinline__ ArgMax sm_row_max(const SmPartA* part_a, int t) {
     }
     return am;
 }
-__global__ __launch_bounds__(256) void softmax_exp_kernel(const f16* __restrict__ logits, const SmPartA* part_a,
-                                                          float* __restrict__ probs, double* __restrict__ part_s,
-                                                          int V) {
+// np <= 256 partial maxima per row (QS_SM_CHUNKS from softmax_max_kernel, or one per workgroup of the lm_head
+// launch): one load per thread, then a block reduction (call from all 256 threads of the workgroup)
+__device__ __forceinline__ ArgMax sm_row_max_n(const SmPartA* part_a, int t, int np, ArgMax* red_a) {
+    ArgMax am{-__builtin_inff(), 0x7fffffff};
+    if ((int)threadIdx.x < np) {
+        const SmPartA pa = part_a[(size_t)t * np + threadIdx.x];
+        am = ArgMax{pa.v, pa.i};
+    }
+    return block_argmax(am, red_a);
+}
+// pass 2: the chunk's share of the denominator, sum of qexpf(l - M) in fp64.  Nothing is written to probs here: the
+// fp16 logits (2 B per element, cache resident) are cheaper to read twice than an fp32 e-array is to write and re-read
+// (the reference's softmax + log_softmax make two passes over T x V x 4 B, sampler.py:270-287).
+__global__ __launch_bounds__(256) void softmax_sum_kernel(const f16* __restrict__ logits, const SmPartA* part_a, int np,
+                                                          double* __restrict__ part_s, int V) {
     __shared__ double red_d[4];
+    __shared__ ArgMax red_a[4];
     const int c = blockIdx.x, t = blockIdx.y;
     int lo, hi;
     sm_chunk_range(V, c, lo, hi);
-    const float mx = sm_row_max(part_a, t).v;
+    const float mx = sm_row_max_n(part_a, t, np, red_a).v;
     const f16* l = logits + (size_t)t * V;
-    float* p = probs + (size_t)t * V;
     double den = 0.0;
-    for (int v = lo + threadIdx.x; v < hi; v += 256) {
-        float e = qexpf(h2f(l[v]) - mx);
-        p[v] = e;
-        den += (double)e;
-    }
+    for (int v = lo + threadIdx.x; v < hi; v += 256) den += (double)qexpf(h2f(l[v]) - mx);
     den = block_sum_f64(den, red_d);
     if (threadIdx.x == 0) part_s[t * QS_SM_CHUNKS + c] = den;
 }
-__global__ __launch_bounds__(256) void softmax_norm_kernel(const SmPartA* part_a, const double* part_s,
-                                                           float* __restrict__ probs, int64_t* __restrict__ token,
-                                                           int64_t token_stride, int V) {
+// pass 3: p = qexpf(l - M) / float(total) written ONCE; chunk 0 writes the token
+__global__ __launch_bounds__(256) void softmax_write_kernel(const f16* __restrict__ logits, const SmPartA* part_a,
+                                                            int np, const double* part_s, float* __restrict__ probs,
+                                                            int64_t* __restrict__ token, int64_t token_stride, int V) {
+    __shared__ ArgMax red_a[4];
     const int c = blockIdx.x, t = blockIdx.y;
     int lo, hi;
     sm_chunk_range(V, c, lo, hi);
     double den = 0.0;
     for (int cc = 0; cc < QS_SM_CHUNKS; cc++) den += part_s[t * QS_SM_CHUNKS + cc];
     const float inv = (float)den;
+    const ArgMax am = sm_row_max_n(part_a, t, np, red_a);
+    const f16* l = logits + (size_t)t * V;
     float* p = probs + (size_t)t * V;
-    for (int v = lo + threadIdx.x; v < hi; v += 256) p[v] = p[v] / inv;
-    if (c == 0 && threadIdx.x == 0) {
-        ArgMax am = sm_row_max(part_a, t);
-        token[t * token_stride] = am.i == 0x7fffffff ? 0 : am.i;
-    }
+    for (int v = lo + threadIdx.x; v < hi; v += 256) p[v] = qexpf(h2f(l[v]) - am.v) / inv;
+    if (c == 0 && threadIdx.x == 0) token[t * token_stride] = am.i == 0x7fffffff ? 0 : am.i;
 }
 size_t sampler_ws_bytes(int rows) { return (size_t)rows * QS_SM_CHUNKS * 16; }
 int softmax_argmax(const f16* logits, float* probs, int64_t* token, int T, int V, void* ws, hipStream_t st) {
@@ -152,9 +161,24 @@ int softmax_argmax(const f16* logits, float* probs, int64_t* token, int T, int V
     SmPartA* part_a = reinterpret_cast<SmPartA*>(ws);
     double* part_s = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + (size_t)T * QS_SM_CHUNKS * 8);
     hipLaunchKernelGGL(softmax_max_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, logits, part_a, V);
-    hipLaunchKernelGGL(softmax_exp_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, logits, part_a, probs, part_s, V);
-    hipLaunchKernelGGL(softmax_norm_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, part_a, part_s, probs, token,
-                       (int64_t)1, V);
+    hipLaunchKernelGGL(softmax_sum_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, logits, part_a, QS_SM_CHUNKS, part_s, V);
+    hipLaunchKernelGGL(softmax_write_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, logits, part_a, QS_SM_CHUNKS,
+                       part_s, probs, token, (int64_t)1, V);
+    return 0;
+}
+// Behind an lm_head launch that left nparts <= 256 partial maxima per row: two launches, the logits are read twice
+// (fp16) and probs written once.  ws: [rows][256] SmPartA, then [rows][QS_SM_CHUNKS] double.
+size_t head_softmax_ws_bytes(int rows) { return (size_t)rows * (256 * 8 + QS_SM_CHUNKS * 8); }
+void* head_softmax_part_max(void* ws, int rows) { return ws; }
+int head_softmax_argmax(const f16* logits, float* probs, int64_t* token, int T, int V, int nparts, void* ws,
+                        hipStream_t st) {
+    if (T == 0) return 0;
+    if (nparts < 1 || nparts > 256) return -1;
+    SmPartA* part_a = reinterpret_cast<SmPartA*>(ws);
+    double* part_s = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + (size_t)T * 256 * 8);
+    hipLaunchKernelGGL(softmax_sum_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, logits, part_a, nparts, part_s, V);
+    hipLaunchKernelGGL(softmax_write_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, logits, part_a, nparts, part_s,
+                       probs, token, (int64_t)1, V);
     return 0;
 }
 

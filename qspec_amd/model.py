@@ -337,6 +337,21 @@ class QuarotLlamaForCausalLM:
         ops.linear_f16(hidden_states, self.lm_head, logits)
         return logits
 
+    def sample_greedy(self, hidden_states, scratch: Scratch, probs, token, shard_vocab: bool = False, logits_hook=None):
+        """compute_logits + Sampler.forward (greedy, modify_greedy_probs = False: sampler.py:216-316): probs [T, V] fp32,
+        token [T].  At decode-sized T on one GPU the lm_head launch and the softmax are fused (ops.lm_head_softmax_argmax);
+        a vocab-parallel lm_head, a large T or a logits hook (bench only) take the two-step path.  Same bits."""
+        T = hidden_states.shape[0]
+        V, K = self.lm_head.shape
+        sharded = shard_vocab and self.tp is not None and self.tp.world > 1
+        if not sharded and logits_hook is None and ops.lm_head_softmax_argmax_supported(T, V, K):
+            ops.lm_head_softmax_argmax(hidden_states, self.lm_head, scratch.logits[:T], probs, token)
+            return
+        logits = self.compute_logits(hidden_states, scratch, shard_vocab=shard_vocab)
+        if logits_hook is not None:
+            logits_hook(logits)
+        ops.softmax_argmax(logits, probs, token)
+
     # ------------------------------------------------------------------ module-wise path (reference op order)
     def forward_modulewise(self, input_ids, positions, kv_caches, attn_metadata: AttentionMetadata, w4a4=False):
         cfg, md = self.config, attn_metadata

@@ -480,6 +480,27 @@ def softmax_argmax(logits, probs, token, workspace=None):
           T, V, ws.data_ptr(), _stream())
 
 
+_head_ws = {}
+
+
+def lm_head_softmax_argmax_supported(T: int, V: int, K: int) -> bool:
+    return bool(_lib.load().qspec_lm_head_softmax_argmax_supported(T, V, K))
+
+
+def lm_head_softmax_argmax(hidden, lm_head, logits, probs, token):
+    """logits = hidden @ lm_head^T (fp16, scratch), probs = softmax(float(logits)), token = argmax -- the lm_head launch
+    hands its row maxima to the softmax, probs is written once (logits_processor.py:92-97 + sampler.py:270-287)."""
+    T, K = hidden.shape
+    V = lm_head.shape[0]
+    key = (str(hidden.device), T)
+    if key not in _head_ws:
+        _head_ws[key] = torch.empty(int(_lib.load().qspec_lm_head_sampler_workspace_bytes(T)), dtype=torch.uint8,
+                                    device=hidden.device)
+    _call("qspec_lm_head_softmax_argmax", _chk(hidden, "hidden", _F16), _chk(lm_head, "lm_head", _F16),
+          _chk(logits, "logits", _F16), _chk(probs, "probs", _F32), _chk(token, "token", _I64), T, V, K,
+          _head_ws[key].data_ptr(), _stream())
+
+
 def rejection_sample(target_with_bonus_probs, bonus_token_ids, draft_probs, draft_token_ids, out_tokens, accepted,
                      recovered, counters=None, uniform=None, exponential=None, seed: int = 0, offset: int = 0,
                      rng_state=None, workspace=None, active_lens=None):

@@ -241,8 +241,7 @@ class QSpecEngine:
                                self.d_slots, self.d_ctx)
         for i in range(k):
             hs = m.forward(self.d_tokens, self.d_pos, self.kv_caches, self.md_draft, self.scratch_draft, w4a4=True)
-            logits = m.compute_logits(hs, self.scratch_draft)
-            ops.softmax_argmax(logits, self.draft_probs_kbv[i], self.draft_ids_kb[i])
+            m.sample_greedy(hs, self.scratch_draft, self.draft_probs_kbv[i], self.draft_ids_kb[i])
             if i != k - 1:  # _gpu_advance_step (draft_model_runner.py:78-135)
                 ops.spec_advance_draft(bs, self.d_tokens, self.draft_ids_kb[i], self.d_pos, self.d_ctx, self.d_slots,
                                        self.block_tables)
@@ -255,10 +254,9 @@ class QSpecEngine:
         ops.spec_prepare_verify(self.last_token, draft_ids, self.eff_lens, self.block_tables, bs, self.v_tokens,
                                 self.v_pos, self.v_slots, self.v_ctx)
         hs = m.forward(self.v_tokens, self.v_pos, self.kv_caches, self.md_verify, self.scratch_verify, w4a4=False)
-        logits = m.compute_logits(hs, self.scratch_verify, shard_vocab=True)
-        if self._post_logits_hook is not None:
-            self._post_logits_hook(logits, draft_ids)
-        ops.softmax_argmax(logits, self.target_probs.view(B * (k + 1), -1), self.target_tokens.view(-1))
+        hook = None if self._post_logits_hook is None else (lambda logits: self._post_logits_hook(logits, draft_ids))
+        m.sample_greedy(hs, self.scratch_verify, self.target_probs.view(B * (k + 1), -1), self.target_tokens.view(-1),
+                        shard_vocab=True, logits_hook=hook)
         # _verify_tokens (:861-970): bonus = the target's own token at the last position
         self.sampler.forward(self.target_probs, self.target_tokens[:, k], draft_probs, draft_ids, out=self.out_tokens,
                              accepted=self.accepted, recovered=self.recovered, uniform=self.inject_uniform,

@@ -699,6 +699,38 @@ def test_softmax_argmax(ops, oracle, T, V):
     assert np.array_equal(host(probs).view(np.uint32), p0.view(np.uint32))
 
 
+@pytest.mark.parametrize("T,V,K", [(4, 128256, 4096), (16, 128256, 4096), (3, 32000, 2048), (16, 2048, 1024)])
+def test_lm_head_softmax_argmax_fused_front_end(ops, oracle, T, V, K):
+    """lm_head launch (row maxima from its epilogue) + denominator + write-once probabilities == the two-step path
+    (qspec_linear_f16 + qspec_softmax_argmax) bit for bit, and == the oracle's softmax of the GPU's own logits
+    (logits_processor.py:92-97 + sampler.py:270-287).  Ties: the first column wins, also across workgroups."""
+    rng = np.random.default_rng(V + T)
+    x = dev((rng.standard_normal((T, K)) * 1.0).astype(np.float16))
+    w_np = (rng.standard_normal((V, K)) * 0.02).astype(np.float16)
+    w_np[V // 2 + 5] = w_np[7]          # two identical vocabulary rows, far apart: an exact tie of their logits
+    w_np[V - 3] = w_np[7]
+    w = dev(w_np)
+    logits_a = torch.empty(T, V, dtype=torch.float16, device=DEV)
+    probs_a = torch.empty(T, V, dtype=torch.float32, device=DEV); tok_a = torch.empty(T, dtype=torch.int64, device=DEV)
+    ops.linear_f16(x, w, logits_a)
+    ops.softmax_argmax(logits_a, probs_a, tok_a)
+    logits_b = torch.empty_like(logits_a); probs_b = torch.full_like(probs_a, float("nan")); tok_b = torch.empty_like(tok_a)
+    assert ops.lm_head_softmax_argmax_supported(T, V, K)
+    ops.lm_head_softmax_argmax(x, w, logits_b, probs_b, tok_b)
+    torch.cuda.synchronize()
+    assert torch.equal(logits_a.view(torch.int16), logits_b.view(torch.int16))
+    assert torch.equal(probs_a.view(torch.int32), probs_b.view(torch.int32)) and torch.equal(tok_a, tok_b)
+    p0, t0 = oracle.softmax_argmax(host(logits_b))
+    assert np.array_equal(host(tok_b), t0)
+    assert np.array_equal(host(probs_b).view(np.uint32), p0.view(np.uint32))
+    # force the tie to be the row maximum: boost the shared direction
+    x2 = dev((w_np[7].astype(np.float32)[None, :] * 50.0).repeat(T, 0).astype(np.float16))
+    ops.lm_head_softmax_argmax(x2, w, logits_b, probs_b, tok_b)
+    torch.cuda.synchronize()
+    assert host(tok_b).tolist() == [7] * T
+    assert np.array_equal(host(tok_b), oracle.softmax_argmax(host(logits_b))[1])
+
+
 def test_rejection_sampler_golden_bit_exact(ops, golden_dir):
     """Outputs of the REFERENCE sampler run on CPU with recorded draws: masks, recovered ids, layout, counters."""
     g = np.load(os.path.join(golden_dir, "rejection.npz"))
