@@ -25,18 +25,22 @@ def main():
     p.add_argument("--ctx", type=int, default=512)
     p.add_argument("--agreement", type=float, default=0.96)
     p.add_argument("--eager", action="store_true")
+    p.add_argument("--plain-engine", action="store_true", help="the product engine, no synthetic-agreement hook (no bench library loaded)")
     a = p.parse_args()
     from qspec_amd.model import CONFIGS, QuarotLlamaForCausalLM
-    sys.path.insert(0, ROOT)
-    import bench
-    QSpecEngine = bench.make_bench_engine_class()
+    if a.plain_engine:
+        from qspec_amd.spec_decode import QSpecEngine
+    else:
+        import bench
+        QSpecEngine = bench.make_bench_engine_class()
     dev = "cuda:0"
     cfg = CONFIGS[a.model]
     model = QuarotLlamaForCausalLM(cfg, dev).init_synthetic(0, 0.02)
     total = a.steps + 8
     eng = QSpecEngine(model, a.k, a.batch, max_model_len=a.ctx + total * (a.k + 1) + 32, block_size=16,
                       max_new_tokens=total * (a.k + 1) + 8, use_graph=not a.eager, seed=0)
-    eng.set_agreement(a.agreement)
+    if not a.plain_engine:
+        eng.set_agreement(a.agreement)
     g = torch.Generator(device=dev).manual_seed(1)
     for kc, vc in eng.kv_caches:
         kc.copy_((torch.randn(kc.shape, generator=g, device=dev) * 0.5).half())

@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/cycle -- python3 $r
     --model $model --batch $batch --k $k > $out/cycle.log 2>&1
 # (3) PMC pass: HBM read bytes per launch
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc -- python3 $root/scripts/profile_cycle.py --steps 6 \
-    --model $model --batch $batch --k $k > $out/pmc.log 2>&1
+    --model $model --batch $batch --k $k --plain-engine > $out/pmc.log 2>&1 || echo "PMC pass failed (see $out/pmc.log)"
 cd $root
 suffix=""; [ "$model $batch $k" != "llama-3-8b 4 3" ] && suffix="_${model}_bs${batch}_k${k}"
 f=$(find $out/bench -name '*kernel_stats.csv' | head -1)
@@ -26,6 +26,6 @@ f=$(find $out/bench -name '*kernel_stats.csv' | head -1)
 f=$(find $out/cycle -name '*kernel_stats.csv' | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- python3 scripts/profile_cycle.py --steps 20 --model $model --batch $batch --k $k   (decode cycles only)"; cat $out/cycle.log | grep cycle_ms; python3 scripts/summarize_prof.py $f; } > profiles/${tag}_cycle${suffix}_kernel_stats.txt
 f=$(find $out/pmc -name '*counter_collection.csv' | head -1)
-python3 scripts/pmc_traffic.py $f profiles/${tag}_pmc_fetch_size${suffix}.json $model $batch $k > profiles/${tag}_pmc_fetch_size${suffix}.txt
+[ -n "$f" ] && python3 scripts/pmc_traffic.py $f profiles/${tag}_pmc_fetch_size${suffix}.json $model $batch $k > profiles/${tag}_pmc_fetch_size${suffix}.txt
 cp profiles/${tag}_*${suffix}* $out/ 2>/dev/null || true
 echo "profiles written: $(ls profiles/${tag}_*${suffix}* | tr '\n' ' ')"

@@ -14,3 +14,6 @@ for w in ws:
 torch.cuda.synchronize()
 st = hout.view(-1)[-32:].view(torch.int64).cpu().tolist()
 print("cycles [load issue, LN compute, main loop, last compute, last finish]:", [st[i + 1] - st[i] for i in range(5)])
+ln = hout.view(-1)[-64:-32].view(torch.int64).cpu().tolist()
+print("  inside the norm, from the kernel's first stamp: [residual stream arrived, mean tree done, variance tree done, "
+      "quantised, barrier passed]:", [ln[i] - st[0] for i in range(5)])
