@@ -216,6 +216,26 @@ int qspec_gate_up_silu_linear_w4a16_shard(const qspec_half* x, const int8_t* wq,
                                           int M, int intermediate, int K, int first_channel, int num_channels,
                                           void* workspace, void* stream);
 
+/* One-shot all-reduce over peer-mapped buffers (xGMI) for the small fp32 messages of the tensor-parallel verify pass.
+ * Contract mirrored: vllm's custom all-reduce, one-shot form (csrc/custom_all_reduce.cuh;
+ * vllm/distributed/device_communicators/custom_all_reduce.py:50-56,242-255): every rank maps every peer's buffer through
+ * IPC handles exchanged on the host, messages below a size limit take this path, the library collective (RCCL) stays
+ * the fallback.  Each rank PUSHES its vector into a slot of every peer's buffer (xGMI is point to point: one hop per
+ * peer, all links at once), flags, and sums the world slots in RANK ORDER in fp32: same bits on every rank and on every
+ * run.  No host-side state per call (device-side generation tags): capturable in a hipGraph.
+ *   create: this rank's buffer (uncached device memory); max_bytes = capacity of one message, a multiple of 16.
+ *   local_handle / open_peers: hipIpcMemHandle_t exchange (handles rank-major, qspec_oneshot_handle_bytes() each).
+ *   all_reduce_f32: data [n] fp32 in place, n * 4 <= max_bytes, data 16-byte aligned; every rank must call it in the
+ *     same order with the same n; ranks' kernels wait for each other on the GPU (bounded; qspec_oneshot_error != 0 if a
+ *     wait timed out). */
+int qspec_oneshot_create(int rank, int world, size_t max_bytes, void** ctx_out);
+int qspec_oneshot_handle_bytes(void);
+int qspec_oneshot_local_handle(void* ctx, void* handle_out);
+int qspec_oneshot_open_peers(void* ctx, const void* handles);
+int qspec_oneshot_all_reduce_f32(void* ctx, float* data, int n, void* stream);
+int qspec_oneshot_error(void* ctx);
+int qspec_oneshot_destroy(void* ctx);
+
 /* lm_head: F.linear(hidden, lm_head.weight)  (vllm/model_executor/layers/logits_processor.py:92-97). w [N,K] fp16. */
 int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, int M, int N, int K, void* stream);
 

@@ -56,6 +56,13 @@ SIGNATURES = {
     "qspec_w4a16_linear_ksliced": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "qspec_w4a16_linear_ksliced_raw": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _vp]),
     "qspec_gate_up_silu_linear_w4a16_shard": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "qspec_oneshot_create": (_i, [_i, _i, _sz, ctypes.POINTER(_vp)]),
+    "qspec_oneshot_handle_bytes": (_i, []),
+    "qspec_oneshot_local_handle": (_i, [_vp, _vp]),
+    "qspec_oneshot_open_peers": (_i, [_vp, _vp]),
+    "qspec_oneshot_all_reduce_f32": (_i, [_vp, _vp, _i, _vp]),
+    "qspec_oneshot_error": (_i, [_vp]),
+    "qspec_oneshot_destroy": (_i, [_vp]),
     "qspec_linear_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_dequant_w4": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "qspec_rotary_embedding": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i64, _vp]),

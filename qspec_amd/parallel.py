@@ -93,6 +93,70 @@ class TorchDistComm:
         return box[0]
 
 
+class OneShotComm(TorchDistComm):
+    """TorchDistComm whose small fp32 all-reduces (the [T, H] row-parallel partials of the verify pass) go through the
+    one-shot push all-reduce over IPC-mapped peer buffers (csrc/comm.hip; the contract of vllm's custom all-reduce,
+    custom_all_reduce.py:50-56,242-255); everything else, and anything above `max_bytes`, stays on the library
+    collective.  Opt-in (QSPEC_ONESHOT_AR=1, or constructed directly): NOT yet measured on a multi-GPU box -- it is
+    exercised with two processes on one GPU (tests/oneshot_check.py)."""
+
+    def __init__(self, rank: int, world: int, group: Optional[dist.ProcessGroup] = None, max_bytes: int = 2 << 20):
+        super().__init__(group)
+        import ctypes
+        from . import _lib
+        self._lib = _lib.load()
+        self.rank, self.world, self.max_bytes = rank, world, max_bytes
+        ctx = ctypes.c_void_p()
+        rc = self._lib.qspec_oneshot_create(rank, world, max_bytes, ctypes.byref(ctx))
+        if rc != 0:
+            raise RuntimeError(f"qspec_oneshot_create failed ({rc})")
+        self._ctx = ctx
+        hb = self._lib.qspec_oneshot_handle_bytes()
+        mine = ctypes.create_string_buffer(hb)
+        if self._lib.qspec_oneshot_local_handle(ctx, mine) != 0:
+            raise RuntimeError("hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set on this pool)")
+        handles = [None] * world
+        dist.all_gather_object(handles, mine.raw, group=group)
+        rc = self._lib.qspec_oneshot_open_peers(ctx, b"".join(handles))
+        if rc != 0:
+            raise RuntimeError(f"hipIpcOpenMemHandle failed for rank {rc - 2}")
+        dist.barrier(group=group)
+        self.backend = "oneshot+" + self.backend
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() * 4 <= self.max_bytes \
+                and t.data_ptr() % 16 == 0 and t.numel() % 4 == 0:
+            rc = self._lib.qspec_oneshot_all_reduce_f32(self._ctx, t.data_ptr(), t.numel(),
+                                                        torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                raise RuntimeError(f"qspec_oneshot_all_reduce_f32 failed ({rc})")
+            return t
+        if self.backend.endswith("gloo") and t.is_cuda:
+            c = t.cpu()
+            dist.all_reduce(c, group=self.group)
+            t.copy_(c)
+            return t
+        dist.all_reduce(t, group=self.group)
+        return t
+
+    def all_gather(self, recv: torch.Tensor, send: torch.Tensor) -> torch.Tensor:
+        if self.backend.endswith("gloo") and send.is_cuda:
+            rc = recv.cpu()
+            dist.all_gather_into_tensor(rc, send.cpu(), group=self.group)
+            recv.copy_(rc)
+            return recv
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        return recv
+
+    def error(self) -> int:
+        return int(self._lib.qspec_oneshot_error(self._ctx))
+
+    def close(self):
+        if self._ctx is not None:
+            self._lib.qspec_oneshot_destroy(self._ctx)
+            self._ctx = None
+
+
 class ThreadComm:
     """`world` ranks as threads of ONE process sharing one device (tests: a GPU box admits at most 6 processes on
     its card, so the 8-rank shard ranges of Llama-3-70B are exercised in-process).  All ranks enqueue on the same
@@ -150,7 +214,11 @@ class TensorParallel:
                  comm=None):
         self.rank, self.world, self.group = rank, world, group
         if comm is None and world > 1:
-            comm = TorchDistComm(group)
+            import os
+            if os.environ.get("QSPEC_ONESHOT_AR", "0") == "1":
+                comm = OneShotComm(rank, world, group)
+            else:
+                comm = TorchDistComm(group)
         self.comm = comm
         self.backend = comm.backend if comm is not None else "none"
         # False: the decoder layers of the verify pass stay replicated (no collectives); lm_head stays vocab-parallel

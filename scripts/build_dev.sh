@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 name=${1:-dev}; extra=${2:-}
 mkdir -p build_dev/$name
-for f in capi norm_quant hadamard gemm gemm_stream gemm_tiled attention sampler; do
+for f in capi norm_quant hadamard gemm gemm_stream gemm_tiled attention sampler comm; do
   src=qspec_amd/csrc/$f.hip; obj=build_dev/$name/$f.o
   if [ ! -f $obj ] || [ $src -nt $obj ] || [ qspec_amd/csrc/common.cuh -nt $obj ] || [ "$FORCE" = 1 ]; then
     /opt/rocm/bin/hipcc $extra -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math \

@@ -910,7 +910,7 @@ def test_gate_up_shards_concatenate_to_full(ops, oracle, M, I, K, world):
     assert (host(act) != 0).mean() > 0.99   # every channel range was written
 
 
-def _run_tp_check(args, nproc):
+def _run_tp_check(args, nproc, extra_env=None):
     import subprocess, sys, socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = os.path.join(root, "tests", "tp_check.py")
@@ -920,7 +920,7 @@ def _run_tp_check(args, nproc):
                "--master-addr", "127.0.0.1", "--master-port", str(port), script] + args
     else:
         cmd = [sys.executable, script] + args
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, **(extra_env or {})))
     if "TP_OK" not in r.stdout:   # the full output of the ranks, for the post-mortem (pytest truncates long reprs)
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         with open(os.path.join(root, "gpurun_out", "tp_check_%s.log" % "_".join(a.strip("-") for a in args)), "w") as f:
@@ -929,9 +929,32 @@ def _run_tp_check(args, nproc):
     print(r.stdout.strip().splitlines()[-1])
 
 
+def test_oneshot_all_reduce_two_processes_one_gpu():
+    """The one-shot push all-reduce over IPC-mapped peer buffers (csrc/comm.hip; contract: vllm custom_all_reduce.py:
+    50-56,242-255) with two processes on this GPU: eager, inside a replayed hipGraph, and the fallback path."""
+    import subprocess, sys, socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "oneshot_check.py")],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    if "ONESHOT_OK" not in r.stdout:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "oneshot_check.log"), "w") as f:
+            f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
+    assert "ONESHOT_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_tensor_parallel_engine_two_ranks():
     """2 gloo ranks (processes) on this GPU: TP verify path vs single-GPU path + engine cycles (tests/tp_check.py)."""
     _run_tp_check(["--family", "tiny"], 2)
+
+
+def test_tensor_parallel_engine_two_ranks_oneshot_all_reduce():
+    """The same check with the row-parallel partials reduced by the one-shot push all-reduce (QSPEC_ONESHOT_AR=1)
+    instead of the host-staged gloo collective: the path a multi-GPU run takes over xGMI, here over IPC on one GPU."""
+    _run_tp_check(["--family", "tiny"], 2, {"QSPEC_ONESHOT_AR": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
 
 
 def test_tensor_parallel_llama2_13b_width_two_ranks():

@@ -161,6 +161,7 @@ def main():
     dist.all_gather(gathered, mine)
     assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged"
     if rank == 0:
+        print("collectives:", "oneshot+gloo" if os.environ.get("QSPEC_ONESHOT_AR") == "1" else "gloo (host staged)", flush=True)
         print("TP_OK %s world=%d max_hidden_err/1e-3=%.2f frac>1e-3=%.2e max_logit_err/1e-3=%.2f tokens=%s"
               % (a.family, world, results[0][1], results[0][2], results[0][3], results[0][0][:4]), flush=True)
     dist.destroy_process_group()
