@@ -383,6 +383,9 @@ def main():
                                 if model.tp.shard_layers else
                                 "verify pass: vocab-parallel lm_head + all-gather; decoder layers replicated (their collectives "
                                 "would cost more than the weight stream they save at this size); draft pass replicated")),
+                   "tp_collective": (None if world == 1 else model.tp.backend),
+                   "tp_plan_basis": (None if world == 1 else "collective cost is an ESTIMATE (parallel.COLLECTIVE_US), not "
+                                     "measured on a multi-GPU box; QSPEC_TP_LAYERS=0/1 forces either plan"),
                    "agreement": rho,
                    "capture": ("graph" if eng._graph is not None else
                                ("draft-graph+eager-verify" if eng._graph_draft is not None else "eager"))},

@@ -468,13 +468,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
         load_pre(pre, tile);
         QS_SSTAMP(1);
         if (tid == 0) {
-            for (int guard = 0; guard < (1 << 22); guard++) {   // bounded: a lost producer gives wrong numbers, not a hang
-                int ok = 1;
+            int ok = 0;
+            for (int guard = 0; guard < (1 << 22) && !ok; guard++) {   // bounded: a lost producer must not hang the GPU
+                ok = 1;
                 for (int i = 0; i < P; i++)
                     ok &= __hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                if (ok) break;
-                __builtin_amdgcn_s_sleep(4);
+                if (!ok) __builtin_amdgcn_s_sleep(4);
             }
+            // ... and must not pass silently either: sticky error word of the workspace (word 31), read by the host once
+            // per cycle (QSpecEngine.error_flag)
+            if (!ok) __hip_atomic_store(&a.sync[31], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         {

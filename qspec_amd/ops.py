@@ -245,6 +245,12 @@ def ln_linear_workspace(device, M: int = 16):
     return _ln_ws[key]
 
 
+def ln_linear_error_word(device):
+    """int32 view [1] of the hand-off workspace's sticky error word (None if the workspace was never created)."""
+    ws = _ln_ws.get((device.type, device.index))
+    return None if ws is None else ws.view(torch.int32)[31:32]
+
+
 def ln_qkv_rope_linear(hidden_in, delta, hidden_out, eps, wq, w_scale, qkv, positions, cos_sin_cache, key_cache,
                        value_cache, slot_mapping, num_heads, num_kv_heads, head_size):
     """Draft pass: hidden_out = hidden_in + delta; LN + int4 quant; qkv GEMM; RoPE; KV write -- one launch

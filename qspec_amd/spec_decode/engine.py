@@ -384,5 +384,8 @@ class QSpecEngine:
 
     def error_flag(self) -> int:
         """Sticky device-side error word of the kernels that hand data between workgroups (0 = fine)."""
-        w = ops.xwg_error_word(self.device)
-        return 0 if w is None else int(w.item())
+        flag = 0
+        for w in (ops.xwg_error_word(self.device), ops.ln_linear_error_word(self.device)):
+            if w is not None:
+                flag |= int(w.item())
+        return flag
