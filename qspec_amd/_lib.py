@@ -44,6 +44,7 @@ SIGNATURES = {
     "qspec_ln_gate_up_silu_linear_s4s4": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "qspec_ln_linear_workspace_bytes": (_sz, []),
     "qspec_prefetch": (_i, [_vp, _sz, _i, _vp]),
+    "qspec_prefetch_tiles": (_i, [_vp, _sz, _i, _i, _i, _vp]),
     "qspec_ln_linear_s4s4_supported": (_i, [_i, _i, _i]),
     "qspec_rowwise_scaled_linear_s4s4_residual": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_rowwise_scaled_linear_s4s4_residual_supported": (_i, [_i, _i, _i]),

@@ -555,6 +555,13 @@ int qspec_prefetch(const void* p, size_t bytes, int workgroups, void* stream) {
     if (((uintptr_t)p) % 16) return fail("%s: pointer must be 16-byte aligned", op);
     return finish(op, qspec::prefetch_l2(p, bytes, workgroups, ST));
 }
+int qspec_prefetch_tiles(const void* p, size_t tile_bytes, int first_tile, int ntiles, int workgroups, void* stream) {
+    const char* op = "qspec_prefetch_tiles";
+    if (ntiles <= 0) return 0;
+    NONNULL(op, p);
+    if (((uintptr_t)p) % 16 || tile_bytes % 16) return fail("%s: pointer and tile_bytes must be multiples of 16", op);
+    return finish(op, qspec::prefetch_tiles(p, tile_bytes, first_tile, ntiles, workgroups, ST));
+}
 int qspec_ln_linear_s4s4_supported(int M, int N, int K) { return qspec::gemm_w4a4_stream_supported(M, N, K, true) ? 1 : 0; }
 
 }  // extern "C"

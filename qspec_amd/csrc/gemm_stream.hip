@@ -843,6 +843,34 @@ __global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__
     }
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9E3779B9u && sink) sink[0] = 1;   // keeps the loads alive
 }
+// Tile-aligned form: workgroup b touches tiles b, b + grid, ... of `tile_bytes` each -- the byte ranges the streaming
+// GEMM's workgroup b will read (weight tile t = rows 16 t .. 16 t + 15 of a [N, K/2] matrix = one contiguous range), so
+// that, dispatched alike, the lines wait in the consumer's own XCD's L2.  first_tile / ntiles bound the part touched.
+__global__ __launch_bounds__(256) void prefetch_tiles_kernel(const char* __restrict__ p, size_t tile_bytes, int first_tile,
+                                                             int ntiles, unsigned* sink) {
+    u32x4 acc = {0, 0, 0, 0};
+    const size_t n16 = tile_bytes / 16;
+    for (int t = first_tile + blockIdx.x; t < first_tile + ntiles; t += gridDim.x) {
+        const u32x4* q = reinterpret_cast<const u32x4*>(p + (size_t)t * tile_bytes);
+        for (size_t i = threadIdx.x; i < n16; i += 1024) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const size_t j = i + u * 256;
+                v[u] = q[j < n16 ? j : i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc ^= v[u];
+        }
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9E3779B9u && sink) sink[0] = 1;
+}
+int prefetch_tiles(const void* p, size_t tile_bytes, int first_tile, int ntiles, int workgroups, hipStream_t st) {
+    if (ntiles < 1 || workgroups < 1 || tile_bytes % 16) return 0;
+    hipLaunchKernelGGL(prefetch_tiles_kernel, dim3(workgroups), dim3(256), 0, st, reinterpret_cast<const char*>(p), tile_bytes,
+                       first_tile, ntiles, (unsigned*)nullptr);
+    return 0;
+}
 int prefetch_l2(const void* p, size_t bytes, int workgroups, hipStream_t st) {
     if (bytes < 16 || workgroups < 1) return 0;
     hipLaunchKernelGGL(prefetch_kernel, dim3(workgroups), dim3(256), 0, st, reinterpret_cast<const u32x4*>(p), bytes / 16,

@@ -105,6 +105,7 @@ bool gemm_f16_stream_supported(int M, int N, int K);
 int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, void* part_max, hipStream_t st);
 int gemm_f16_stream_grid(int N);
 int prefetch_l2(const void* p, size_t bytes, int workgroups, hipStream_t st);
+int prefetch_tiles(const void* p, size_t tile_bytes, int first_tile, int ntiles, int workgroups, hipStream_t st);
 
 // attention.hip
 int rope_kv_write(const int64_t* positions, f16* qkv, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,

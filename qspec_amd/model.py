@@ -158,7 +158,11 @@ class QuarotLlamaForCausalLM:
 
     # M above which the fused GEMM epilogues (QKV+RoPE+KV write, gate_up+SiLU) give way to plain GEMM + separate kernels
     BIG_M = 64
-    FUSE_LN = True   # draft pass: LN in the GEMM prologue (False = separate LN kernel; the two are bit-identical)
+    # draft pass: LN in the GEMM prologue up to this many tokens (0 = always a separate LN launch; bit-identical).
+    # Measured in the engine (round 2): bs = 4 fused 8.39 vs separate 8.43 ms per cycle; bs = 16 fused (hand-off form)
+    # 14.30 vs separate 13.38 ms -- the standalone norm launch (3.4 us) beats the hand-off from 8 tokens on.
+    FUSE_LN_MAX_M = int(__import__("os").environ.get("QSPEC_FUSE_LN_MAX_M", "4"))
+    FUSE_LN = True
 
     def _w4a16(self, x, lin, out):
         # every M reads the packed int4 buffer: streaming kernel (M <= 16), M-tiled kernel (prefill-sized M)
@@ -224,7 +228,8 @@ class QuarotLlamaForCausalLM:
         nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         # draft pass at decode-sized M: residual add + LN + int4 quant run in the prologue of the qkv / gate_up GEMM
         # launches (gemm_stream.hip); the residual stream ping-pongs between two buffers
-        ln_fused = (w4a4 and fuse and self.FUSE_LN and ops.ln_linear_s4s4_supported(T, row, cfg.hidden_size)
+        ln_fused = (w4a4 and fuse and self.FUSE_LN and T <= self.FUSE_LN_MAX_M
+                    and ops.ln_linear_s4s4_supported(T, row, cfg.hidden_size)
                     and ops.ln_linear_s4s4_supported(T, 2 * cfg.intermediate_size, cfg.hidden_size)
                     and ops.rowwise_scaled_linear_s4s4_residual_supported(T, cfg.hidden_size, cfg.hidden_size)
                     and ops.rowwise_scaled_linear_s4s4_residual_supported(T, cfg.hidden_size, cfg.intermediate_size))

@@ -224,6 +224,13 @@ def prefetch(t, workgroups: int = 128):
     _call("qspec_prefetch", t.data_ptr(), t.numel() * t.element_size(), workgroups, _stream())
 
 
+def prefetch_tiles(wq, first_tile: int = 0, ntiles: Optional[int] = None, workgroups: int = 256):
+    """Cache hint, tile aligned: workgroup b touches weight tiles b, b + workgroups, ... (16 rows each) of wq [N, K/2]."""
+    tile_bytes = 16 * wq.shape[1] * wq.element_size()
+    n = wq.shape[0] // 16 if ntiles is None else ntiles
+    _call("qspec_prefetch_tiles", wq.data_ptr(), tile_bytes, first_tile, n, workgroups, _stream())
+
+
 def ln_linear_s4s4_supported(M: int, N: int, K: int) -> bool:
     return bool(_lib.load().qspec_ln_linear_s4s4_supported(M, N, K))
 
