@@ -58,6 +58,10 @@ class QSpecEngine:
                  seed: int = 0):
         self.model = model
         self.cfg = cfg = model.config
+        if max_model_len > cfg.max_position_embeddings:
+            # the RoPE table has max_position_embeddings rows (quarot_llama.py:112-120); vLLM refuses such a
+            # max_model_len at config time -- a position beyond it would read past the table
+            raise ValueError(f"max_model_len {max_model_len} > max_position_embeddings {cfg.max_position_embeddings}")
         self.k = k = num_speculative_tokens
         self.B = B = max_batch
         self.block_size = block_size

@@ -636,6 +636,8 @@ def test_engine_capacity_guard_refuses_cleanly(tiny):
     eng.add_sequence(1, prng.integers(0, V, 8).tolist())
     with pytest.raises(ValueError):
         eng.add_sequence(1, [1, 2, 3])                    # occupied
+    with pytest.raises(ValueError, match="max_position_embeddings"):
+        QSpecEngine(tiny, k, B, max_model_len=tiny.config.max_position_embeddings + 16)   # beyond the RoPE table
     n = 0
     with pytest.raises(ValueError, match="slot 0"):
         for _ in range(20):
