@@ -21,6 +21,14 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _ws_key(device):
+    """Key of the process-wide scratch / hand-off workspaces: they carry ticket, flag or generation state and are
+    safe for ONE stream at a time (launches on a stream are serialised), so each (device, stream) gets its own."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return (device.type, idx, torch.cuda.current_stream(device).cuda_stream)
+
+
 def _chk(t: torch.Tensor, name: str, dtype=None):
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a HIP/CUDA tensor (the QSpec hot path has no CPU fallback)")
@@ -158,17 +166,19 @@ def xwg_workspace(device):
     serialised, two streams must not share its counters.  Word 0 is a sticky error flag (xwg_error)."""
     if not XWG_SPREAD:
         return None
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = _ws_key(device)
     if key not in _xwg_ws:
         _xwg_ws[key] = torch.zeros(int(_lib.load().qspec_xwg_workspace_bytes()) // 4, dtype=torch.int32, device=device)
     return _xwg_ws[key]
 
 
 def xwg_error_word(device):
-    """int32 view [1] of the sticky error flag of the current stream's exchange workspace (None if never used)."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-    ws = _xwg_ws.get(key)
-    return None if ws is None else ws[:1]
+    """Sticky error flags of EVERY exchange workspace of the device (a captured graph keeps the workspace of its
+    capture stream): an int32 tensor [n] (one word per workspace), or None if none exists."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    words = [ws[:1] for key, ws in _xwg_ws.items() if key[:2] == (device.type, idx)]
+    return torch.cat(words) if words else None
 
 
 def mlp_hadamard(act, hadK, K: int, had_scale: float, out_f16=None, q=None, scale=None, clip_ratio: float = 1.0,
@@ -246,16 +256,18 @@ def ln_linear_workspace(device, M: int = 16):
     tokens the producer / hand-off form wins (15 vs 25 us at 16 tokens)."""
     if not LN_HANDOFF or M < LN_HANDOFF_MIN_M:
         return None
-    key = (device.type, device.index)
+    key = _ws_key(device)
     if key not in _ln_ws:
         _ln_ws[key] = torch.zeros(int(_lib.load().qspec_ln_linear_workspace_bytes()), dtype=torch.uint8, device=device)
     return _ln_ws[key]
 
 
 def ln_linear_error_word(device):
-    """int32 view [1] of the hand-off workspace's sticky error word (None if the workspace was never created)."""
-    ws = _ln_ws.get((device.type, device.index))
-    return None if ws is None else ws.view(torch.int32)[31:32]
+    """Sticky error words of every norm hand-off workspace of the device (int32 [n]) or None."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    words = [ws.view(torch.int32)[31:32] for key, ws in _ln_ws.items() if key[:2] == (device.type, idx)]
+    return torch.cat(words) if words else None
 
 
 def ln_qkv_rope_linear(hidden_in, delta, hidden_out, eps, wq, w_scale, qkv, positions, cos_sin_cache, key_cache,
@@ -316,9 +328,9 @@ _w16_ws = {}
 
 
 def w4a16_workspace(device):
-    """Zero-initialised split-K scratch of the W4A16 kernels, one per device (calls on one stream are serialised,
-    so they can share it; every call leaves the ticket counters at zero)."""
-    key = str(device)
+    """Zero-initialised split-K scratch of the W4A16 kernels, one per (device, stream): calls on one stream are
+    serialised, so they can share it (every call leaves the ticket counters at zero); two streams must not."""
+    key = _ws_key(device)
     if key not in _w16_ws:
         _w16_ws[key] = torch.zeros(int(_lib.load().qspec_w4a16_workspace_bytes()), dtype=torch.uint8, device=device)
     return _w16_ws[key]
@@ -476,10 +488,10 @@ _ws_cache = {}
 
 
 def _sampler_ws(rows: int, device, workspace=None):
-    """Scratch for the chunked softmax / rejection kernels (64 partials per row); cached per (device, rows)."""
+    """Scratch for the chunked softmax / rejection kernels (64 partials per row); cached per (device, stream, rows)."""
     if workspace is not None:
         return workspace
-    key = (str(device), rows)
+    key = (_ws_key(device), rows)
     if key not in _ws_cache:
         n = int(_lib.load().qspec_sampler_workspace_bytes(rows))
         _ws_cache[key] = torch.empty(n, dtype=torch.uint8, device=device)
@@ -505,7 +517,7 @@ def lm_head_softmax_argmax(hidden, lm_head, logits, probs, token):
     hands its row maxima to the softmax, probs is written once (logits_processor.py:92-97 + sampler.py:270-287)."""
     T, K = hidden.shape
     V = lm_head.shape[0]
-    key = (str(hidden.device), T)
+    key = (_ws_key(hidden.device), T)
     if key not in _head_ws:
         _head_ws[key] = torch.empty(int(_lib.load().qspec_lm_head_sampler_workspace_bytes(T)), dtype=torch.uint8,
                                     device=hidden.device)

@@ -391,5 +391,5 @@ class QSpecEngine:
         flag = 0
         for w in (ops.xwg_error_word(self.device), ops.ln_linear_error_word(self.device)):
             if w is not None:
-                flag |= int(w.item())
+                flag |= int(w.abs().max().item())
         return flag

@@ -140,7 +140,7 @@ def test_mlp_hadamard_quant_draft_form_vs_oracle(ops, oracle, golden_dir, M, spr
     ops.mlp_hadamard(dev(act), dev(had), 28, sc, out_f16=z, workspace=ws)
     assert np.array_equal(bits(host(z)), bits(z0))
     if spread:
-        assert int(ops.xwg_error_word(torch.device(DEV)).item()) == 0
+        assert int(ops.xwg_error_word(torch.device(DEV)).abs().max().item()) == 0
 
 
 def test_mlp_hadamard_spread_70b_width_vs_oracle(ops, oracle, golden_dir):
