@@ -72,17 +72,22 @@ def make_bench_engine_class():
                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 
     class BenchEngine(QSpecEngine):
-        def set_agreement(self, rho):
-            if rho is None:
-                self._post_logits_hook = None
-                return
+        _rho = None
 
-            def hook(logits, draft_ids):
+        def set_agreement(self, rho):
+            self._rho = rho
+
+        def _verify_logits_hook(self, draft_ids):
+            if self._rho is None:
+                return None
+            rho, rng = float(self._rho), self.sampler.rng_state
+
+            def hook(logits):
                 B, k = draft_ids.shape
-                rc = fn(logits.data_ptr(), draft_ids.data_ptr(), draft_ids.stride(0), draft_ids.stride(1), float(rho),
-                        self.sampler.rng_state.data_ptr(), B, k, logits.shape[-1], torch.cuda.current_stream().cuda_stream)
+                rc = fn(logits.data_ptr(), draft_ids.data_ptr(), draft_ids.stride(0), draft_ids.stride(1), rho,
+                        rng.data_ptr(), B, k, logits.shape[-1], torch.cuda.current_stream().cuda_stream)
                 assert rc == 0
-            self._post_logits_hook = hook
+            return hook
     return BenchEngine
 
 
@@ -177,8 +182,10 @@ def measure_dominant_kernel(model, engine, reps=5):
             act_in += 2 * B * out_cols                         # residual read by the epilogue (written back below)
         return w + act_in + 2 * B * out_cols
 
+    import gc
     res, tot_b, tot_t, launches = {}, 0.0, 0.0, 0
     for kind in kinds + ("all",):
+        gc.collect()   # a stale CUDAGraph must not be finalised during the capture below
         sel = kinds if kind == "all" else (kind,)
 
         def body():
@@ -359,6 +366,9 @@ def main():
         barrier(world)
         dt = time.perf_counter() - t0
         total = sum(done.values())
+        del eng
+        import gc
+        gc.collect()
         return total / dt, t_prefill, cycles, dt
 
     eng, dt, acc, emit, draft = run(rho, args.warmup, args.steps)

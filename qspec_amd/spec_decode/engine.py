@@ -124,7 +124,6 @@ class QSpecEngine:
         self.inject_uniform: Optional[torch.Tensor] = None
         self.inject_exponential: Optional[torch.Tensor] = None
         self._prefill_scratch: Optional[Scratch] = None
-        self._post_logits_hook = None   # verify logits -> None, inside the captured cycle (bench.py's BenchEngine only)
 
     # ------------------------------------------------------------------ prefill (_run_no_spec, :666-720)
     @torch.no_grad()
@@ -258,7 +257,7 @@ class QSpecEngine:
         ops.spec_prepare_verify(self.last_token, draft_ids, self.eff_lens, self.block_tables, bs, self.v_tokens,
                                 self.v_pos, self.v_slots, self.v_ctx)
         hs = m.forward(self.v_tokens, self.v_pos, self.kv_caches, self.md_verify, self.scratch_verify, w4a4=False)
-        hook = None if self._post_logits_hook is None else (lambda logits: self._post_logits_hook(logits, draft_ids))
+        hook = self._verify_logits_hook(draft_ids)
         m.sample_greedy(hs, self.scratch_verify, self.target_probs.view(B * (k + 1), -1), self.target_tokens.view(-1),
                         shard_vocab=True, logits_hook=hook)
         # _verify_tokens (:861-970): bonus = the target's own token at the last position
@@ -333,6 +332,8 @@ class QSpecEngine:
             self._cycle_body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        import gc
+        gc.collect()   # no stale CUDAGraph may be finalised while this capture is under way
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
