@@ -128,10 +128,54 @@ class QSpecEngine:
     # ------------------------------------------------------------------ prefill (_run_no_spec, :666-720)
     @torch.no_grad()
     def add_sequences(self, prompts: Sequence[Sequence[int]]):
-        """Prompt pass for slots 0 .. len(prompts)-1 (a full batch in the benchmarks and most tests)."""
+        """Prompt pass for slots 0 .. len(prompts)-1 (a full batch in the benchmarks and most tests): ONE varlen
+        forward over all prompts (vLLM batches prompts the same way), the target's greedy token per prompt."""
         assert len(prompts) <= self.B
-        for b, prompt in enumerate(prompts):
-            self.add_sequence(b, prompt, sync=False)
+        self.add_sequences_to(list(range(len(prompts))), prompts)
+
+    @torch.no_grad()
+    def add_sequences_to(self, slots: Sequence[int], prompts: Sequence[Sequence[int]],
+                         block_tables: Optional[Sequence[Optional[Sequence[int]]]] = None) -> None:
+        """Admit several requests at once: one W4A16 forward over the concatenated prompts (flash-attn varlen form)."""
+        cfg, dev = self.cfg, self.device
+        n = len(slots)
+        if n == 0:
+            return
+        if n == 1:
+            self.add_sequence(slots[0], prompts[0], None if block_tables is None else block_tables[0])
+            return
+        for i, b in enumerate(slots):
+            if not 0 <= b < self.B or self._len_ub[b] != 0:
+                raise ValueError(f"slot {b} is not an empty slot of this engine")
+            if block_tables is not None and block_tables[i] is not None:
+                self.set_block_table(b, block_tables[i])
+            T = len(prompts[i])
+            if T < 1 or T + 1 > min(self._capacity[b], self.max_model_len):
+                raise ValueError(f"prompt of {T} tokens does not fit slot {b}")
+        lens = [len(p) for p in prompts]
+        Ttot, Tmax = sum(lens), max(lens)
+        s = Scratch(cfg, Ttot, n, Tmax, 1, dev, logits_rows=n)
+        ids = torch.tensor([t for p in prompts for t in p], dtype=torch.int64, device=dev)
+        pos = torch.cat([torch.arange(T, dtype=torch.int64, device=dev) for T in lens])
+        slot_map = torch.cat([self._slots_for(b, torch.arange(T, dtype=torch.int64, device=dev)) for b, T in zip(slots, lens)])
+        q_start = torch.tensor([0] + list(torch.tensor(lens).cumsum(0).tolist()), dtype=torch.int32, device=dev)
+        md = AttentionMetadata(slot_map, self.block_tables[list(slots)].contiguous(),
+                               torch.tensor(lens, dtype=torch.int32, device=dev), q_start, Tmax, 1)
+        hs = self.model.forward(ids, pos, self.kv_caches, md, s, w4a4=False)
+        last = (q_start[1:].long() - 1)
+        logits = self.model.compute_logits(hs[last].contiguous(), s)
+        probs = torch.empty(n, cfg.vocab_size, dtype=torch.float32, device=dev)
+        tok = torch.empty(n, dtype=torch.int64, device=dev)
+        ops.softmax_argmax(logits, probs, tok)
+        for i, (b, T) in enumerate(zip(slots, lens)):
+            self.seq_lens[b] = T + 1
+            self.last_token[b] = tok[i]
+            self.gen_tokens[b].fill_(-1)
+            self.gen_tokens[b, 0] = tok[i]
+            self.gen_lens[b] = 1
+            self._len_ub[b] = T + 1
+            self._gen_ub[b] = 1
+        self.n_active = sum(1 for v in self._len_ub if v > 0)
         torch.cuda.synchronize()
 
     @torch.no_grad()
@@ -268,6 +312,13 @@ class QSpecEngine:
         ops.spec_commit(self.out_tokens, self.seq_lens, self.last_token, self.gen_tokens, self.gen_lens)
 
     @torch.no_grad()
+    def _verify_logits_hook(self, draft_ids):
+        """A callable(logits) applied to the verify logits inside the cycle, or None.  The product has none; bench.py's
+        BenchEngine overrides this (synthetic draft/target agreement).  A method, not a stored closure: an engine must
+        not sit in a reference cycle -- its hipGraphs would then be destroyed by the cyclic collector at an arbitrary
+        moment, and destroying a graph while another capture is under way aborts the process."""
+        return None
+
     def _set_participants(self, participants: Optional[Sequence[int]]) -> List[int]:
         want = [1] * self.B if participants is None else [1 if b in participants else 0 for b in range(self.B)]
         if want != self._mask_host:

@@ -269,20 +269,26 @@ class SpecDecodeWorker:
             raise NotImplementedError("beam / parallel sampling groups are not on the QSpec path (one sequence per request)")
         return next(iter(s.seq_data.items()))
 
-    def _admit(self, s: SequenceGroupMetadata) -> int:
-        """A prompt (or a preempted request coming back for recomputation) takes the first free slot."""
-        if s.request_id in self._slots:          # recomputation: start over in the same slot
-            self.engine.free_slot(self._slots.pop(s.request_id))
+    def _admit(self, prompts: List[SequenceGroupMetadata]) -> List[int]:
+        """Prompts (or preempted requests coming back for recomputation) take the first free slots; their prompt pass
+        is ONE varlen forward (engine.add_sequences_to)."""
+        for s in prompts:
+            if s.request_id in self._slots:          # recomputation: start over
+                self.engine.free_slot(self._slots.pop(s.request_id))
         free = [b for b in range(self.max_num_seqs) if b not in self._slots.values()]
-        if not free:
-            raise RuntimeError(f"no free sequence slot for request {s.request_id}: max_num_seqs={self.max_num_seqs} are running")
-        slot = free[0]
-        seq_id, data = self._only_seq(s)
-        blocks = s.block_tables.get(seq_id) if s.block_tables else None
-        self.engine.add_sequence(slot, data.get_token_ids(), block_table=blocks)
-        self._slots[s.request_id] = slot
-        self._request_id_seq_id_mapping[s.request_id].add(seq_id)
-        return slot
+        if len(free) < len(prompts):
+            raise RuntimeError(f"no free sequence slot for request {prompts[len(free)].request_id}: "
+                               f"max_num_seqs={self.max_num_seqs} are running")
+        slots, toks, tables = free[:len(prompts)], [], []
+        for s in prompts:
+            seq_id, data = self._only_seq(s)
+            toks.append(data.get_token_ids())
+            tables.append(s.block_tables.get(seq_id) if s.block_tables else None)
+        self.engine.add_sequences_to(slots, toks, tables)
+        for s, slot in zip(prompts, slots):
+            self._slots[s.request_id] = slot
+            self._request_id_seq_id_mapping[s.request_id].add(self._only_seq(s)[0])
+        return slots
 
     def _decode_slots(self, sgml) -> List[int]:
         """Engine slots of a decode batch in request order; refreshes block tables; cross-checks the lengths."""
@@ -312,10 +318,11 @@ class SpecDecodeWorker:
         prompts = [i for i, s in enumerate(sgml) if s.is_prompt]
         decodes = [i for i, s in enumerate(sgml) if not s.is_prompt]
         dslots = self._decode_slots([sgml[i] for i in decodes])     # before admissions: validates the running ones
-        for i in prompts:
-            slot = self._admit(sgml[i])
-            tokens[i] = int(self.engine.gen_tokens[slot, 0])
         if prompts:
+            slots = self._admit([sgml[i] for i in prompts])
+            first = self.engine.gen_tokens[:, 0].cpu()
+            for i, slot in zip(prompts, slots):
+                tokens[i] = first[slot]
             self.scorer_calls += 1          # one scorer call for the prompt batch, as in the reference
         if decodes:
             self.engine.step_no_spec(participants=dslots)

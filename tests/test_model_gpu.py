@@ -564,7 +564,8 @@ def test_engine_slots_are_independent_and_empty_slots_are_inert(tiny):
     prompts = [prng.integers(0, V, n).tolist() for n in (17, 33, 64, 5)]
     full = QSpecEngine(tiny, k, B, max_model_len=256, block_size=16, max_new_tokens=64, use_graph=False, seed=0)
     half = QSpecEngine(tiny, k, B, max_model_len=256, block_size=16, max_new_tokens=64, use_graph=False, seed=0)
-    full.add_sequences(prompts)
+    for b in range(B):                    # one prompt pass per request in both engines: the same KV history bit for
+        full.add_sequence(b, prompts[b])  # bit (a batched prompt pass tiles its GEMMs differently: 1e-3-close, not identical)
     half.add_sequence(0, prompts[0])
     half.add_sequence(2, prompts[2])
     assert half.active_slots() == [0, 2]

@@ -43,6 +43,10 @@ class FakeEngine:
         self._len_ub[slot] = len(prompt) + 1
         self.gen_tokens[slot, 0] = 1000 + slot
 
+    def add_sequences_to(self, slots, prompts, block_tables=None):
+        for i, (b, p) in enumerate(zip(slots, prompts)):
+            self.add_sequence(b, p, None if block_tables is None else block_tables[i])
+
     def free_slot(self, slot):
         self.calls.append(("free", slot))
         self._len_ub[slot] = 0
