@@ -357,8 +357,8 @@ def main():
         while len(done) < args.batch:
             eng.step()
             cycles += 1
-            lens = eng.gen_lens.tolist()                            # the per-cycle host read
-            eng.sync_lens()
+            eng.sync_lens()                                         # the per-cycle host read (as the worker's)
+            lens = list(eng._gen_ub)
             for b, n in enumerate(lens):                            # a request at max_tokens leaves the batch
                 if b not in done and n >= max_tokens:
                     done[b] = max_tokens

@@ -181,7 +181,12 @@ int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const
  * sync_workspace: NULL -> every workgroup recomputes the norm; else qspec_ln_linear_workspace_bytes() bytes,
  * ZERO-FILLED once before first use (every call leaves it zeroed): a few producer workgroups compute the norm and
  * hand the packed rows to the others through L2 (write-through stores + flags, no fences) while all of them already
- * stream weights (faster from 8 tokens).  One workspace serves all calls of a stream; not for concurrent streams. */
+ * stream weights.  Faster than recomputing from 8 tokens on, but slower than a separate qspec_add_rms_norm_i4 launch +
+ * the (xq, xs) GEMM entry at those sizes (measured): the engine fuses up to 4 tokens only.  One workspace
+ * serves all calls of a stream; not for concurrent streams.  The consumers WAIT for the producers on the GPU: the launch
+ * must have the device to itself (<= one workgroup per CU; two processes sharing a GPU void this).  The wait is
+ * bounded: on expiry int32 word 31 of the workspace is set (sticky) and the launch continues with stale rows -- the host
+ * must read that word (QSpecEngine.error_flag does, once per cycle) and discard the step. */
 size_t qspec_ln_linear_workspace_bytes(void);
 int qspec_ln_qkv_rope_linear_s4s4(const qspec_half* hidden_in, const qspec_half* delta, qspec_half* hidden_out,
                                   float eps, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M, int N,

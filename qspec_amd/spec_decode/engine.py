@@ -245,7 +245,8 @@ class QSpecEngine:
 
     def sync_lens(self) -> None:
         """Make the host-side length bounds exact (one small device read)."""
-        lens, gens = self.seq_lens.tolist(), self.gen_lens.tolist()
+        both = torch.stack((self.seq_lens, self.gen_lens)).tolist()
+        lens, gens = both[0], both[1]
         for b in range(self.B):
             if self._len_ub[b] > 0:
                 self._len_ub[b], self._gen_ub[b] = int(lens[b]), int(gens[b])

@@ -78,3 +78,40 @@ def test_tp_plan_shards_layers_only_when_it_pays(monkeypatch):
     assert shard_layers_pays(l8b, 2)
     monkeypatch.setenv("QSPEC_TP_LAYERS", "0")
     assert not shard_layers_pays(l70b, 8)
+
+
+def test_thread_ranks_collectives_and_column_gathers():
+    """ThreadComm (ranks as threads of one process; what the 8-rank full-width TP test uses on the GPU): rank-order fp32
+    all-reduce, all-gather of even and uneven column ranges, object broadcast -- on CPU tensors."""
+    import threading
+    from qspec_amd.parallel import ThreadComm
+    world = 4
+    shared = ThreadComm.Shared(world)
+    out, errs = {}, []
+
+    def body(r):
+        try:
+            tp = TensorParallel(r, world, None, comm=ThreadComm(shared, r))
+            x = torch.full((3, 8), float(r + 1))
+            tp.all_reduce(x)
+            I = 32 * 6                                   # 6 units of 32 over 4 ranks: 2, 2, 1, 1 -> uneven ranges
+            full = torch.arange(3 * I, dtype=torch.float32).view(3, I)
+            c0, c1 = tp.channel_range(I)
+            act = torch.zeros(3, I)
+            act[:, c0:c1] = full[:, c0:c1]
+            tp.all_gather_channels(act, I)
+            V = 16 * 8                                   # even vocabulary ranges
+            logits = torch.arange(2 * V, dtype=torch.float32).view(2, V)
+            v0, v1 = tp.vocab_range(V)
+            got = torch.empty(2, V)
+            tp.all_gather_vocab(logits[:, v0:v1].contiguous(), got, V)
+            obj = tp.broadcast_object({"k": 3} if r == 0 else None, src=0)
+            out[r] = (bool((x == 10.0).all()), torch.equal(act, full), torch.equal(got, logits), obj)
+        except BaseException as exc:  # noqa: BLE001
+            errs.append((r, repr(exc)))
+            shared.barrier.abort()
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(timeout=60) for t in ts]
+    assert not errs, errs
+    assert all(out[r] == (True, True, True, {"k": 3}) for r in range(world)), out
