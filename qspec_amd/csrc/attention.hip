@@ -615,20 +615,10 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
         for (int i = 0; i < 8; i++)   // 16 lanes cover one 256-byte V row: key 4 i + g4 of the slice
             kv.vr[i] = *reinterpret_cast<const u32x4*>(value_cache + (sl.v[i] * nkv + kvh) * D + c16 * 8);
     };
-    // Two slices of the wave in flight (round 2): a wave alone on its SIMD may hold 512 registers, and with ONE slice
-    // (16 KB per wave) in flight the loop ran at the latency of a load per slice: 4.3 us per 32 keys, 15 GB/s per CU.
-    // Ring of two register sets A / B: slice i is computed from set i & 1, every register of the set is refilled with
-    // slice i + 2 right behind its last use; the loop is unrolled by two so that the sets stay in registers.  A wave
-    // with an odd slice count runs one masked extra body (no loads behind a branch; addresses are clamped).
-    const int sb0 = k_begin + wave * QS_AW_KEYS;
-    Slots slA, slB;        // slots of the slices that will REFILL set A / set B
-    {
-        Slots s0, s1;
-        lookup(s0, sb0);
-        lookup(s1, sb0 + 4 * QS_AW_KEYS);
-        slA = s0;
-        slB = s1;
-    }
+    int sb = k_begin + wave * QS_AW_KEYS;
+    Slots sl_cur, sl_nxt;
+    lookup(sl_cur, sb);
+    lookup(sl_nxt, sb + 4 * QS_AW_KEYS);
     u32x4 qfrag[4];
     {
         const int r = r0 + (c16 < R ? c16 : 0);
@@ -637,11 +627,8 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
 #pragma unroll
         for (int j = 0; j < 4; j++) qfrag[j] = *reinterpret_cast<const u32x4*>(qp + 32 * j);
     }
-    KV kvA, kvB;
-    fetch(kvA, slA);
-    fetch(kvB, slB);
-    lookup(slA, sb0 + 8 * QS_AW_KEYS);
-    lookup(slB, sb0 + 12 * QS_AW_KEYS);
+    KV cur;
+    fetch(cur, sl_cur);
     int pos[4];
     float row_m[4], row_l[4];
     f32x4 o[8];
@@ -656,10 +643,10 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
     const uint32_t vl_base = (uint32_t)(uintptr_t)vl;
     const int qd = c16 >> 2, pq = c16 & 3;
 
-    // one slice: computed from `cur`, whose registers are refilled from `sl` (the slice two steps ahead of it)
-    auto body = [&](KV& cur, Slots& sl, int sb) {
+    for (int s2 = wave; s2 < n_sl; s2 += 4) {
         const int nkeys = max(0, min(k_end - sb, QS_AW_KEYS));
-        // ---- S = Q K^T: lane holds rows 4 g4 + reg, key column t2 * 16 + c16
+        // ---- S = Q K^T: lane holds rows 4 g4 + reg, key column t2 * 16 + c16.  Each K register is refilled with the
+        // wave's NEXT slice right behind its last use (as the weight ring of gemm_stream.hip): the loads never stop.
         f32x4 sacc[2];
 #pragma unroll
         for (int t2 = 0; t2 < 2; t2++) {
@@ -676,7 +663,7 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t2 = 0; t2 < 2; t2++) {
-            const f16* kp = key_cache + (sl.k[t2] * nkv + kvh) * D + g4 * 8;
+            const f16* kp = key_cache + (sl_nxt.k[t2] * nkv + kvh) * D + g4 * 8;
 #pragma unroll
             for (int j = 0; j < 4; j++) cur.kf[t2][j] = *reinterpret_cast<const u32x4*>(kp + 32 * j);
         }
@@ -691,9 +678,9 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 8; i++)
-            cur.vr[i] = *reinterpret_cast<const u32x4*>(value_cache + (sl.v[i] * nkv + kvh) * D + c16 * 8);
+            cur.vr[i] = *reinterpret_cast<const u32x4*>(value_cache + (sl_nxt.v[i] * nkv + kvh) * D + c16 * 8);
         __builtin_amdgcn_sched_barrier(0);
-        lookup(sl, sb + 16 * QS_AW_KEYS);                // table entries of this set's refill after the next (clamped)
+        lookup(sl_nxt, sb + 8 * QS_AW_KEYS);             // table entries of the slice after the next (clamped)
         // ---- running softmax: the 16 lanes of a g4 group hold the 32 keys of rows 4 g4 + reg
         float alpha[4];
 #pragma unroll
@@ -739,13 +726,7 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
             }
         }
-    };
-    const int n_mine = n_sl > wave ? (n_sl - wave + 3) / 4 : 0;   // slices of this wave
-    int sb = sb0;
-    for (int i = 0; i < n_mine; i += 2) {
-        body(kvA, slA, sb);
-        body(kvB, slB, sb + 4 * QS_AW_KEYS);     // i + 1 == n_mine (odd count): every key masked, nothing changes
-        sb += 8 * QS_AW_KEYS;
+        sb += 4 * QS_AW_KEYS;
     }
     // ---- combine the four waves (wave order), store the split's partial: ws_o [T, nq, n_splits, D], ws_ml [.., 2]
     __syncthreads();   // every wave is done with its private tiles: the same LDS now carries the exchange
