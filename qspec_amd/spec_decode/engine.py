@@ -125,6 +125,8 @@ class QSpecEngine:
         self.inject_exponential: Optional[torch.Tensor] = None
         self._prefill_scratch: Optional[Scratch] = None
 
+    PREFILL_TOKEN_BUDGET = 4096   # tokens per prompt-pass forward when several requests are admitted together
+
     # ------------------------------------------------------------------ prefill (_run_no_spec, :666-720)
     @torch.no_grad()
     def add_sequences(self, prompts: Sequence[Sequence[int]]):
@@ -143,6 +145,19 @@ class QSpecEngine:
             return
         if n == 1:
             self.add_sequence(slots[0], prompts[0], None if block_tables is None else block_tables[0])
+            return
+        if sum(len(p) for p in prompts) > self.PREFILL_TOKEN_BUDGET:
+            # several passes of at most PREFILL_TOKEN_BUDGET tokens (measured: 4 x 512 tokens in one pass 37 ms vs 49 ms
+            # one by one, but 32 x 512 in one pass 335 ms vs 283 ms)
+            group, tokens = [], 0
+            for i in range(n + 1):
+                if i == n or (group and tokens + len(prompts[i]) > self.PREFILL_TOKEN_BUDGET):
+                    self.add_sequences_to([slots[j] for j in group], [prompts[j] for j in group],
+                                          None if block_tables is None else [block_tables[j] for j in group])
+                    group, tokens = [], 0
+                if i < n:
+                    group.append(i)
+                    tokens += len(prompts[i])
             return
         for i, b in enumerate(slots):
             if not 0 <= b < self.B or self._len_ub[b] != 0:
