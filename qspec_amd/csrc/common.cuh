@@ -13,6 +13,7 @@ typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32;
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
@@ -108,6 +109,82 @@ __device__ __forceinline__ float wave_max_f(float v) {
     v = fmaxf(v, shfl_xor_f(v, 16));
     v = fmaxf(v, shfl_xor_f(v, 32));
     return v;
+}
+
+// ---- one-instruction butterfly steps.  hipcc does not fold a v_mov_b32_dpp into a float add / max (its DPP combiner only
+// knows integer identities), so x + dpp_xor<M>(x) costs two VALU issues; written as v_add_f32_dpp it is one (two for M = 4:
+// the two bank-masked halves).  IEEE addition commutes, so the bits are those of x + dpp_xor<M>(x).  The leading s_nop
+// gives the 2 wait states a DPP read needs behind the VALU write of its source: the hazard recogniser does not look into
+// inline asm.
+template <int M>
+__device__ __forceinline__ float dpp_add_xor(float x) {
+    float r;
+    if (M == 1) asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+    else if (M == 2) asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+    else if (M == 8) asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+    else
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+            : "=&v"(r)
+            : "v"(x));
+    return r;
+}
+template <int M>
+__device__ __forceinline__ float dpp_max_xor(float x) {
+    float r;
+    if (M == 1) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+    else if (M == 2) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+    else if (M == 8) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+    else
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_max_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+            : "=&v"(r)
+            : "v"(x));
+    return r;
+}
+// p[c] += p[c] of lanes ^4, then ^2, then ^1, for four independent values at once: the four chains are interleaved, so
+// every DPP read sits four instructions behind the write of its source and no wait states are needed in between.
+__device__ __forceinline__ void dpp_add_tree421_x4(float (&p)[4]) {
+    float t0, t1, t2, t3;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));
+    p[0] = t0; p[1] = t1; p[2] = t2; p[3] = t3;
+}
+// lane ^ 16 through the LDS crossbar without an address register (ds_swizzle, bit mode: and 0x1f, xor 0x10)
+__device__ __forceinline__ float swizzle_xor16_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+// maximum over the wave as a wave-uniform value (SGPR): xor 1, 2, 4, 8 inside the rows of 16, then the GFX9 row
+// broadcasts (lane 15 of the row before into rows 1 and 3, lane 31 into rows 2 and 3) leave the total in lane 63.
+__device__ __forceinline__ float wave_max_uniform(float v) {
+    v = dpp_max_xor<1>(v);
+    v = dpp_max_xor<2>(v);
+    v = dpp_max_xor<4>(v);
+    v = dpp_max_xor<8>(v);
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
 // pack two int4 values (two's complement) into one byte: lo nibble = even index

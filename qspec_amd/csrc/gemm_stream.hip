@@ -91,38 +91,35 @@ __device__ __forceinline__ int stile_row(int tb, int r, int I) {
 
 // Reference summation tree over 1024 virtual-thread partials held 4 per lane (norm_quant.hip:ref_tree_sum_1024),
 // for RB rows at once.  j = index inside the 256-thread group; red = [RB][32] floats of this group, written once.
-// Same pairings, same order as the reference's two xor butterflies (so the same bits); the second butterfly is
-// evaluated directly from the 32 warp sums (every lane of a butterfly ends with the same value, so any one
-// lane's expression tree will do) instead of through five cross-lane exchanges.
+// Same pairings, same order as the reference's two xor butterflies (so the same bits):
+//   * first butterfly (virtual lane = 4 j + c): lanes ^4, ^2, ^1 as one-instruction DPP adds, the four chains of a row
+//     interleaved (dpp_add_tree421_x4), then the c pairs (0,2), (1,3) and the last add in registers;
+//   * second butterfly over the 32 warp sums: lane l of a wave takes warp sum l & 31 of row (l >> 5) (two rows per
+//     register), and the five levels 16, 8, 4, 2, 1 run ACROSS LANES (ds_swizzle for 16, DPP adds for the rest) --
+//     10 instructions for two rows where every thread used to add up all 32 sums of every row (8 broadcast
+//     ds_read_b128 + 31 adds per row).  Every lane of a butterfly ends with the same value; lane 0 / 32 is read back
+//     as a wave-uniform value.
 template <int RB>
 __device__ __forceinline__ void tree_sum_rows(float (&p)[RB][4], float* red, int j, float (&out)[RB]) {
+    const int lane = j & 63;
 #pragma unroll
     for (int i = 0; i < RB; i++) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) p[i][c] = p[i][c] + dpp_xor<4>(p[i][c]);
-#pragma unroll
-        for (int c = 0; c < 4; c++) p[i][c] = p[i][c] + dpp_xor<2>(p[i][c]);
-#pragma unroll
-        for (int c = 0; c < 4; c++) p[i][c] = p[i][c] + dpp_xor<1>(p[i][c]);
+        dpp_add_tree421_x4(p[i]);
         const float r0 = p[i][0] + p[i][2], r1 = p[i][1] + p[i][3];
         const float s = r0 + r1;
         if ((j & 7) == 0) red[i * 32 + (j >> 3)] = s;
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RB; i++) {
-        float v[32];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(red + i * 32 + 4 * q);
-            v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
-        }
-        // lane 0 of the butterfly: level m pairs index k with k ^ m, m = 16, 8, 4, 2, 1
-#pragma unroll
-        for (int m = 16; m > 0; m >>= 1)
-#pragma unroll
-            for (int k = 0; k < m; k++) v[k] = v[k] + v[k + m];
-        out[i] = v[0];
+    for (int i0 = 0; i0 < RB; i0 += 2) {
+        float x = red[i0 * 32 + (RB == 1 ? (lane & 31) : lane)];
+        x = x + swizzle_xor16_f(x);
+        x = dpp_add_xor<8>(x);
+        x = dpp_add_xor<4>(x);
+        x = dpp_add_xor<2>(x);
+        x = dpp_add_xor<1>(x);
+        out[i0] = readlane_f(x, 0);
+        if (RB > 1) out[i0 + 1] = readlane_f(x, 32);
     }
 }
 
@@ -166,14 +163,16 @@ template <int NI, int NG, int RB, bool HASD = true>
 __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs<NI, RB>& rg,
                                            unsigned char* xq_lds, int RS, float* xs_lds,
                                            float* lnred /* [3][NG][RB][32] */, bool write_hidden) {
-    const int tid = threadIdx.x, j = tid & 255, grp = tid >> 8;
+    static_assert(RB == 1 || RB == 2 || RB == 4, "rows per 256-thread group");
+    const int tid = threadIdx.x, j = tid & 255, grp = tid >> 8, lane = tid & 63;
     const int H = a.K;
     float* red_mean = lnred + (0 * NG + grp) * RB * 32;
     float* red_var = lnred + (1 * NG + grp) * RB * 32;
     float* red_max = lnred + (2 * NG + grp) * RB * 32;
-    float v[RB][NI][4];
-    int row[RB];
-    bool act[RB];
+    // v[i][it][h] = elements (2h, 2h + 1) of the thread's 4-element piece: the element-wise passes run on pairs
+    // (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: one VALU issue per two elements, each half rounded like the scalar op)
+    f32x2 v[RB][NI][2];
+    const int row0 = base + grp * RB;   // rows row0 .. row0 + RB - 1 (< MP <= 16: the caller's LDS rows exist even beyond M)
 #ifdef QS_STREAM_STAMPS
     long long lnst[8];
 #endif
@@ -188,83 +187,108 @@ __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs
     }
 #pragma unroll
     for (int i = 0; i < RB; i++) {
-        row[i] = base + grp * RB + i;
-        act[i] = row[i] < a.M;
-        const int rr = act[i] ? row[i] : 0;
+        const bool act = row0 + i < a.M;
+        const int rr = act ? row0 + i : 0;
 #pragma unroll
         for (int it = 0; it < NI; it++) {
-            if (HASD && write_hidden && act[i])
+            if (HASD && write_hidden && act)
                 *reinterpret_cast<f16x4*>(a.hidden_out + (size_t)rr * H + it * 1024 + 4 * j) = rg.x[i][it];
-#pragma unroll
-            for (int c = 0; c < 4; c++) v[i][it][c] = h2f(rg.x[i][it][c]);
+            v[i][it][0] = f32x2{h2f(rg.x[i][it][0]), h2f(rg.x[i][it][1])};
+            v[i][it][1] = f32x2{h2f(rg.x[i][it][2]), h2f(rg.x[i][it][3])};
         }
     }
     float p[RB][4], mean[RB], var[RB];
 #pragma unroll
     for (int i = 0; i < RB; i++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            float s = 0.0f;
+        for (int h = 0; h < 2; h++) {
+            // (the reference starts its chain at +0: 0 + v == v except that an all -0 chain ends as +0 there and -0
+            // here; a mean of -0 instead of +0 changes no deviation's magnitude and no rounded quotient)
+            f32x2 s = v[i][0][h];
 #pragma unroll
-            for (int it = 0; it < NI; it++) s = s + v[i][it][c];
-            p[i][c] = s;
+            for (int it = 1; it < NI; it++) s = s + v[i][it][h];
+            p[i][2 * h] = s[0];
+            p[i][2 * h + 1] = s[1];
         }
     tree_sum_rows<RB>(p, red_mean, j, mean);
     QS_LNSTAMP(1);
+    // x / H for a power of two H is x * (1 / H) bit for bit (both are the one correct rounding of the same real)
+    // (compile-time: H = 1024 NI; left to a run-time test hipcc computes the division anyway and selects)
+    constexpr bool pow2 = (NI & (NI - 1)) == 0;
+    constexpr float invH = 1.0f / (float)(NI > 0 ? NI * 1024 : 1);   // (NI = 0: instantiated but never run)
     // Second pass: sum of squared deviations AND max |deviation|.  The reference takes the maximum over
     // |h((x - mean) * rstd)| after the variance is known (a third block reduction); rstd > 0 and both roundings are
     // monotonic and sign-symmetric, so that maximum is |h(max|x - mean| * rstd)| bit for bit and the maximum can ride
-    // on the variance pass's barrier.
+    // on the variance pass's barrier.  The deviations replace the values in registers: the last pass needs only them.
 #pragma unroll
     for (int i = 0; i < RB; i++) {
-        mean[i] = mean[i] / (float)H;
+        mean[i] = pow2 ? mean[i] * invH : mean[i] / (float)H;
+        const f32x2 m2 = {mean[i], mean[i]};
         float dm = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            float s = 0.0f;
+        for (int h = 0; h < 2; h++) {
+            f32x2 s;
 #pragma unroll
             for (int it = 0; it < NI; it++) {
-                const float d = v[i][it][c] - mean[i];
-                s = __builtin_fmaf(d, d, s);
-                dm = fmaxf(dm, __builtin_fabsf(d));
+                const f32x2 d = v[i][it][h] - m2;
+                v[i][it][h] = d;
+                s = it == 0 ? d * d : __builtin_elementwise_fma(d, d, s);   // fma(d, d, +0) == d * d
+                dm = fmaxf(fmaxf(dm, __builtin_fabsf(d[0])), __builtin_fabsf(d[1]));
             }
-            p[i][c] = s;
+            p[i][2 * h] = s[0];
+            p[i][2 * h + 1] = s[1];
         }
-        dm = wave_max_f(dm);
+        dm = wave_max_uniform(dm);
         if ((j & 63) == 0) red_max[i * 32 + (j >> 6)] = dm;
     }
     tree_sum_rows<RB>(p, red_var, j, var);
     QS_LNSTAMP(2);
-    float amax[RB], rstd[RB];
+    // Row scalars, ONE IEEE sqrt and TWO IEEE divisions per call instead of one sqrt and five divisions per row (each
+    // ~11 dependent VALU instructions that every wave of every workgroup repeats): lane l works on row l % RB; lanes
+    // with bit RB clear produce 7 / amax (the quantiser's multiplier), lanes with it set amax / 7 (the stored scale).
+    const int li = lane & (RB - 1);
+    float tv = pow2 ? var[0] * invH : var[0] / (float)H;
+    tv = tv + a.eps;
+    f32x4 m4 = *reinterpret_cast<const f32x4*>(red_max + li * 32);
 #pragma unroll
-    for (int i = 0; i < RB; i++) {
-        rstd[i] = 1.0f / __builtin_sqrtf(var[i] / (float)H + a.eps);
-        const f32x4 m4 = *reinterpret_cast<const f32x4*>(red_max + i * 32);
-        const float dmax = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-        const f16 a16 = f2h(dmax * rstd[i]), floor16 = f2h(1e-6f);
-        amax[i] = h2f(a16 > floor16 ? a16 : floor16);
+    for (int i = 1; i < RB; i++) {
+        float t = pow2 ? var[i] * invH : var[i] / (float)H;
+        t = t + a.eps;
+        tv = li == i ? t : tv;
     }
+    const float rl = 1.0f / __builtin_sqrtf(tv);
+    const float dmax = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    const f16 a16 = f2h(dmax * rl), floor16 = f2h(1e-6f);
+    const float amax = h2f(a16 > floor16 ? a16 : floor16);
+    const bool second = (lane & RB) != 0;
+    const float ql = (second ? amax : 7.0f) / (second ? 7.0f : amax);
+    if (j >= RB && j < 2 * RB) xs_lds[row0 + j - RB] = h2f(f2h(ql));
+    // Last pass.  |(x - mean) * rstd| <= dmax * rstd =: y and amax >= h(y) >= y (1 - 2^-11) (fp16 normal range; below it
+    // the absolute rounding error 2^-25 against the floor of 17 * 2^-24 bounds the ratio by 1.03; h(y) = inf gives s = 0),
+    // so |t| <= 7.21 for every finite row and rounds into [-7, 7]: the reference's clamp to [-8, 7] never acts and is
+    // not executed.  Round to nearest even by adding 1.5 * 2^23 (+ 8): the low mantissa nibble is then q + 8 in 0..15
+    // with zeros above it up to bit 22, so the four nibbles of a piece are spliced with three shift-or's, no masks, and
+    // one xor with 0x8888 turns the offset nibbles into two's complement.
 #pragma unroll
     for (int i = 0; i < RB; i++) {
-        const float s = 7.0f / amax[i];
-        if (act[i]) {
+        const float rstd = readlane_f(rl, i), s = readlane_f(ql, i);
+        const f32x2 r2 = {rstd, rstd}, s2 = {s, s}, mg2 = {12582920.0f, 12582920.0f};
 #pragma unroll
-            for (int it = 0; it < NI; it++) {
-                u32 nib[4];
+        for (int it = 0; it < NI; it++) {
+            u32 b[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    float t = ((v[i][it][c] - mean[i]) * rstd[i]) * s;
-                    t = fmaxf(fminf(t, 7.0f), -8.0f);
-                    // round to nearest even: the low bits of (t + 1.5 * 2^23) are the two's complement integer
-                    float mg = t + 12582912.0f;
-                    asm("" : "+v"(mg));
-                    nib[c] = __builtin_bit_cast(u32, mg);
-                }
-                const u32 lo = (nib[0] & 0xFu) | (nib[1] << 4), hi = (nib[2] & 0xFu) | (nib[3] << 4);
-                const uint16_t two = (uint16_t)((lo & 0xFFu) | (hi << 8));
-                *reinterpret_cast<uint16_t*>(xq_lds + (size_t)row[i] * RS + it * 512 + 2 * j) = two;
+            for (int h = 0; h < 2; h++) {
+                f32x2 t = (v[i][it][h] * r2) * s2;
+                t = t + mg2;
+                float t0 = t[0], t1 = t[1];
+                asm("" : "+v"(t0), "+v"(t1));
+                b[2 * h] = __builtin_bit_cast(u32, t0);
+                b[2 * h + 1] = __builtin_bit_cast(u32, t1);
             }
-            if (j == 0) xs_lds[row[i]] = h2f(f2h(amax[i] / 7.0f));
+            u32 w = (b[1] << 4) | b[0];
+            w = (b[2] << 8) | w;
+            w = (b[3] << 12) | w;
+            *reinterpret_cast<uint16_t*>(xq_lds + (size_t)(row0 + i) * RS + it * 512 + 2 * j) = (uint16_t)(w ^ 0x8888u);
         }
     }
     QS_LNSTAMP(3);
