@@ -154,7 +154,11 @@ __device__ __forceinline__ void ln_load(const StreamArgs& a, int base, LnRegs<NI
 }
 
 #ifdef QS_STREAM_STAMPS
+#ifdef QS_STAMPS_DRAIN   // drains vmcnt first: "the time until the residual stream has arrived" (perturbs: also waits for the weights)
 #define QS_LNSTAMP(i) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lnst[i])::"memory")
+#else
+#define QS_LNSTAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lnst[i])::"memory")
+#endif
 __device__ long long g_lnst[8];
 #else
 #define QS_LNSTAMP(i)
@@ -541,8 +545,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
         LnRegs<NI, RB> rg;
         ln_load<NI, NG, RB, HASD>(a, 0, rg);
         __builtin_amdgcn_sched_barrier(0);
+        // The CU's vector L1 returns data in request order ACROSS waves, and the waves of a workgroup start ~1 k cycles
+        // apart: a wave whose (L2-resident) rows were requested behind an earlier wave's weight loads gets them only when
+        // those HBM misses have returned, and the norm's first barrier waited ~2.5 k cycles for that wave (in-kernel
+        // stamps).  So: every wave's row requests first (a bare barrier, no memory wait), then the weights.
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < UB; u++) w[u] = wload<u32x4>(wp0 + step_off<NW, UB>(wave, u));
+        __builtin_amdgcn_sched_barrier(0);   // (else hipcc hoists load_pre's wait for the position load above the weight loads)
         load_pre(pre, tile);
         __builtin_amdgcn_sched_barrier(0);
         const bool wh = blockIdx.x == 0 && a.hidden_out != nullptr;
@@ -570,6 +581,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < UB; u++) w[u] = wload<u32x4>(wp0 + step_off<NW, UB>(wave, u));
+        __builtin_amdgcn_sched_barrier(0);   // (else hipcc hoists load_pre's wait for the position load above the weight loads)
         load_pre(pre, tile);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -104,6 +104,43 @@ def test_ln_gate_up_silu_linear_draft_form_vs_oracle(ops, oracle, M):
     assert np.array_equal(bits(host(act)), bits(ref))
 
 
+def adversarial_rows(rng, n):
+    """Rows that lean on the corners of the norm + quantiser arithmetic: the fused prologue drops the reference's clamp
+    to [-8, 7] (proved dead for finite rows: |t| <= 7.21), takes x / H as x * (1 / H), and shares one sqrt / division
+    between rows -- each must still give the oracle's bytes."""
+    rows = []
+    rows.append(np.zeros(n))                                                   # all zero: amax = floor, scale from 1e-6
+    rows.append(np.full(n, 3.14159))                                           # constant: every deviation is rounding noise
+    rows.append(rng.integers(-3, 4, n) * 2.0 ** -24)                           # fp16 subnormals: y in the subnormal range
+    r = rng.standard_normal(n) * 1e-3; r[7] = 60000.0; rows.append(r)          # one huge outlier
+    rows.append(np.where(rng.random(n) < 0.5, 65504.0, -65504.0))              # +-max alternating: var near overflow of fp16
+    r = np.full(n, 1.0); r[::2] = 1.0009765625; rows.append(r)                 # two adjacent fp16 values
+    r = rng.integers(-7, 8, n).astype(np.float64); r[0] = 7.0; r[1] = -7.0; rows.append(r * 0.5)   # values on the grid: ties
+    r = rng.standard_normal(n); r[3] = -9.7; rows.append(r)                    # the maximum on the negative side
+    return np.stack(rows).astype(np.float16)
+
+
+@pytest.mark.parametrize("M", [4, 8])
+def test_norm_prologue_corner_rows_vs_oracle(ops, oracle, M):
+    rng = np.random.default_rng(250)
+    allrows = adversarial_rows(rng, H)
+    wg, wgs = rand_packed(rng, 2 * I, H), rand_scales(rng, 2 * I)
+    wgd, wgsd = dev(wg), dev(wgs)
+    for lo in range(0, len(allrows), M):
+        hid = allrows[lo:lo + M]
+        q, s, _ = oracle.ln_quant_i4(hid, EPS)
+        ref = oracle.silu_mul(oracle.gemm_w4a4(q, s, wg, wgs), I)
+        act = torch.empty(len(hid), I, dtype=torch.float16, device=DEV)
+        ops.ln_gate_up_silu_linear(dev(hid), None, None, EPS, wgd, wgsd, act)
+        assert np.array_equal(bits(host(act)), bits(ref)), lo
+        # and the standalone norm + quantiser on the same rows
+        q1 = torch.empty(len(hid), H // 2, dtype=torch.int8, device=DEV)
+        s1 = torch.empty(len(hid), dtype=torch.float16, device=DEV)
+        sum1 = torch.empty(len(hid), dtype=torch.float16, device=DEV)
+        ops.rms_norm_general_fuse_sum_i4(q1, dev(hid), sum1, s1, EPS)
+        assert np.array_equal(host(q1).view(np.uint8), np.asarray(q).view(np.uint8)) and np.array_equal(bits(host(s1)), bits(s)), lo
+
+
 @pytest.mark.parametrize("M", [3, 4, 16])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (4096, 14336)])
 def test_s4s4_residual_in_place_draft_form_vs_oracle(ops, oracle, M, N, K):
