@@ -100,17 +100,6 @@ __device__ __forceinline__ float dpp_xor(float x) {
     return __builtin_bit_cast(float, r);
 }
 
-// max over the 64 lanes of a wave (order independent): xor 1, 2, 4, 8 as DPP moves, 16 and 32 through ds_bpermute
-__device__ __forceinline__ float wave_max_f(float v) {
-    v = fmaxf(v, dpp_xor<1>(v));
-    v = fmaxf(v, dpp_xor<2>(v));
-    v = fmaxf(v, dpp_xor<4>(v));
-    v = fmaxf(v, dpp_xor<8>(v));
-    v = fmaxf(v, shfl_xor_f(v, 16));
-    v = fmaxf(v, shfl_xor_f(v, 32));
-    return v;
-}
-
 // ---- one-instruction butterfly steps.  hipcc does not fold a v_mov_b32_dpp into a float add / max (its DPP combiner only
 // knows integer identities), so x + dpp_xor<M>(x) costs two VALU issues; written as v_add_f32_dpp it is one (two for M = 4:
 // the two bank-masked halves).  IEEE addition commutes, so the bits are those of x + dpp_xor<M>(x).  The leading s_nop
@@ -183,6 +172,8 @@ __device__ __forceinline__ float wave_max_uniform(float v) {
         : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// max over the 64 lanes of a wave in every lane (order independent; all 64 lanes must be active)
+__device__ __forceinline__ float wave_max_f(float v) { return wave_max_uniform(v); }
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }

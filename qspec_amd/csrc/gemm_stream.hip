@@ -545,10 +545,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
         LnRegs<NI, RB> rg;
         ln_load<NI, NG, RB, HASD>(a, 0, rg);
         __builtin_amdgcn_sched_barrier(0);
-        // The CU's vector L1 returns data in request order ACROSS waves, and the waves of a workgroup start ~1 k cycles
-        // apart: a wave whose (L2-resident) rows were requested behind an earlier wave's weight loads gets them only when
-        // those HBM misses have returned, and the norm's first barrier waited ~2.5 k cycles for that wave (in-kernel
-        // stamps).  So: every wave's row requests first (a bare barrier, no memory wait), then the weights.
+        // The CU's vector L1 returns data in request order ACROSS waves, and its address path takes the eight waves' row
+        // requests one by one (~1 k cycles from the first to the last; the waves themselves start within 30 cycles of
+        // each other, scripts/micro/wave_start.hip): a wave whose (L2-resident) rows were requested behind an earlier
+        // wave's weight loads gets them only when those HBM misses have returned, and the norm's first barrier waited
+        // ~2.5 k cycles for that wave (in-kernel stamps).  So: every wave's row requests first (a bare barrier, no
+        // memory wait), then the weights.
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

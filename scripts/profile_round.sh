@@ -28,4 +28,6 @@ f=$(find $out/cycle -name '*kernel_stats.csv' | head -1)
 f=$(find $out/pmc -name '*counter_collection.csv' | head -1)
 [ -n "$f" ] && python3 scripts/pmc_traffic.py $f profiles/${tag}_pmc_fetch_size${suffix}.json $model $batch $k > profiles/${tag}_pmc_fetch_size${suffix}.txt
 cp profiles/${tag}_*${suffix}* $out/ 2>/dev/null || true
+# gpurun merges gpurun_out/ back only below 64 MiB: keep the logs and summaries, drop the raw traces
+rm -rf $out/bench $out/cycle $out/pmc
 echo "profiles written: $(ls profiles/${tag}_*${suffix}* | tr '\n' ' ')"
