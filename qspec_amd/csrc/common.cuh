@@ -156,6 +156,32 @@ __device__ __forceinline__ void dpp_add_tree421_x4(float (&p)[4]) {
         : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));
     p[0] = t0; p[1] = t1; p[2] = t2; p[3] = t3;
 }
+// a, b += a, b of lane ^ 1 (four independent values, interleaved: no wait states in between)
+__device__ __forceinline__ void dpp_add_xor1_x4(f32x2& a, f32x2& b) {
+    float t0, t1, t2, t3;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)   // early clobber: t0 is written before the later inputs are read
+        : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
+    a = f32x2{t0, t1};
+    b = f32x2{t2, t3};
+}
+// x + x[lane ^ 32] and x + x[lane ^ 16] on the VALU (gfx950 v_permlane32_swap / v_permlane16_swap: the odd half / the odd
+// rows of the first register change places with the even half / rows of the second; with both = x the two registers then
+// hold the two operands of the butterfly level in every lane).  Inline asm: clang 19's builtin mis-pairs the two results.
+__device__ __forceinline__ float add_xor32(float x) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float add_xor16(float x) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
 // lane ^ 16 through the LDS crossbar without an address register (ds_swizzle, bit mode: and 0x1f, xor 0x10)
 __device__ __forceinline__ float swizzle_xor16_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));

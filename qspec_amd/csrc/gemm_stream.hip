@@ -39,7 +39,7 @@ __device__ __forceinline__ T wload(const void* p) {
 }
 
 enum { SEPI_PLAIN = 0, SEPI_QKV = 1, SEPI_GATEUP = 2, SEPI_RESID = 3, SEPI_PARTIAL = 4 };   // RESID: plain + fp16 residual add
-enum { PRO_Q = 0, PRO_LN = 1, PRO_LNH = 2, PRO_LN1 = 3 };   // LN1: norm of hidden_in alone (no delta, no write-back)  // LNH: LN by a few producer workgroups, handed to the rest through L2
+enum { PRO_Q = 0, PRO_LN = 1, PRO_LNH = 2, PRO_LN1 = 3, PRO_LNS = 4, PRO_LN1S = 5 };   // ..S: the norm on four waves of its own (see the kernel)   // LN1: norm of hidden_in alone (no delta, no write-back)  // LNH: LN by a few producer workgroups, handed to the rest through L2
 
 struct StreamArgs {
     const int8_t* xq;       // PRO_Q : [M, K/2] packed int4 activations
@@ -304,6 +304,143 @@ __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs
 #endif
 }
 
+// ---- The same norm + quantiser with ONE WAVE PER ROW: no LDS, no barrier inside.  Lane l of the row's wave plays the
+// reference's virtual threads t = 16 l + i, i = 0..15, i.e. holds the 16 CONSECUTIVE elements 1024 it + 16 l + i of every
+// 1024-block `it` (two 16-byte loads per block, one 8-byte LDS store):
+//   first butterfly (t ^ 16, 8, 4, 2, 1):  lane ^ 1 as DPP adds on all 16 partials, then i ^ 8, 4, 2, 1 in registers;
+//   second butterfly over the 32 warp sums (warp = t >> 5 = lane >> 1; levels 16, 8, 4, 2, 1): lane ^ 32 and lane ^ 16 with
+//   v_permlane32_swap / v_permlane16_swap, lane ^ 8, 4, 2 as DPP adds.
+// Same pairings in the same order as ref_tree_sum_1024, every addition commutative: the same bits.  On the critical path
+// of all eight waves this form is SLOWER than ln_compute (four waves x 550 instructions against eight x 430 with three
+// barriers); it is what the split forms run on their four norm waves, where having no barrier is the point.
+template <int NI>
+struct LnwRegs {
+    u32x4 x[NI > 0 ? NI : 1][2], d[NI > 0 ? NI : 1][2];
+};
+
+template <int NI, bool HASD>
+__device__ __forceinline__ void lnw_load(const StreamArgs& a, int row, LnwRegs<NI>& rg) {
+    const int lane = threadIdx.x & 63;
+    const int rr = row < a.M ? row : 0;   // no branch around a load: clamped, the value is discarded
+    const f16* xp = a.hidden_in + (size_t)rr * a.K + 16 * lane;
+    const f16* dp = (a.delta ? a.delta : a.hidden_in) + (size_t)rr * a.K + 16 * lane;
+#pragma unroll
+    for (int it = 0; it < NI; it++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            rg.x[it][h] = *reinterpret_cast<const u32x4*>(xp + it * 1024 + 8 * h);
+            if (HASD) rg.d[it][h] = *reinterpret_cast<const u32x4*>(dp + it * 1024 + 8 * h);
+        }
+}
+
+__device__ __forceinline__ float lnw_tree(f32x2 (&p)[8]) {
+    dpp_add_xor1_x4(p[0], p[1]);
+    dpp_add_xor1_x4(p[2], p[3]);
+    dpp_add_xor1_x4(p[4], p[5]);
+    dpp_add_xor1_x4(p[6], p[7]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) p[k] = p[k] + p[k + 4];
+    p[0] = p[0] + p[2];
+    p[1] = p[1] + p[3];
+    p[0] = p[0] + p[1];
+    float s = p[0][0] + p[0][1];
+    s = add_xor32(s);
+    s = add_xor16(s);
+    s = dpp_add_xor<8>(s);
+    s = dpp_add_xor<4>(s);
+    s = dpp_add_xor<2>(s);
+    return readlane_f(s, 0);
+}
+
+// row < a.M (the caller skips the others); the arithmetic, step for step, is ln_compute's (see there for the proofs of
+// the maximum riding on the variance pass, the dead clamp and the nibble splice)
+template <int NI, bool HASD>
+__device__ __forceinline__ void lnw_compute(const StreamArgs& a, int row, LnwRegs<NI>& rg, unsigned char* xq_lds, int RS,
+                                            float* xs_lds, bool write_hidden) {
+    const int lane = threadIdx.x & 63;
+    f32x2 v[NI > 0 ? NI : 1][8];
+#pragma unroll
+    for (int it = 0; it < NI; it++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            f16x8 x8 = __builtin_bit_cast(f16x8, rg.x[it][h]);
+            if (HASD && a.delta) {   // uniform; no load inside
+                const f16x8 d8 = __builtin_bit_cast(f16x8, rg.d[it][h]);
+#pragma unroll
+                for (int e = 0; e < 8; e++) x8[e] = f2h(h2f(x8[e]) + h2f(d8[e]));
+            }
+            if (HASD && write_hidden)
+                *reinterpret_cast<u32x4*>(a.hidden_out + (size_t)row * a.K + it * 1024 + 16 * lane + 8 * h) =
+                    __builtin_bit_cast(u32x4, x8);
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[it][4 * h + k] = f32x2{h2f(x8[2 * k]), h2f(x8[2 * k + 1])};
+        }
+    }
+    f32x2 p[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        f32x2 s = v[0][k];
+#pragma unroll
+        for (int it = 1; it < NI; it++) s = s + v[it][k];
+        p[k] = s;
+    }
+    constexpr bool pow2 = (NI & (NI - 1)) == 0;
+    constexpr float invH = 1.0f / (float)(NI > 0 ? NI * 1024 : 1);
+    float mean = lnw_tree(p);
+    mean = pow2 ? mean * invH : mean / (float)a.K;
+    const f32x2 m2 = {mean, mean};
+    float dm = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        f32x2 s;
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
+            const f32x2 d = v[it][k] - m2;
+            v[it][k] = d;
+            s = it == 0 ? d * d : __builtin_elementwise_fma(d, d, s);
+            dm = fmaxf(fmaxf(dm, __builtin_fabsf(d[0])), __builtin_fabsf(d[1]));
+        }
+        p[k] = s;
+    }
+    float var = lnw_tree(p);
+    const float dmax = wave_max_uniform(dm);
+    var = pow2 ? var * invH : var / (float)a.K;
+    const float rstd = 1.0f / __builtin_sqrtf(var + a.eps);
+    const f16 a16 = f2h(dmax * rstd), floor16 = f2h(1e-6f);
+    const float amax = h2f(a16 > floor16 ? a16 : floor16);
+    // 7 / amax (the multiplier) in the even lanes, amax / 7 (the stored scale) in the odd ones: one division
+    const bool second = (lane & 1) != 0;
+    const float ql = (second ? amax : 7.0f) / (second ? 7.0f : amax);
+    if (lane == 1) xs_lds[row] = h2f(f2h(ql));
+    const float sq = readlane_f(ql, 0);
+    const f32x2 r2 = {rstd, rstd}, s2 = {sq, sq}, mg2 = {12582920.0f, 12582920.0f};
+#pragma unroll
+    for (int it = 0; it < NI; it++) {
+        u32 half[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {   // 4 elements -> 16 bits (upper bits: junk)
+            u32 b[4];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                f32x2 t = (v[it][2 * q4 + h] * r2) * s2;
+                t = t + mg2;
+                float t0 = t[0], t1 = t[1];
+                asm("" : "+v"(t0), "+v"(t1));
+                b[2 * h] = __builtin_bit_cast(u32, t0);
+                b[2 * h + 1] = __builtin_bit_cast(u32, t1);
+            }
+            u32 w = (b[1] << 4) | b[0];
+            w = (b[2] << 8) | w;
+            half[q4] = (b[3] << 12) | w;
+        }
+        // bytes 0, 1 of the even piece, bytes 0, 1 of the odd piece
+        u32x2 o;
+        o[0] = __builtin_amdgcn_perm(half[1], half[0], 0x05040100u) ^ 0x88888888u;
+        o[1] = __builtin_amdgcn_perm(half[3], half[2], 0x05040100u) ^ 0x88888888u;
+        *reinterpret_cast<u32x2*>(xq_lds + (size_t)row * RS + it * 512 + 8 * lane) = o;
+    }
+}
+
 // NW waves; UB steps of 64 packed bytes per wave and batch (K/2 = 64 * NW * UB * NB bytes, NB batches per tile);
 // NI = K / 1024 for the LN prologue (0 otherwise).
 #ifdef QS_STREAM_STAMPS
@@ -313,8 +450,23 @@ __device__ __forceinline__ void ln_compute(const StreamArgs& a, int base, LnRegs
 #endif
 // MT = 16-token tiles per workgroup (1: M <= 16; 2: M <= 32, PRO_Q only, activation fragments kept PACKED in registers
 // and widened at each use -- 8 VGPRs per step and tile would not fit beside the weight ring at 1024 threads).
+// PRO_LNS / PRO_LN1S ("split", M <= 4): the workgroup has NW + 4 waves.  Waves 0 .. NW-1 are the STREAM waves: they request
+// the workgroup's first 1 + PF weight tiles into registers right away and then wait; waves NW .. NW+3 are NORM waves: one
+// row each (lnw_compute: no barrier inside), then they retire.  One barrier joins them.  Why: a CU holds ~32 KB of loads in
+// flight and a wave that issues a load beyond that stalls AT THE ISSUE, so weight requests inside the norm's instruction
+// stream stop the norm ("Measured and rejected") and HBM idled underneath it; waves that have nothing else to
+// do can stall, provided no barrier of the norm waits for them.
+template <int PRO>
+constexpr bool pro_split() { return PRO == PRO_LNS || PRO == PRO_LN1S; }
+// Tiles beyond the first that the stream waves request up front.  Measured in the engine (same box, ms per cycle): unsplit
+// 7.96, split with 1 / 2 extra tiles 7.92 / 7.95; gate_up with 3 / 4 / 5 extra tiles 14.3 / 14.5 / 15.2 us per launch
+// against 13.4: the eight waves' requests are not tile-major (a wave takes in-flight slots for its later tiles before
+// another wave has requested its part of tile 0), and every tile's cross-wave reduction then waits for the last part.
+#ifndef QS_LN_PF
+#define QS_LN_PF 1
+#endif
 template <int EPI, int PRO, int NW, int UB, int NI, int MT = 1>
-__global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a) {
+__global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w4a4_stream_kernel(StreamArgs a) {
     static_assert(MT == 1 || (PRO == PRO_Q && NW >= 8), "two token tiles: (xq, xs) input, >= 512 threads for the epilogue");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef QS_STREAM_STAMPS
@@ -323,7 +475,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
     QS_SSTAMP(0);
     constexpr int NG = NW / 4;
     constexpr int RB = NW == 4 ? 4 : (NW == 8 ? 2 : 1);
-    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr bool SPLIT = pro_split<PRO>();
+    const int tid = threadIdx.x, lane = tid & 63;   // (split: the norm waves are tid >= NW * 64: no epilogue thread among them)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int Kb = a.K >> 1, RS = Kb + 32;
@@ -455,6 +608,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
     u32x4 w[UB];
     Pre pre = {};
     const uint8_t* wp0 = wptr(tile, 0);
+    // split forms: tiles beyond the first that the stream waves request underneath the norm (one batch per tile there)
+    constexpr int PF = SPLIT ? QS_LN_PF : 0;
+    u32x4 pfw[PF > 0 ? PF : 1][UB];
+    Pre pfpre[PF > 0 ? PF : 1];
 
     // ---- prologue: activations -> LDS.  Their loads are issued BEFORE the first weight batch (results return in
     // issue order), the arithmetic runs underneath the weights' latency.
@@ -540,6 +697,44 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
                 __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+    } else if (SPLIT) {
+        constexpr bool HASD = PRO == PRO_LNS;
+        if (tid >= NW * 64) {   // ---- norm waves (wave-uniform branch): row = wave - NW, then retire
+            const int row = wave - NW;
+            LnwRegs<NI> rg;
+            lnw_load<NI, HASD>(a, row, rg);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();   // #0: every row request is out before any weight request (in-order L1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (row < a.M) lnw_compute<NI, HASD>(a, row, rg, xq_lds, RS, xs_lds, blockIdx.x == 0 && a.hidden_out != nullptr);
+            __syncthreads();                // #1: publishes xq_lds / xs_lds
+            return;                         // retired waves leave the workgroup's later barriers
+        }
+        __builtin_amdgcn_s_barrier();       // #0
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; u++) w[u] = wload<u32x4>(wp0 + step_off<NW, UB>(wave, u));
+        __builtin_amdgcn_sched_barrier(0);
+        load_pre(pre, tile);
+        __builtin_amdgcn_sched_barrier(0);
+        // The next PF tiles, where the workgroup has them (uniform branches around loads cost nothing HERE: a CU holds one
+        // tile's worth of loads in flight, so tile d + 1 could not be requested before tile d has returned anyway, and
+        // this wave has nothing to do but wait).
+#pragma unroll
+        for (int d = 1; d <= PF; d++) {
+            if (d < my_tiles) {
+                const uint8_t* wpd = wptr(tile + d * (int)gridDim.x, 0);
+#pragma unroll
+                for (int u = 0; u < UB; u++) pfw[d - 1][u] = wload<u32x4>(wpd + step_off<NW, UB>(wave, u));
+                load_pre(pfpre[d - 1], tile + d * (int)gridDim.x);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // #1 (a bare barrier: __syncthreads() is fine too, the loads above are what this wave waits for next anyway; the
+        // norm waves drained their LDS writes in front of theirs, the clobber keeps this wave's LDS reads behind it)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     } else if (PRO == PRO_LN || PRO == PRO_LN1) {
         constexpr bool HASD = PRO == PRO_LN;
         LnRegs<NI, RB> rg;
@@ -608,7 +803,38 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
     // reductions and epilogues.  The last unit is peeled (nothing to refill), so the loop body has no branch
     // around a load and the waits hipcc inserts are the exact counted ones.
     QS_SSTAMP(2);
-    for (int q = 0; q < n_units - 1; q++) {
+    int n_left = n_units;
+    if constexpr (PF > 0) {   // split forms (one batch per tile): tile 0 from w, tiles 1 .. PF from the prefetched registers
+        {
+            const bool more = PF + 1 < my_tiles;   // uniform
+            const int tn = tile + (PF + 1) * (int)gridDim.x;
+            Pre npre = pre;
+            if (more) load_pre(npre, tn);          // (a branch around loads: everything in flight has arrived by now)
+#pragma unroll
+            for (int u = 0; u < UB; u++) use(w[u], 0, u);
+            if (more) {
+                const uint8_t* wp = wptr(tn, 0);
+#pragma unroll
+                for (int u = 0; u < UB; u++) w[u] = wload<u32x4>(wp + step_off<NW, UB>(wave, u));
+            }
+            finish(tile, par, pre);
+            par ^= 1;
+            pre = npre;
+        }
+#pragma unroll
+        for (int d = 1; d <= PF; d++) {
+            if (d < my_tiles) {   // uniform; no load inside
+#pragma unroll
+                for (int u = 0; u < UB; u++) use(pfw[d - 1][u], 0, u);
+                finish(tile + d * (int)gridDim.x, par, pfpre[d - 1]);
+                par ^= 1;
+            }
+        }
+        tile += (PF + 1) * (int)gridDim.x;
+        n_left = my_tiles - (PF + 1);
+    }
+    if (PF == 0 || n_left > 0) {
+    for (int q = 0; q < n_left - 1; q++) {
         int nb = b + 1, nt = tile;
         if (nb == NB) {
             nb = 0;
@@ -639,6 +865,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a4_stream_kernel(StreamArgs a)
     for (int u = 0; u < UB; u++) use(w[u], b, u);
     QS_SSTAMP(4);
     finish(tile, par, pre);
+    }
     QS_SSTAMP(5);
 #ifdef QS_STREAM_STAMPS
     if (PRO != PRO_Q && a.hidden_out && blockIdx.x == 100 && tid == 0) {  // debug build only: stamps into the tail of hidden_out
@@ -1104,8 +1331,17 @@ static int launch_stream_inst(const StreamArgs& a, hipStream_t st) {
         const int per = (a.ntiles + cap - 1) / cap;
         grid = (a.ntiles + per - 1) / per;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64 + (pro_split<PRO>() ? 256 : 0)), lds, st, a);
     return 0;
+}
+
+static int g_ln_split = -1;   // QSPEC_LN_SPLIT=0: the norm on the streaming waves themselves
+static bool ln_split() {
+    if (g_ln_split < 0) {
+        const char* e = getenv("QSPEC_LN_SPLIT");
+        g_ln_split = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_ln_split != 0;
 }
 
 template <int EPI>
@@ -1142,12 +1378,24 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
     if (!a.delta && !a.hidden_out) {   // pure norm of hidden_in: half the prologue loads
         // (16 waves instead of 8 at M <= 4 -- one row per 256-thread group, 4 waves per SIMD -- measured equal: qkv 9.4 vs
         // 9.1 us, gate_up 15.4 vs 15.6; the prologue is bound by the CU's VALU issue, not by one wave's latency chain)
+        if (a.M <= 4 && ln_split()) {   // (K = 8192: the row-wave's 128 values per lane do not fit 168 VGPRs)
+            if (a.K == 4096) return launch_stream_inst<EPI, PRO_LN1S, 8, 4, 4>(a, st);
+            if (a.K == 5120) return launch_stream_inst<EPI, PRO_LN1S, 8, 5, 5>(a, st);
+            if (a.K == 2048) return launch_stream_inst<EPI, PRO_LN1S, 4, 4, 2>(a, st);
+            if (a.K == 1024) return launch_stream_inst<EPI, PRO_LN1S, 4, 2, 1>(a, st);
+        }
         if (a.K == 4096) return launch_stream_inst<EPI, PRO_LN1, 8, 4, 4>(a, st);
         if (a.K == 8192) return launch_stream_inst<EPI, PRO_LN1, 8, 8, 8>(a, st);
         if (a.K == 5120) return launch_stream_inst<EPI, PRO_LN1, 8, 5, 5>(a, st);
         if (a.K == 2048) return launch_stream_inst<EPI, PRO_LN1, 4, 4, 2>(a, st);
         if (a.K == 1024) return launch_stream_inst<EPI, PRO_LN1, 4, 2, 1>(a, st);
         return -1;
+    }
+    if (a.M <= 4 && ln_split()) {
+        if (a.K == 4096) return launch_stream_inst<EPI, PRO_LNS, 8, 4, 4>(a, st);
+        if (a.K == 5120) return launch_stream_inst<EPI, PRO_LNS, 8, 5, 5>(a, st);
+        if (a.K == 2048) return launch_stream_inst<EPI, PRO_LNS, 4, 4, 2>(a, st);
+        if (a.K == 1024) return launch_stream_inst<EPI, PRO_LNS, 4, 2, 1>(a, st);
     }
     if (a.K == 4096) return launch_stream_inst<EPI, PRO_LN, 8, 4, 4>(a, st);
     if (a.K == 8192) return launch_stream_inst<EPI, PRO_LN, 8, 8, 8>(a, st);
