@@ -460,8 +460,9 @@ template <int PRO>
 constexpr bool pro_split() { return PRO == PRO_LNS || PRO == PRO_LN1S; }
 // Tiles beyond the first that the stream waves request up front.  Measured in the engine (same box, ms per cycle): unsplit
 // 7.96, split with 1 / 2 extra tiles 7.92 / 7.95; gate_up with 3 / 4 / 5 extra tiles 14.3 / 14.5 / 15.2 us per launch
-// against 13.4: the eight waves' requests are not tile-major (a wave takes in-flight slots for its later tiles before
-// another wave has requested its part of tile 0), and every tile's cross-wave reduction then waits for the last part.
+// against 13.4 -- also with a vmcnt(0) between the tiles' requests (13.3 / 13.7 / 14.0 / 14.6 us for 1 / 2 / 3 / 4): the
+// stream waves reach the joining barrier only when their last request has been ISSUED, i.e. when all but one of the
+// requested tiles have returned, and the serial consumption of the hoard then costs more than the overlap won.
 #ifndef QS_LN_PF
 #define QS_LN_PF 1
 #endif
