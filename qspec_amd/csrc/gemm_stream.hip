@@ -14,8 +14,12 @@
 //   * PRO_LN: the residual add + LayerNorm-no-gamma + per-token int4 quantisation that feeds qkv_proj / gate_up
 //     (layernorm_kernels.cu:569-716, quarot_llama.py:373-388) runs as the PROLOGUE of the GEMM, redundantly in every
 //     workgroup, underneath the latency of the first weight batch: the LN kernel and its launch boundary disappear.
-//     It is the same code path as norm_quant.hip:ln_kernel (reference reduction tree, bit for bit), batched over
+//     It is the same arithmetic as norm_quant.hip:ln_kernel (reference reduction tree, bit for bit), batched over
 //     rows.  Workgroup 0 also writes the updated residual stream (hidden_out != hidden_in: ping-pong, no race).
+//     Forms: PRO_LN / PRO_LN1 (every wave of the workgroup takes part in the norm; LN1 = no delta, no write-back),
+//     PRO_LNS / PRO_LN1S (M <= 4, what the draft pass launches: four extra norm waves, one row each with no barrier
+//     inside, while the streaming waves already request their first two tiles), PRO_LNH (a few producer workgroups
+//     hand the rows over through L2; M >= 8, not the default any more).
 //   * Epilogues as in gemm.hip (plain / RoPE + KV-cache write / silu(gate)*up), with their operands (channel
 //     scale, cos/sin, position, slot) prefetched together with the tile's weights.
 //   * Cross-wave K reduction through LDS in wave order: int32, exact, deterministic.
@@ -39,7 +43,7 @@ __device__ __forceinline__ T wload(const void* p) {
 }
 
 enum { SEPI_PLAIN = 0, SEPI_QKV = 1, SEPI_GATEUP = 2, SEPI_RESID = 3, SEPI_PARTIAL = 4 };   // RESID: plain + fp16 residual add
-enum { PRO_Q = 0, PRO_LN = 1, PRO_LNH = 2, PRO_LN1 = 3, PRO_LNS = 4, PRO_LN1S = 5 };   // ..S: the norm on four waves of its own (see the kernel)   // LN1: norm of hidden_in alone (no delta, no write-back)  // LNH: LN by a few producer workgroups, handed to the rest through L2
+enum { PRO_Q = 0, PRO_LN = 1, PRO_LNH = 2, PRO_LN1 = 3, PRO_LNS = 4, PRO_LN1S = 5 };   // (see the header)
 
 struct StreamArgs {
     const int8_t* xq;       // PRO_Q : [M, K/2] packed int4 activations
