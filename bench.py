@@ -138,6 +138,10 @@ def measure_dominant_kernel(model, engine, reps=5):
                 and ops.rowwise_scaled_linear_s4s4_residual_supported(B, cfg.hidden_size, cfg.hidden_size)
                 and ops.rowwise_scaled_linear_s4s4_residual_supported(B, cfg.hidden_size, cfg.intermediate_size))
     gu_out = s.act_buffer_gate_up[:B]
+    # o_proj at <= 4 tokens: fp16 head-Hadamard rows + partial row maxima, quantised in the launch's prologue (model.py)
+    hq = (ln_fused and model.HADAMARD_QUANT_IN_OPROJ and model.MERGE_IN_HADAMARD and model.head_had_K == 1
+          and ops.heads_hadamard_merged_spread_supported(B, cfg.num_attention_heads, cfg.head_dim)
+          and ops.rowwise_scaled_linear_s4s4_residual_hq_supported(B, cfg.hidden_size, cfg.q_size))
 
     def launch(layer, kc, vc, kind):
         if kind == "qkv":
@@ -153,7 +157,10 @@ def measure_dominant_kernel(model, engine, reps=5):
                 ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq, sc, layer.qkv_proj.weight, layer.qkv_proj._scales(), None,
                                                                s.act_buffer_qkv[:B])
         elif kind == "o":
-            if ln_fused:
+            if hq:
+                ops.rowwise_scaled_linear_s4s4_residual_hq(s.act_buffer_had[:B], s.had_part_amax[:B], 1.0, layer.o_proj.weight,
+                                                           layer.o_proj._scales(), hid, hid)
+            elif ln_fused:
                 ops.rowwise_scaled_linear_s4s4_residual(xq, sc, layer.o_proj.weight, layer.o_proj._scales(), hid, hid)
             else:
                 ops.rowwise_scaled_linear_cutlass_s4s4_unified(xq, sc, layer.o_proj.weight, layer.o_proj._scales(), None, o)
@@ -176,6 +183,8 @@ def measure_dominant_kernel(model, engine, reps=5):
         w = n * kb + 2 * n                                     # packed weights + channel scales
         if ln_fused and kd in ("qkv", "gate_up"):
             act_in = B * (2 * kb) * 2                          # the residual stream, fp16 (normed in the prologue)
+        elif hq and kd == "o":
+            act_in = B * (2 * kb) * 2 + B * 8 * 4              # fp16 rows + partial maxima (quantised in the prologue)
         else:
             act_in = B * kb + 2 * B                            # packed int4 activations + scales
         if ln_fused and kd in ("o", "down"):

@@ -127,6 +127,16 @@ int qspec_rowwise_scaled_linear_s4s4_residual(const int8_t* xq, const qspec_half
                                               int M, int N, int K, void* stream);
 int qspec_rowwise_scaled_linear_s4s4_residual_supported(int M, int N, int K);
 
+/* qspec_rowwise_scaled_linear_s4s4_residual fed with UNQUANTISED fp16 rows x16 [M, K] and n_parts partial row maxima each
+ * (part_amax [M, n_parts] fp32): row-absmax int4 quantisation (quant.cu:102-167: scale = h(h(amax / 7) * h(clip_ratio)),
+ * q = clamp(rne(h(x / scale)), -8, 7), all-zero row -> 0) in the prologue of the GEMM launch.  M <= 4, K = 4096,
+ * n_parts = 8 (what qspec_heads_hadamard_merged_spread leaves). */
+int qspec_rowwise_scaled_linear_s4s4_residual_hq(const qspec_half* x16, const float* part_amax, int n_parts,
+                                                 float clip_ratio, const int8_t* wq, const qspec_half* ws,
+                                                 const qspec_half* resid_in, qspec_half* resid_out, int M, int N, int K,
+                                                 void* stream);
+int qspec_rowwise_scaled_linear_s4s4_residual_hq_supported(int M, int N, int K, int n_parts);
+
 /* bitblas.Matmul.__call__(x, w ^ 0x88, output=C, scale=ws, bias=bias)  (quarot_nn/linear.py:102-124,156-211).
  *   Takes the SAME wq buffer as the s4s4 op (no XOR copy).  x [M,K] fp16.
  *   workspace: NULL, or qspec_w4a16_workspace_bytes() bytes ZERO-FILLED once before first use: lets narrow layers
@@ -301,6 +311,17 @@ int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_hal
 int qspec_heads_hadamard_merged(const void* attn_workspace, int max_tokens, int n_splits, qspec_half* out_f16, int8_t* q,
                                 qspec_half* scale, float had_scale, float clip_ratio, int tokens, int heads,
                                 int head_dim, void* stream);
+
+/* The same split merge + head Hadamard SPREAD over 8 workgroups per token (32 heads of 128; each workgroup owns 16 columns
+ * of every head -- the transform mixes heads, never columns): fp16 rows out_f16 [tokens, heads * head_dim] plus
+ * part_amax [tokens, 8] fp32, max |out| of each workgroup's share.  The quantiser of quarot_llama.py:235-238
+ * (Quantizer -> quant.cu:102-167) then runs in the prologue of the o_proj launch:
+ * qspec_rowwise_scaled_linear_s4s4_residual_hq below.  Same bits as qspec_heads_hadamard_merged(q != NULL) followed by
+ * qspec_rowwise_scaled_linear_s4s4_residual. */
+int qspec_heads_hadamard_merged_spread(const void* attn_workspace, int max_tokens, int n_splits, qspec_half* out_f16,
+                                       float* part_amax, float had_scale, int tokens, int heads, int head_dim,
+                                       void* stream);
+int qspec_heads_hadamard_merged_spread_supported(int tokens, int heads, int head_dim);
 
 /* ---- token side ------------------------------------------------------------------------------- */
 

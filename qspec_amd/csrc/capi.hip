@@ -52,7 +52,7 @@ static int tiled_min_m() {
 
 extern "C" {
 
-int qspec_abi_version(void) { return 2; }
+int qspec_abi_version(void) { return 3; }
 const char* qspec_last_error(void) { return g_err; }
 
 int qspec_rms_norm_general_fuse_sum_i4(int8_t* out_q, const qspec_half* x, qspec_half* input_sum, qspec_half* scaling,
@@ -187,6 +187,22 @@ int qspec_rowwise_scaled_linear_s4s4_residual(const int8_t* xq, const qspec_half
 int qspec_rowwise_scaled_linear_s4s4_residual_supported(int M, int N, int K) {
     return qspec::gemm_w4a4_stream_supported(M, N, K, false) ? 1 : 0;
 }
+int qspec_rowwise_scaled_linear_s4s4_residual_hq_supported(int M, int N, int K, int n_parts) {
+    return qspec::gemm_w4a4_stream_residual_hq_supported(M, N, K, n_parts) ? 1 : 0;
+}
+int qspec_rowwise_scaled_linear_s4s4_residual_hq(const qspec_half* x16, const float* part_amax, int n_parts,
+                                                 float clip_ratio, const int8_t* wq, const qspec_half* ws,
+                                                 const qspec_half* resid_in, qspec_half* resid_out, int M, int N, int K,
+                                                 void* stream) {
+    const char* op = "qspec_rowwise_scaled_linear_s4s4_residual_hq";
+    if (M < 0 || N < 0) return fail("%s: negative size", op);
+    if (M == 0 || N == 0) return 0;
+    NONNULL(op, x16); NONNULL(op, part_amax); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, resid_in); NONNULL(op, resid_out);
+    if (!qspec::gemm_w4a4_stream_residual_hq_supported(M, N, K, n_parts))
+        return fail("%s: need M <= 4, K = 4096, n_parts = 8, N %% 16 == 0 (M=%d N=%d K=%d n_parts=%d)", op, M, N, K, n_parts);
+    return finish(op, qspec::gemm_w4a4_stream_residual_hq(CH(x16), part_amax, n_parts, clip_ratio, wq, CH(ws), CH(resid_in),
+                                                          H(resid_out), M, N, K, ST));
+}
 size_t qspec_w4a16_workspace_bytes(void) { return qspec::gemm_w4a16_ws_bytes(); }
 int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* ws, const qspec_half* bias,
                        qspec_half* out, int M, int N, int K, void* workspace, void* stream) {
@@ -282,6 +298,21 @@ int qspec_heads_hadamard_merged(const void* attn_workspace, int max_tokens, int 
     if (head_dim != 128 || !(heads == 32 || heads == 64))
         return fail("%s: built for head_dim 128 and 32 / 64 heads (got %d x %d)", op, heads, head_dim);
     return finish(op, qspec::heads_hadamard_merge((const float*)attn_workspace, max_tokens, n_splits, H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, heads, head_dim, ST));
+}
+int qspec_heads_hadamard_merged_spread_supported(int tokens, int heads, int head_dim) {
+    return tokens >= 0 && tokens * 8 <= 1024 && heads == 32 && head_dim == 128;
+}
+int qspec_heads_hadamard_merged_spread(const void* attn_workspace, int max_tokens, int n_splits, qspec_half* out_f16,
+                                       float* part_amax, float had_scale, int tokens, int heads, int head_dim,
+                                       void* stream) {
+    const char* op = "qspec_heads_hadamard_merged_spread";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, attn_workspace); NONNULL(op, out_f16); NONNULL(op, part_amax);
+    if (!qspec_heads_hadamard_merged_spread_supported(tokens, heads, head_dim))
+        return fail("%s: built for 32 heads of 128 and at most 128 tokens (got %d x %d, %d tokens)", op, heads, head_dim, tokens);
+    return finish(op, qspec::heads_hadamard_merge_spread((const float*)attn_workspace, max_tokens, n_splits, H(out_f16),
+                                                         part_amax, had_scale, tokens, heads, head_dim, ST));
 }
 int qspec_embedding(const int64_t* ids, const qspec_half* table, qspec_half* out, int tokens, int hidden, int vocab,
                     void* stream) {

@@ -20,6 +20,9 @@
 //     PRO_LNS / PRO_LN1S (M <= 4, what the draft pass launches: four extra norm waves, one row each with no barrier
 //     inside, while the streaming waves already request their first two tiles), PRO_LNH (a few producer workgroups
 //     hand the rows over through L2; M >= 8, not the default any more).
+//   * PRO_RQ (M <= 4, K = 4096): fp16 rows + eight partial row maxima each (the spread head-Hadamard's output) -> the
+//     row-absmax int4 quantiser (quant.cu:102-167: scale = h(h(amax / 7) h(clip)), q = clamp(rne(h(x / scale)), -8, 7)) in
+//     the prologue of o_proj, under the latency of the workgroup's one weight tile.
 //   * Epilogues as in gemm.hip (plain / RoPE + KV-cache write / silu(gate)*up), with their operands (channel
 //     scale, cos/sin, position, slot) prefetched together with the tile's weights.
 //   * Cross-wave K reduction through LDS in wave order: int32, exact, deterministic.
@@ -43,7 +46,7 @@ __device__ __forceinline__ T wload(const void* p) {
 }
 
 enum { SEPI_PLAIN = 0, SEPI_QKV = 1, SEPI_GATEUP = 2, SEPI_RESID = 3, SEPI_PARTIAL = 4 };   // RESID: plain + fp16 residual add
-enum { PRO_Q = 0, PRO_LN = 1, PRO_LNH = 2, PRO_LN1 = 3, PRO_LNS = 4, PRO_LN1S = 5 };   // (see the header)
+enum { PRO_Q = 0, PRO_LN = 1, PRO_LNH = 2, PRO_LN1 = 3, PRO_LNS = 4, PRO_LN1S = 5, PRO_RQ = 6 };   // (see the header)
 
 struct StreamArgs {
     const int8_t* xq;       // PRO_Q : [M, K/2] packed int4 activations
@@ -53,6 +56,9 @@ struct StreamArgs {
     f16* hidden_out;        // PRO_LN: [M, K] updated residual stream (written by workgroup 0) or nullptr
     float eps;
     int* sync;              // PRO_LNH: hand-off workspace (gemm_w4a4_stream_sync_bytes(), zero-filled once)
+    const f16* x16;         // PRO_RQ: [M, K] fp16 rows
+    const float* part_amax; // PRO_RQ: [M, 8] partial maxima of |x16| per row
+    float clip;             // PRO_RQ: the quantiser's clip ratio
     const f16* resid_in;    // SEPI_RESID: [M, N] residual stream; resid_out = h(f(resid_in) + f(h(gemm)))
     f16* resid_out;         // SEPI_RESID: [M, N] (may alias resid_in: each element is read and written by one thread)
     const f16* x;           // W4A16: [M, K] fp16 activations, row stride ldx halves
@@ -702,6 +708,50 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w
                 __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+    } else if (PRO == PRO_RQ) {
+        // thread tid owns the 16-byte chunk tid of every row (K = 4096: 512 chunks per row = the 512 threads)
+        u32x4 xr[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            xr[i] = *reinterpret_cast<const u32x4*>(a.x16 + (size_t)min(i, a.M - 1) * a.K + 8 * tid);
+        float pv = a.part_amax[min(lane & 31, a.M * 8 - 1)];   // lanes 8 r .. 8 r + 7: the eight partial maxima of row r
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();   // every wave's row requests before any weight request (in-order L1, see PRO_LN)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; u++) w[u] = wload<u32x4>(wp0 + step_off<NW, UB>(wave, u));
+        __builtin_amdgcn_sched_barrier(0);
+        load_pre(pre, tile);
+        __builtin_amdgcn_sched_barrier(0);
+        pv = dpp_max_xor<1>(pv);
+        pv = dpp_max_xor<2>(pv);
+        pv = dpp_max_xor<4>(pv);
+        // scale = h(h(amax / 7) * h(clip)) and its correctly rounded reciprocal, lane-parallel (lane 8 r works on row r)
+        const f16 scl = f2h(h2f(f2h(pv / 7.0f)) * h2f(f2h(a.clip)));
+        const float scfl = h2f(scl), rcfl = 1.0f / scfl;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float scf = readlane_f(scfl, 8 * i), rcf = readlane_f(rcfl, 8 * i);
+            const f16x8 x8 = __builtin_bit_cast(f16x8, xr[i]);
+            // rni_sat(h(x / scale), -8, 7) as: clamp, then round to nearest even by adding 1.5 * 2^23 -- the two's
+            // complement integer is the low mantissa bits.  (The quotient of finite values by a non-zero scale is never
+            // NaN; an all-zero row has scale 0, every quotient NaN and the reference's 0 for it: selected per row below.)
+            u32 pk = 0;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                float dq = h2f(f2h(div3_h(h2f(x8[c]), rcf, scf)));
+                dq = __builtin_amdgcn_fmed3f(dq, -8.0f, 7.0f);
+                float mg = dq + 12582912.0f;
+                asm("" : "+v"(mg));
+                pk |= (__builtin_bit_cast(u32, mg) & 0xFu) << (4 * c);
+            }
+            if (scf == 0.0f) pk = 0;   // uniform
+            if (i < a.M) {
+                *reinterpret_cast<u32*>(xq_lds + (size_t)i * RS + 4 * tid) = pk;
+                if (tid == 0) xs_lds[i] = scf;
+            }
+        }
+        __syncthreads();   // publishes xq_lds / xs_lds
     } else if (SPLIT) {
         constexpr bool HASD = PRO == PRO_LNS;
         if (tid >= NW * 64) {   // ---- norm waves (wave-uniform branch): row = wave - NW, then retire
@@ -1562,6 +1612,18 @@ int gemm_w4a4_stream_residual(const StreamActs& x, const int8_t* wq, const f16* 
     return launch_stream<SEPI_RESID>(a, x.hidden_in != nullptr, st);
 }
 
+bool gemm_w4a4_stream_residual_hq_supported(int M, int N, int K, int nparts) {
+    return M >= 1 && M <= 4 && K == 4096 && nparts == 8 && N % 16 == 0 && N > 0;
+}
+int gemm_w4a4_stream_residual_hq(const f16* x16, const float* part_amax, int nparts, float clip, const int8_t* wq, const f16* ws,
+                                 const f16* resid_in, f16* resid_out, int M, int N, int K, hipStream_t st) {
+    if (!gemm_w4a4_stream_residual_hq_supported(M, N, K, nparts)) return -1;
+    StreamArgs a{};
+    a.x16 = x16; a.part_amax = part_amax; a.clip = clip;
+    a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
+    a.resid_in = resid_in; a.resid_out = resid_out;
+    return launch_stream_inst<SEPI_RESID, PRO_RQ, 8, 4, 4>(a, st);
+}
 int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                               const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
                               const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st) {

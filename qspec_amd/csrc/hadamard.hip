@@ -14,6 +14,8 @@
 // the lane mapping.  The reference needs 2 transposes + .contiguous() around
 // the head transform and a cuBLAS batched GEMM for the had28 mix; here each is
 // one kernel that reads the producer's layout directly.
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -471,6 +473,93 @@ __global__ __launch_bounds__(1024) void heads_hadamard_merge_kernel(const float*
     }
 }
 
+// The same merge + head transform SPREAD over 8 workgroups per token (32 heads): workgroup (t, y) owns the 16 columns
+// [16 y, 16 y + 16) of every head -- the head transform mixes heads, never columns, so the workgroups of a token share
+// nothing (fp16 output; the draft pass's quantiser needs the row maximum and stays with the one-workgroup form).
+// Why: a CU holds ~32 KB of loads in flight, and a token's 131 KB of split partials (written by other XCDs: they come
+// from memory, not from this XCD's L2) took one workgroup four round trips; 16 KB per workgroup is one.
+// Thread (wave w, lane): head = 4 w + (lane >> 4), column = lane & 15.  Same merge expression per element and the same
+// butterfly order (head strides 1, 2 across lanes; 4, 8, 16 across the waves through 2 KB of LDS) as the kernel above.
+// AMAX: also leaves max |output| of the workgroup's 512 values in part_amax[t][y] -- the o_proj launch of the draft pass
+// combines the eight maxima of a row and quantises the fp16 row in its own prologue (gemm_stream.hip, PRO_RQ), so the
+// eight workgroups of a token need no exchange here either.
+template <bool AMAX>
+__global__ __launch_bounds__(512) void heads_hadamard_merge_spread32_kernel(const float* __restrict__ ws_o,
+                                                                             const float* __restrict__ ws_ml, int S,
+                                                                             f16* __restrict__ out16, float had_scale,
+                                                                             float* __restrict__ part_amax) {
+    constexpr int NH = 32, D = 128, SMAX = 8;
+    __shared__ float xl[NH][16];
+    __shared__ float red8[8];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int hl = lane >> 4, col = lane & 15, head = 4 * w + hl, d = 16 * blockIdx.y + col;
+    const size_t th = (size_t)t * NH + head;
+    const float* ob = ws_o + th * S * D + d;
+    const float* mlb = ws_ml + th * S * 2;
+    float num = 0.0f, den = 0.0f, M = -__builtin_inff();
+    for (int s0 = 0; s0 < S; s0 += SMAX) {   // S <= 8 in one trip: every load in flight before the first use
+        float2 ml[SMAX];
+        float o[SMAX];
+#pragma unroll
+        for (int s2 = 0; s2 < SMAX; s2++) {
+            const int sc = min(s0 + s2, S - 1);
+            ml[s2] = *reinterpret_cast<const float2*>(mlb + sc * 2);
+            o[s2] = ob[(size_t)sc * D];
+        }
+        if (s0 == 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < SMAX; s2++) M = fmaxf(M, s2 < S ? ml[s2].x : -__builtin_inff());
+            for (int s2 = SMAX; s2 < S; s2++) M = fmaxf(M, mlb[s2 * 2]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < SMAX; s2++) {
+            if (s0 + s2 < S) {
+                const float m = ml[s2].x;
+                const float wgt = m == -__builtin_inff() ? 0.0f : aexp(m - M);
+                den = __builtin_fmaf(wgt, ml[s2].y, den);
+                num = __builtin_fmaf(wgt, o[s2], num);
+            }
+        }
+    }
+    float v = h2f(f2h(num / den));
+    {   // head strides 1 and 2: lanes ^ 16, ^ 32
+        float o = swizzle_xor16_f(v);
+        v = (lane & 16) ? (o - v) : (v + o);
+        o = shfl_xor_f(v, 32);
+        v = (lane & 32) ? (o - v) : (v + o);
+    }
+    xl[head][col] = v;
+    __syncthreads();
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = xl[4 * j + hl][col];
+#pragma unroll
+    for (int stride = 1; stride < 8; stride <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (!(j & stride)) {
+                const float a = x[j], b = x[j + stride];
+                x[j] = a + b;
+                x[j + stride] = a - b;
+            }
+    float r = x[0];
+#pragma unroll
+    for (int j = 1; j < 8; j++) r = w == j ? x[j] : r;
+    const f16 y = f2h(r * had_scale);
+    out16[(size_t)t * NH * D + (size_t)head * D + d] = y;
+    if (AMAX) {
+        const float am = wave_max_uniform(__builtin_fabsf(h2f(y)));
+        if (lane == 0) red8[w] = am;
+        __syncthreads();
+        if (tid == 0) {
+            float m8 = red8[0];
+#pragma unroll
+            for (int j = 1; j < 8; j++) m8 = fmaxf(m8, red8[j]);
+            part_amax[(size_t)t * 8 + blockIdx.y] = m8;
+        }
+    }
+}
+
 // partials: the workspace of paged_attention(..., out = nullptr) called for `max_tokens` = n_seqs * max_q_len tokens
 int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out_f16, int8_t* q, f16* scale,
                          float had_scale, float clip, int T, int heads, int d, hipStream_t st) {
@@ -479,6 +568,16 @@ int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out
     const float* ws_o = ws + paged_attention_ws_o_offset();
     const float* ws_ml = ws + paged_attention_ws_ml_offset(max_tokens, heads, d, n_splits);
     const bool quant = q != nullptr;
+    static int spread = -1;   // QSPEC_HHM_SPREAD=0: one workgroup per token also for the fp16 form
+    if (spread < 0) {
+        const char* e = getenv("QSPEC_HHM_SPREAD");
+        spread = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!quant && heads == 32 && spread && T * 8 <= 1024) {
+        hipLaunchKernelGGL(heads_hadamard_merge_spread32_kernel<false>, dim3(T, 8), dim3(512), 0, st, ws_o, ws_ml, n_splits,
+                           out_f16, had_scale, (float*)nullptr);
+        return 0;
+    }
 #define QS_HHM(NHV)                                                                                                \
     if (heads == NHV) {                                                                                             \
         if (quant)                                                                                                  \
@@ -492,6 +591,18 @@ int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out
     QS_HHM(32) QS_HHM(64)
 #undef QS_HHM
     return -1;
+}
+
+// fp16 output + 8 partial row maxima per token (see the kernel); 32 heads of 128
+int heads_hadamard_merge_spread(const float* ws, int max_tokens, int n_splits, f16* out_f16, float* part_amax, float had_scale,
+                                int T, int heads, int d, hipStream_t st) {
+    if (T == 0) return 0;
+    if (d != 128 || heads != 32 || n_splits < 1 || T > max_tokens || T * 8 > 1024) return -1;
+    const float* ws_o = ws + paged_attention_ws_o_offset();
+    const float* ws_ml = ws + paged_attention_ws_ml_offset(max_tokens, heads, d, n_splits);
+    hipLaunchKernelGGL(heads_hadamard_merge_spread32_kernel<true>, dim3(T, 8), dim3(512), 0, st, ws_o, ws_ml, n_splits, out_f16,
+                       had_scale, part_amax);
+    return 0;
 }
 
 int heads_hadamard(const f16* attn, f16* out_f16, int8_t* q, f16* scale, float had_scale, float clip, int T, int heads,

@@ -72,6 +72,13 @@ int gemm_w4a4_stream(const StreamActs& x, const int8_t* wq, const f16* ws, f16* 
                      hipStream_t st);
 int gemm_w4a4_stream_residual(const StreamActs& x, const int8_t* wq, const f16* ws, const f16* resid_in, f16* resid_out,
                               int M, int N, int K, hipStream_t st);
+// the same launch fed with fp16 rows + `nparts` partial row maxima each: row-absmax int4 quantisation (quant.cu:102-167) in the
+// prologue (M <= 4, K = 4096, nparts = 8: the spread head-Hadamard's output)
+int gemm_w4a4_stream_residual_hq(const f16* x16, const float* part_amax, int nparts, float clip, const int8_t* wq, const f16* ws,
+                                 const f16* resid_in, f16* resid_out, int M, int N, int K, hipStream_t st);
+bool gemm_w4a4_stream_residual_hq_supported(int M, int N, int K, int nparts);
+int heads_hadamard_merge_spread(const float* ws, int max_tokens, int n_splits, f16* out_f16, float* part_amax, float had_scale,
+                                int T, int heads, int d, hipStream_t st);
 int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                               const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
                               const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st);

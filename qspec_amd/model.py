@@ -101,6 +101,7 @@ class Scratch:
         # verify pass: raw fp32 K-slice sums of down_proj, finished inside the next norm (ops.w4a16_linear_partial)
         self.down_part = e(4, T, H, dtype=torch.float32) if T <= 16 else None
         self.tp_part = e(1, min(T, 32), H, dtype=torch.float32)   # TP verify pass (T <= 32): fp32 row-parallel partials
+        self.had_part_amax = e(min(T, 16), 8, dtype=torch.float32)  # draft pass (T <= 4): partial row maxima of the spread head Hadamard
         ws = ops.paged_attention_workspace_bytes(n_seqs * max_q_len, cfg.num_attention_heads, cfg.head_dim, n_splits)
         self.attn_ws = torch.zeros(ws, dtype=torch.uint8, device=device)   # ticket counters start at zero
 
@@ -163,6 +164,8 @@ class QuarotLlamaForCausalLM:
     # 14.30 vs separate 13.38 ms -- the standalone norm launch (3.4 us) beats the hand-off from 8 tokens on.
     FUSE_LN_MAX_M = int(__import__("os").environ.get("QSPEC_FUSE_LN_MAX_M", "4"))
     FUSE_LN = True
+    # draft pass, T <= 4, 32 heads of 128: head Hadamard spread over 8 workgroups per token + the quantiser in o_proj's prologue
+    HADAMARD_QUANT_IN_OPROJ = __import__("os").environ.get("QSPEC_HQ_OPROJ", "1") != "0"
 
     def _w4a16(self, x, lin, out):
         # every M reads the packed int4 buffer: streaming kernel (M <= 16), M-tiled kernel (prefill-sized M)
@@ -233,6 +236,10 @@ class QuarotLlamaForCausalLM:
                     and ops.ln_linear_s4s4_supported(T, 2 * cfg.intermediate_size, cfg.hidden_size)
                     and ops.rowwise_scaled_linear_s4s4_residual_supported(T, cfg.hidden_size, cfg.hidden_size)
                     and ops.rowwise_scaled_linear_s4s4_residual_supported(T, cfg.hidden_size, cfg.intermediate_size))
+        hq = (ln_fused and self.HADAMARD_QUANT_IN_OPROJ and self.MERGE_IN_HADAMARD and self.head_had_K == 1
+              and md.n_splits <= 64 and ops.heads_hadamard_merged_spread_supported(T, nh, hd)
+              and ops.rowwise_scaled_linear_s4s4_residual_hq_supported(T, cfg.hidden_size, cfg.q_size))
+        had16 = s.act_buffer_had[:T]
         for li, layer in enumerate(self.layers):
             kc, vc = kv_caches[li]
             qkv_w, qkv_s = layer.qkv_proj.weight, layer.qkv_proj._scales()
@@ -242,8 +249,18 @@ class QuarotLlamaForCausalLM:
                 # (hidden = residual + proj_out, :380,390), the norms read it in the qkv / gate_up prologues
                 ops.ln_qkv_rope_linear(hidden, None, None, eps, qkv_w, qkv_s, qkv, positions, self.cos_sin_cache,
                                        kc, vc, md.slot_mapping, nh, nkv, hd)                       # :373-374,183-226
-                self._attention_hadamard(qkv, row, kc, vc, md, T, s, attn, q1, sc, None)            # :213-238
-                ops.rowwise_scaled_linear_s4s4_residual(q1, sc, layer.o_proj.weight, layer.o_proj._scales(), hidden, hidden)
+                if hq:
+                    # merge + head Hadamard spread over 8 workgroups per token (fp16 + partial row maxima), the Quantizer
+                    # of :235-238 in the o_proj launch's prologue: same bits as the two calls of the else branch
+                    ops.paged_attention(qkv, row, kc, vc, md.block_tables, md.ctx_lens, md.q_start, T, md.max_q_len, nh,
+                                        self.sm_scale, md.n_splits, s.attn_ws, None)
+                    ops.heads_hadamard_merged_spread(s.attn_ws, md.ctx_lens.numel() * md.max_q_len, md.n_splits, T, nh, hd,
+                                                     self.head_had_scale, had16, s.had_part_amax[:T])
+                    ops.rowwise_scaled_linear_s4s4_residual_hq(had16, s.had_part_amax[:T], 1.0, layer.o_proj.weight,
+                                                               layer.o_proj._scales(), hidden, hidden)
+                else:
+                    self._attention_hadamard(qkv, row, kc, vc, md, T, s, attn, q1, sc, None)        # :213-238
+                    ops.rowwise_scaled_linear_s4s4_residual(q1, sc, layer.o_proj.weight, layer.o_proj._scales(), hidden, hidden)
                 ops.ln_gate_up_silu_linear(hidden, None, None, eps, gu_w, gu_s, act)                # :380-388,266-284
                 ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, q=q3, scale=sc)
                 ops.rowwise_scaled_linear_s4s4_residual(q3, sc, layer.down_proj.weight, layer.down_proj._scales(), hidden, hidden)

@@ -324,6 +324,21 @@ def rowwise_scaled_linear_s4s4_residual_supported(M: int, N: int, K: int) -> boo
     return bool(_lib.load().qspec_rowwise_scaled_linear_s4s4_residual_supported(M, N, K))
 
 
+def rowwise_scaled_linear_s4s4_residual_hq(x16, part_amax, clip_ratio, wq, w_scale, resid_in, resid_out):
+    """rowwise_scaled_linear_s4s4_residual on UNQUANTISED fp16 rows: the row-absmax int4 quantiser (quarot_llama.py:235-238,
+    quant.cu:102-167) runs in the GEMM's prologue from `part_amax` [M, n_parts] partial row maxima."""
+    M, K = x16.shape
+    N = wq.shape[0]
+    _call("qspec_rowwise_scaled_linear_s4s4_residual_hq", _chk(x16, "x16", _F16), _chk(part_amax, "part_amax", _F32),
+          part_amax.shape[1], float(clip_ratio), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
+          _chk(resid_in, "resid_in", _F16), _chk(resid_out, "resid_out", _F16), M, N, K, _stream())
+    return resid_out
+
+
+def rowwise_scaled_linear_s4s4_residual_hq_supported(M: int, N: int, K: int, n_parts: int = 8) -> bool:
+    return bool(_lib.load().qspec_rowwise_scaled_linear_s4s4_residual_hq_supported(M, N, K, n_parts))
+
+
 _w16_ws = {}
 
 
@@ -472,6 +487,17 @@ def heads_hadamard_merged(workspace, max_tokens, n_splits, tokens, heads, head_d
     _call("qspec_heads_hadamard_merged", workspace.data_ptr(), max_tokens, n_splits, _opt(out_f16, "out_f16", _F16),
           _opt(q, "q", _I8), _opt(scale, "scale", _F16), float(had_scale), float(clip_ratio), tokens, heads, head_dim,
           _stream())
+
+
+def heads_hadamard_merged_spread(workspace, max_tokens, n_splits, tokens, heads, head_dim, had_scale: float, out_f16, part_amax):
+    """heads_hadamard_merged spread over 8 workgroups per token: fp16 rows + part_amax [tokens, 8] (the quantiser then runs in
+    rowwise_scaled_linear_s4s4_residual_hq)."""
+    _call("qspec_heads_hadamard_merged_spread", workspace.data_ptr(), max_tokens, n_splits, _chk(out_f16, "out_f16", _F16),
+          _chk(part_amax, "part_amax", _F32), float(had_scale), tokens, heads, head_dim, _stream())
+
+
+def heads_hadamard_merged_spread_supported(tokens: int, heads: int, head_dim: int) -> bool:
+    return bool(_lib.load().qspec_heads_hadamard_merged_spread_supported(tokens, heads, head_dim))
 
 
 # ------------------------------------------------------------------ token side

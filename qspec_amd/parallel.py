@@ -159,9 +159,10 @@ class OneShotComm(TorchDistComm):
 
 class ThreadComm:
     """`world` ranks as threads of ONE process sharing one device (tests: a GPU box admits at most 6 processes on
-    its card, so the 8-rank shard ranges of Llama-3-70B are exercised in-process).  All ranks enqueue on the same
-    stream, so stream order = the order the barrier imposes: every rank's producer kernels are enqueued before rank
-    0 enqueues the reduction, and the result is copied back after it."""
+    its card, so the 8-rank shard ranges of Llama-3-70B are exercised in-process).  Every rank thread runs on a stream
+    of its own (so that the per-(device, stream) workspaces of qspec_amd.ops are per rank, as with one process per GPU);
+    the exchange is host-synchronised: a rank drains its stream before it publishes a tensor or lets the others go on.
+    Not capturable, not fast: a test communicator."""
 
     class Shared:
         def __init__(self, world: int):
@@ -174,29 +175,34 @@ class ThreadComm:
     def __init__(self, shared: "ThreadComm.Shared", rank: int):
         self.sh, self.rank, self.backend = shared, rank, "threads"
 
+    def _sync_wait(self):
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+        self.sh.barrier.wait()
+
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         sh = self.sh
         sh.slots[self.rank] = t
-        sh.barrier.wait()
+        self._sync_wait()
         if self.rank == 0:   # fixed rank order, fp32 accumulate, one rounding: what a one-shot all-reduce does
             acc = sh.slots[0].float()
             for r in range(1, sh.world):
                 acc = acc + sh.slots[r].float()
             sh.result = acc.to(t.dtype)
-        sh.barrier.wait()
+        self._sync_wait()
         t.copy_(sh.result)
-        sh.barrier.wait()
+        self._sync_wait()
         return t
 
     def all_gather(self, recv: torch.Tensor, send: torch.Tensor) -> torch.Tensor:
         sh = self.sh
         sh.slots[self.rank] = send
-        sh.barrier.wait()
+        self._sync_wait()
         n = send.numel()
         flat = recv.view(-1)
         for r in range(sh.world):
             flat[r * n:(r + 1) * n].copy_(sh.slots[r].reshape(-1))
-        sh.barrier.wait()
+        self._sync_wait()
         return recv
 
     def broadcast_object(self, obj, src: int = 0):

@@ -676,6 +676,56 @@ def test_heads_hadamard_merged_equals_attention_merge_then_hadamard(ops, oracle,
     assert torch.equal(o0.view(torch.int16), o1.view(torch.int16))
 
 
+@pytest.mark.parametrize("ctx_lens,q_len,n_splits", [([37, 128, 129, 500], 1, 8), ([600, 5, 77], 1, 8), ([600, 5, 20], 1, 8),
+                                                     ([37, 130], 2, 5)])
+def test_spread_head_hadamard_and_quantiser_in_the_o_proj_prologue(ops, oracle, ctx_lens, q_len, n_splits):
+    """Draft pass, T <= 4: merge + head Hadamard spread over 8 workgroups per token (fp16 rows + 8 partial row maxima) and the
+    row-absmax quantiser in the prologue of the o_proj launch give the bits of heads_hadamard_merged(q) followed by
+    rowwise_scaled_linear_s4s4_residual -- and of the CPU oracle's rowabsmax_quant_i4 -> gemm_w4a4 -> add_f16 on the same
+    fp16 rows; an all-zero row included."""
+    rng = np.random.default_rng(sum(ctx_lens) * 7 + q_len)
+    nq, nkv, d, bs, N = 32, 8, 128, 16, 4096
+    n_seqs = len(ctx_lens)
+    bt, kc, vc = make_paged(rng, n_seqs, ctx_lens, nkv, d, bs)
+    T = n_seqs * q_len
+    row = (nq + 2 * nkv) * d
+    qkv_h = (rng.standard_normal((T, row)) * 0.5).astype(np.float16)
+    vc = np.array(vc)
+    if ctx_lens[-1] <= bs * 2:          # the last sequence sees only zero values -> an all-zero attention row
+        for b in bt[-1]:
+            vc[b] = 0
+    qkv = dev(qkv_h)
+    q_start = dev((np.arange(n_seqs + 1) * q_len).astype(np.int32))
+    ctx = dev(np.array(ctx_lens, np.int32))
+    had_scale = oracle.rsqrt_scale(nq)
+    ws = torch.zeros(ops.paged_attention_workspace_bytes(T, nq, d, n_splits), dtype=torch.uint8, device=DEV)
+    ops.paged_attention(qkv, row, dev(kc), dev(vc), dev(bt), ctx, q_start, T, q_len, nq, d ** -0.5, n_splits, ws, None)
+    wq, wsc = rng.integers(-128, 128, (N, nq * d // 2)).astype(np.int8), (rng.random(N) * 0.01 + 0.001).astype(np.float16)
+    resid = (rng.standard_normal((T, N))).astype(np.float16)
+    # the two-launch form
+    q0 = torch.empty(T, nq * d // 2, dtype=torch.int8, device=DEV); s0 = torch.empty(T, dtype=torch.float16, device=DEV)
+    o0 = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
+    ops.heads_hadamard_merged(ws, T, n_splits, T, nq, d, had_scale, q=q0, scale=s0)
+    ops.heads_hadamard_merged(ws, T, n_splits, T, nq, d, had_scale, out_f16=o0)
+    h0 = dev(resid)
+    ops.rowwise_scaled_linear_s4s4_residual(q0, s0, dev(wq), dev(wsc), h0, h0)
+    # the spread form
+    assert ops.heads_hadamard_merged_spread_supported(T, nq, d) and ops.rowwise_scaled_linear_s4s4_residual_hq_supported(T, N, nq * d)
+    o1 = torch.empty_like(o0)
+    pam = torch.full((T, 8), -1.0, dtype=torch.float32, device=DEV)
+    ops.heads_hadamard_merged_spread(ws, T, n_splits, T, nq, d, had_scale, o1, pam)
+    h1 = dev(resid)
+    ops.rowwise_scaled_linear_s4s4_residual_hq(o1, pam, 1.0, dev(wq), dev(wsc), h1, h1)
+    torch.cuda.synchronize()
+    assert torch.equal(o0.view(torch.int16), o1.view(torch.int16))
+    assert np.array_equal(host(pam).max(axis=1), np.abs(host(o1).astype(np.float32)).max(axis=1))
+    assert torch.equal(h0.view(torch.int16), h1.view(torch.int16))
+    # and against the oracle on the same fp16 rows
+    qo, so = oracle.rowabsmax_quant_i4(host(o1), 1.0)
+    ref = oracle.add_f16(resid, oracle.gemm_w4a4(qo, so, wq, wsc))
+    assert np.array_equal(bits(host(h1)), bits(ref))
+
+
 def test_embedding(ops):
     rng = np.random.default_rng(0)
     V, H = 1000, 4096

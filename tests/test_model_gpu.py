@@ -398,6 +398,10 @@ def test_teacher_forced_layers_llama3_8b(oracle, w4a4, q_len, B):
             assert np.array_equal(k_hip.view(np.uint16), kv_np[li][0].view(np.uint16)), li
             assert np.array_equal(v_hip.view(np.uint16), kv_np[li][1].view(np.uint16)), li
             q_o = s.quantized_buffer_qkv[:T].cpu().numpy()
+            if T <= 4 and one.HADAMARD_QUANT_IN_OPROJ:
+                # the o_proj launch quantises the fp16 head-Hadamard rows in its own prologue (bit-identical to the
+                # Quantizer: test_spread_head_hadamard_and_quantiser_in_the_o_proj_prologue): its input bytes are those
+                q_o = np.asarray(oracle.rowabsmax_quant_i4(s.act_buffer_had[:T].cpu().numpy(), 1.0)[0])
             q_d = s.quantized_buffer_mlp[:T].cpu().numpy()
             # (batch 32 takes the separate-norm branch, where the post-attention norm reuses this buffer)
             f_o = float((q_o != tr[f"o_in_{li}"][0]).mean()) if B <= 16 else 0.0

@@ -132,9 +132,18 @@ def main():
         shared = ThreadComm.Shared(world)
         results, errors = {}, []
 
+        # Every rank thread gets a stream of its own: the per-(device, stream) workspaces of qspec_amd.ops (K-slice
+        # partials of the long-K W4A16 GEMM, the exchange words of the spread kernels, ...) are then per rank, as they
+        # are with one process per GPU.  (On ONE shared stream two ranks' launch pairs "write workspace | consume
+        # workspace" interleave: a rank then read another rank's partials, about one run in ten.)  As in the
+        # process-mode rehearsal below, the ranks' kernels compete for one GPU's CUs, so the one-workgroup-per-token
+        # forms are used.
+        os.environ.setdefault("QSPEC_XWG_SPREAD", "0")
+
         def body(r):
             try:
-                run_rank(r, world, ThreadComm(shared, r), a.family, model, results)
+                with torch.cuda.stream(torch.cuda.Stream(device="cuda:0")):
+                    run_rank(r, world, ThreadComm(shared, r), a.family, model, results)
             except BaseException as exc:  # noqa: BLE001 -- a dead rank would leave the others in the barrier
                 errors.append((r, repr(exc)))
                 shared.barrier.abort()
