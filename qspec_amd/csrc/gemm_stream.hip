@@ -454,6 +454,7 @@ __device__ __forceinline__ void lnw_compute(const StreamArgs& a, int row, LnwReg
 // NW waves; UB steps of 64 packed bytes per wave and batch (K/2 = 64 * NW * UB * NB bytes, NB batches per tile);
 // NI = K / 1024 for the LN prologue (0 otherwise).
 #ifdef QS_STREAM_STAMPS
+__device__ long long g_sstamps[8];
 #define QS_SSTAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i])::"memory")
 #else
 #define QS_SSTAMP(i)
@@ -785,6 +786,7 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        QS_SSTAMP(1);
         // #1 (a bare barrier: __syncthreads() is fine too, the loads above are what this wave waits for next anyway; the
         // norm waves drained their LDS writes in front of theirs, the clobber keeps this wave's LDS reads behind it)
         __builtin_amdgcn_s_barrier();
@@ -929,6 +931,9 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w
         long long* sb2 = sb - 8;
         for (int i = 0; i < 5; i++) sb2[i] = g_lnst[i];
     }
+    // forms without a hidden_out (LN1 / LN1S gate_up): into a device array read back by qspec_debug_stamps()
+    if (EPI == SEPI_GATEUP && !a.hidden_out && blockIdx.x == 100 && tid == 0)
+        for (int i = 0; i < 6; i++) g_sstamps[i] = stamp[i];
 #endif
 }
 
@@ -1649,3 +1654,9 @@ int gemm_w4a4_stream_gate_up_silu(const StreamActs& x, const int8_t* wq, const f
 }
 
 }  // namespace qspec
+
+#ifdef QS_STREAM_STAMPS
+extern "C" int qspec_debug_stamps(long long* host8) {   // dev builds only (scripts/stream_stamps.py)
+    return hipMemcpyFromSymbol(host8, HIP_SYMBOL(qspec::g_sstamps), 8 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif

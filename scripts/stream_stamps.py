@@ -17,3 +17,13 @@ print("cycles [load issue, LN compute, main loop, last compute, last finish]:", 
 ln = hout.view(-1)[-64:-32].view(torch.int64).cpu().tolist()
 print("  inside the norm, from the kernel's first stamp: [residual stream arrived, mean tree done, variance tree done, "
       "quantised, barrier passed]:", [ln[i] - st[0] for i in range(5)])
+# the form the draft pass launches (no delta, no write-back): stamps through qspec_debug_stamps()
+import ctypes
+for w in ws:
+    ops.ln_gate_up_silu_linear(hidden, None, None, 1e-5, w, sc, act)
+torch.cuda.synchronize()
+buf = (ctypes.c_longlong * 8)()
+lib = ctypes.CDLL(os.environ["QSPEC_HIP_LIB"])
+assert lib.qspec_debug_stamps(buf) == 0
+st = list(buf)
+print("LN1 form, cycles [requests issued, norm joined / norm done, main loop, last compute, last finish]:", [st[i + 1] - st[i] for i in range(5)])
