@@ -677,7 +677,7 @@ def test_heads_hadamard_merged_equals_attention_merge_then_hadamard(ops, oracle,
 
 
 @pytest.mark.parametrize("ctx_lens,q_len,n_splits", [([37, 128, 129, 500], 1, 8), ([600, 5, 77], 1, 8), ([600, 5, 20], 1, 8),
-                                                     ([37, 130], 2, 5)])
+                                                     ([37, 130], 2, 5), ([77], 1, 8), ([300, 20], 1, 8), ([900], 3, 8)])
 def test_spread_head_hadamard_and_quantiser_in_the_o_proj_prologue(ops, oracle, ctx_lens, q_len, n_splits):
     """Draft pass, T <= 4: merge + head Hadamard spread over 8 workgroups per token (fp16 rows + 8 partial row maxima) and the
     row-absmax quantiser in the prologue of the o_proj launch give the bits of heads_hadamard_merged(q) followed by
