@@ -869,7 +869,7 @@ def test_w4a16_long_k_slices_and_norm_finish(ops, oracle, M, N, K):
     wq = oracle.pack_i4(w)
     ws = (rng.random(N) * 0.002 + 0.0005).astype(np.float16)
     S = ops.w4a16_linear_partial_slices(M, N, K)
-    assert S == 2
+    assert S == 4      # four slices first: a workgroup stages as many activation bytes as it streams weight bytes
     out = torch.empty(M, N, dtype=torch.float16, device=DEV)
     ops.w4a16_linear(dev(x), dev(wq), dev(ws), out)
     assert_close_1e3(host(out), oracle.gemm_w4a16(x, wq, ws))
