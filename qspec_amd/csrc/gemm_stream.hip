@@ -369,6 +369,11 @@ __device__ __forceinline__ void lnw_compute(const StreamArgs& a, int row, LnwReg
                                             float* xs_lds, bool write_hidden) {
     const int lane = threadIdx.x & 63;
     f32x2 v[NI > 0 ? NI : 1][8];
+#ifdef QS_STREAM_STAMPS
+    long long lnst[8];
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lnst[0])::"memory");
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lnst[1])::"memory");
+#endif
 #pragma unroll
     for (int it = 0; it < NI; it++) {
 #pragma unroll
@@ -397,6 +402,7 @@ __device__ __forceinline__ void lnw_compute(const StreamArgs& a, int row, LnwReg
     constexpr bool pow2 = (NI & (NI - 1)) == 0;
     constexpr float invH = 1.0f / (float)(NI > 0 ? NI * 1024 : 1);
     float mean = lnw_tree(p);
+    QS_LNSTAMP(2);
     mean = pow2 ? mean * invH : mean / (float)a.K;
     const f32x2 m2 = {mean, mean};
     float dm = 0.0f;
@@ -413,6 +419,7 @@ __device__ __forceinline__ void lnw_compute(const StreamArgs& a, int row, LnwReg
         p[k] = s;
     }
     float var = lnw_tree(p);
+    QS_LNSTAMP(3);
     const float dmax = wave_max_uniform(dm);
     var = pow2 ? var * invH : var / (float)a.K;
     const float rstd = 1.0f / __builtin_sqrtf(var + a.eps);
@@ -449,12 +456,18 @@ __device__ __forceinline__ void lnw_compute(const StreamArgs& a, int row, LnwReg
         o[1] = __builtin_amdgcn_perm(half[3], half[2], 0x05040100u) ^ 0x88888888u;
         *reinterpret_cast<u32x2*>(xq_lds + (size_t)row * RS + it * 512 + 8 * lane) = o;
     }
+#ifdef QS_STREAM_STAMPS
+    QS_LNSTAMP(4);
+    if (blockIdx.x == 100 && row == 0 && lane == 0)
+        for (int i = 0; i < 5; i++) g_lnst[i] = lnst[i];
+#endif
 }
 
 // NW waves; UB steps of 64 packed bytes per wave and batch (K/2 = 64 * NW * UB * NB bytes, NB batches per tile);
 // NI = K / 1024 for the LN prologue (0 otherwise).
 #ifdef QS_STREAM_STAMPS
 __device__ long long g_sstamps[8];
+__device__ long long g_wgspan[1024][2];   // per workgroup: first / last instruction of thread 0, s_memrealtime (100 MHz, chip-wide)
 #define QS_SSTAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i])::"memory")
 #else
 #define QS_SSTAMP(i)
@@ -485,6 +498,10 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w
     long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     QS_SSTAMP(0);
+#ifdef QS_STREAM_STAMPS
+    long long wg_t0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0)::"memory");
+#endif
     constexpr int NG = NW / 4;
     constexpr int RB = NW == 4 ? 4 : (NW == 8 ? 2 : 1);
     constexpr bool SPLIT = pro_split<PRO>();
@@ -934,6 +951,12 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w
     // forms without a hidden_out (LN1 / LN1S gate_up): into a device array read back by qspec_debug_stamps()
     if (EPI == SEPI_GATEUP && !a.hidden_out && blockIdx.x == 100 && tid == 0)
         for (int i = 0; i < 6; i++) g_sstamps[i] = stamp[i];
+    if (EPI == SEPI_GATEUP && !a.hidden_out && tid == 0 && blockIdx.x < 1024) {
+        long long t1;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        g_wgspan[blockIdx.x][0] = wg_t0;
+        g_wgspan[blockIdx.x][1] = t1;
+    }
 #endif
 }
 
@@ -1669,5 +1692,11 @@ int gemm_w4a4_stream_gate_up_silu(const StreamActs& x, const int8_t* wq, const f
 #ifdef QS_STREAM_STAMPS
 extern "C" int qspec_debug_stamps(long long* host8) {   // dev builds only (scripts/stream_stamps.py)
     return hipMemcpyFromSymbol(host8, HIP_SYMBOL(qspec::g_sstamps), 8 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+extern "C" int qspec_debug_lnst(long long* host8) {
+    return hipMemcpyFromSymbol(host8, HIP_SYMBOL(qspec::g_lnst), 8 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+extern "C" int qspec_debug_wgspan(long long* host2048) {
+    return hipMemcpyFromSymbol(host2048, HIP_SYMBOL(qspec::g_wgspan), 2048 * sizeof(long long)) == hipSuccess ? 0 : 1;
 }
 #endif

@@ -27,3 +27,15 @@ lib = ctypes.CDLL(os.environ["QSPEC_HIP_LIB"])
 assert lib.qspec_debug_stamps(buf) == 0
 st = list(buf)
 print("LN1 form, cycles [requests issued, norm joined / norm done, main loop, last compute, last finish]:", [st[i + 1] - st[i] for i in range(5)])
+span = (ctypes.c_longlong * 2048)()
+assert lib.qspec_debug_wgspan(span) == 0
+import numpy as np
+sp = np.array(list(span), dtype=np.int64).reshape(1024, 2)[:256]
+t0 = sp[:, 0].min()
+st_, en_ = (sp[:, 0] - t0) * 0.01, (sp[:, 1] - t0) * 0.01      # us (100 MHz)
+print("per workgroup (us from the first workgroup's start): starts min/median/max %.2f %.2f %.2f | ends min/10%%/median/90%%/max %.2f %.2f %.2f %.2f %.2f"
+      % (st_.min(), np.median(st_), st_.max(), en_.min(), np.quantile(en_, 0.1), np.median(en_), np.quantile(en_, 0.9), en_.max()))
+ln8 = (ctypes.c_longlong * 8)()
+assert lib.qspec_debug_lnst(ln8) == 0
+l8 = list(ln8)
+print("norm wave 0 (LN1S), cycles from the kernel's first stamp: [norm code entered, row arrived, mean known, variance known, row quantised]:", [l8[i] - st[0] for i in range(5)])
