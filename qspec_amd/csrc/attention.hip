@@ -260,15 +260,20 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
     struct KV {
         u32x4 kfrag[2][4], vraw[8];
     };
+    // Keys past the split's end are masked after the load; their ADDRESSES are those of the split's last key, so that a
+    // 64-key split does not pull the neighbouring split's 64 keys through this CU as well (a chunk is 128 keys: twice the
+    // bytes in flight, i.e. a second round trip of the CU's ~32 KB window -- 6.7 us per launch at 8 splits of a 512-key
+    // context).  Lanes with equal addresses coalesce inside the wave instruction.
+    const int k_last = max(k_end - 1, 0);
     auto lookup = [&](Slots& sl, int kb) {   // block-table entries of the chunk starting at key kb
 #pragma unroll
         for (int t2 = 0; t2 < 2; t2++) {
-            const int p = kb + (wave * 2 + t2) * 16 + c16;
+            const int p = min(kb + (wave * 2 + t2) * 16 + c16, k_last);
             sl.k[t2] = ((int64_t)bt_get(min(p >> bs_log2, max_blocks - 1)) << bs_log2) + (p & bmask);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const int p = kb + wave * 4 + g4 + 16 * i;
+            const int p = min(kb + wave * 4 + g4 + 16 * i, k_last);
             sl.v[i] = ((int64_t)bt_get(min(p >> bs_log2, max_blocks - 1)) << bs_log2) + (p & bmask);
         }
     };
@@ -447,6 +452,14 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
     }
     QS_STAMP(5);
     // merge == 0: the consumer kernel (heads_hadamard_merge) combines the splits; the launch boundary is the hand-off
+#ifdef QS_ATT_STAMPS
+    if (!merge && tid == 0 && seq == 0 && kvh == 0 && rb == 0 && split == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        QS_STAMP(6);
+        long long* sb = reinterpret_cast<long long*>(cnt + 2048);
+        for (int i = 0; i < 9; i++) sb[i] = stamp[i];
+    }
+#endif
     if (!merge) return;
     // ---- hand-off: every storing wave drains, one lane releases and takes a ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
