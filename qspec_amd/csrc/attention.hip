@@ -390,6 +390,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
             const int qd = c16 >> 2, pq = c16 & 3;              // lane 4q+p of its 16-lane group
 #pragma unroll
             for (int st = 0; st < 4; st++) {
+                if (st * 32 >= nkeys) continue;   // uniform: P is all zero there (short splits: 64 keys = two of the four steps)
                 const f16x8 pa = *reinterpret_cast<const f16x8*>(pl + c16 * QS_ATT_CHUNK + st * 32 + g4 * 8);
                 const f16x8 pb = *reinterpret_cast<const f16x8*>(pl2 + c16 * QS_ATT_CHUNK + st * 32 + g4 * 8);
                 // B fragment of lane (col c16, group g4) = V[key st*32 + 8*g4 + j][d0 + c16], j = 0..7
