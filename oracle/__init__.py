@@ -213,6 +213,17 @@ def gemm_w4a16(x, wq, ws, bias=None):
     return out
 
 
+def gemm_w4a16_f32acc(x, wq, ws):
+    """A second admissible W4A16 implementation (fp32 accumulate, interleaved partial sums): noise-floor probe."""
+    x, wq, ws = _h(x), _i8(wq), _h(ws).reshape(-1)
+    M, K = x.shape
+    N = wq.shape[0]
+    assert wq.shape[1] * 2 == K
+    out = np.empty((M, N), np.float16)
+    lib().qo_gemm_w4a16_f32acc(_p(x), _p(wq), _p(ws), _p(out), c_int(M), c_int(N), c_int(K))
+    return out
+
+
 def gemm_f16(x, w):
     """lm_head: x [M,K] @ w[N,K]^T -> f16 (logits_processor.py:92-97)."""
     x, w = _h(x), _h(w)
@@ -235,12 +246,18 @@ def rope_neox(positions, q, k, cos_sin_cache, head_size):
 
 
 def make_cos_sin_cache(head_size, max_pos, base):
-    """vllm rotary_embedding.py RotaryEmbedding._compute_cos_sin_cache, cast to fp16
-    (quarot_llama.py:112-120: plain rotary, rope_scaling ignored)."""
-    inv_freq = (1.0 / (np.float32(base) ** (np.arange(0, head_size, 2, dtype=np.float32) / np.float32(head_size)))).astype(np.float32)
-    t = np.arange(max_pos, dtype=np.float32)
-    freqs = np.einsum("i,j->ij", t, inv_freq).astype(np.float32)
-    return np.concatenate([np.cos(freqs), np.sin(freqs)], axis=-1).astype(np.float16)
+    """vllm rotary_embedding.py:136-150 RotaryEmbedding._compute_cos_sin_cache, cast to fp16
+    (quarot_llama.py:112-120: plain rotary, rope_scaling ignored).
+
+    Pinned against the reference's own table (tests/golden/rope_cache_softmax.npz): the table is fp32 `pow`, `cos`,
+    `sin` of angles up to max_pos radians, and a numpy restatement differed from the reference's torch-CPU result by up
+    to 8 fp16 ulps in 0.8 % of the entries (numpy's and torch's fp32 `pow` differ by an ulp, the angle multiplies that
+    by the position).  The restatement therefore uses the same torch CPU operators in the same order: bit-identical."""
+    import torch
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_size, 2, dtype=torch.float) / head_size))
+    t = torch.arange(max_pos, dtype=torch.float)
+    freqs = torch.einsum("i,j -> ij", t, inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(torch.float16).numpy()
 
 
 def reshape_and_cache_flash(key, value, key_cache, value_cache, slot_mapping):

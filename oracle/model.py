@@ -27,6 +27,7 @@ class OracleModel:
         self.head_scale = O.rsqrt_scale(cfg.num_attention_heads)
         self.mlp_scale = O.rsqrt_scale(cfg.intermediate_size)
         self.sm_scale = cfg.head_dim ** -0.5
+        self.w4a16_f32acc = False    # noise-floor probe: W4A16 GEMMs through the second admissible implementation
 
     @classmethod
     def from_torch_model(cls, m, block_size, max_layers=None):
@@ -46,7 +47,7 @@ class OracleModel:
         if w4a4:
             q, sc = x
             return O.gemm_w4a4(q, sc, w, s)
-        return O.gemm_w4a16(x, w, s)
+        return O.gemm_w4a16_f32acc(x, w, s) if self.w4a16_f32acc else O.gemm_w4a16(x, w, s)
 
     def forward(self, input_ids, positions, kv_caches, slot_mapping, block_tables, ctx_lens, q_start, w4a4,
                 return_trace=False):

@@ -404,6 +404,43 @@ void qo_gemm_w4a16(const uint16_t* x, const int8_t* wq, const uint16_t* ws, cons
     free(xf);
 }
 
+/* The same W4A16 GEMM as a SECOND admissible implementation: fp32 accumulation in 32 interleaved partial sums
+ * (k mod 32) combined pairwise -- the kind of order a tiled kernel produces.  Used only to measure the noise floor
+ * between two implementations that both meet the 1e-3 bar stage by stage (tests/test_model_gpu.py full-depth test):
+ * how far apart 32 layers of fp16 roundings carry two such implementations. */
+void qo_gemm_w4a16_f32acc(const uint16_t* x, const int8_t* wq, const uint16_t* ws, uint16_t* out, int M, int N, int K) {
+    int Kb = K / 2;
+    float* xf = (float*)malloc(sizeof(float) * (size_t)M * K);
+    for (int64_t i = 0; i < (int64_t)M * K; i++) xf[i] = h2f(x[i]);
+#pragma omp parallel
+    {
+        float* wu = (float*)malloc(sizeof(float) * (size_t)K);
+#pragma omp for schedule(static)
+        for (int n = 0; n < N; n++) {
+            for (int j = 0; j < Kb; j++) {
+                int8_t b = wq[(int64_t)n * Kb + j];
+                wu[2 * j] = (float)nib_lo(b);
+                wu[2 * j + 1] = (float)nib_hi(b);
+            }
+            float swn = h2f(ws[n]);
+            for (int m = 0; m < M; m++) {
+                const float* xr = xf + (int64_t)m * K;
+                float part[32];
+                for (int j = 0; j < 32; j++) part[j] = 0.0f;
+                int k = 0;
+                for (; k + 32 <= K; k += 32)
+                    for (int j = 0; j < 32; j++) part[j] = fmaf(xr[k + j], wu[k + j], part[j]);
+                for (; k < K; k++) part[k & 31] = fmaf(xr[k], wu[k], part[k & 31]);
+                for (int w = 16; w >= 1; w >>= 1)
+                    for (int j = 0; j < w; j++) part[j] = part[j] + part[j + w];
+                out[(int64_t)m * N + n] = f2h(part[0] * swn);
+            }
+        }
+        free(wu);
+    }
+    free(xf);
+}
+
 /* fp16 x fp16^T GEMM with fp32 result rounded to fp16 (lm_head nn.Linear,
  * vllm/model_executor/layers/logits_processor.py:92-97).  fp64 accumulate. */
 void qo_gemm_f16(const uint16_t* x, const uint16_t* w, uint16_t* out, int M, int N, int K) {

@@ -14,6 +14,14 @@ What is imported from the reference (by file path; nothing is copied):
        logger.init_logger and platforms.current_platform.simple_compile_backend = "eager")
   * third-party/ao/test/test_rowwise_scaled_linear_cutlass.py:64-84 is a formula, restated below
     with torch CPU ops on inputs of the shapes that test lists (:14-21).
+  * tests/kernels/test_flash_attn.py:19-75   ref_paged_attn (paged KV, GQA, causal varlen) -- the module is loaded
+      with `vllm.vllm_flash_attn` registered as an empty shell (a CUDA wheel absent here; ref_paged_attn is pure torch)
+  * vllm/model_executor/layers/rotary_embedding.py:47-70,136-150,201-229   RotaryEmbedding._compute_cos_sin_cache,
+      forward_native, _apply_rotary_emb -- loaded with a three-line `CustomOp` base (an nn.Module with a `register`
+      decorator) and an empty `vllm._custom_ops` (forward_native touches neither)
+  * tests/kernels/test_cache.py:295-304 (reshape_and_cache_flash's reference loop) and
+    vllm/model_executor/layers/sampler.py:278-287 (greedy probs / logprobs / argmax) are a five-line loop and three
+    torch calls inside larger functions: restated below with the same torch CPU ops.
 
 The fixtures are data (inputs + expected outputs); the generated .npz files are
 small and committed so the tests run without the reference (it does not exist
@@ -194,12 +202,144 @@ def gen_rejection():
     np.savez_compressed(os.path.join(OUT, "rejection.npz"), **out)
 
 
+def _vllm_shell():
+    """Empty package shell `vllm` with the few attributes the loaded reference files read at import time."""
+    if "vllm" in sys.modules and hasattr(sys.modules["vllm"], "_qspec_shell"):
+        return sys.modules["vllm"]
+    vllm = types.ModuleType("vllm")
+    vllm.__path__ = []
+    vllm._qspec_shell = True
+    platforms = types.ModuleType("vllm.platforms")
+    platforms.current_platform = types.SimpleNamespace(simple_compile_backend="eager",
+                                                       seed_everything=lambda seed: torch.manual_seed(seed))
+    fa = types.ModuleType("vllm.vllm_flash_attn")           # CUDA wheel, absent: names only
+    fa.flash_attn_varlen_func = fa.flash_attn_with_kvcache = None
+    cops = types.ModuleType("vllm._custom_ops")             # CUDA extension bindings, absent
+    me = types.ModuleType("vllm.model_executor")
+    me.__path__ = []
+    co = types.ModuleType("vllm.model_executor.custom_op")
+
+    class CustomOp(torch.nn.Module):
+        @classmethod
+        def register(cls, name):
+            return lambda op_cls: op_cls
+    co.CustomOp = CustomOp
+    layers = types.ModuleType("vllm.model_executor.layers")
+    layers.__path__ = []
+    for name, mod in (("vllm", vllm), ("vllm.platforms", platforms), ("vllm.vllm_flash_attn", fa),
+                      ("vllm._custom_ops", cops), ("vllm.model_executor", me), ("vllm.model_executor.custom_op", co),
+                      ("vllm.model_executor.layers", layers)):
+        sys.modules[name] = mod
+    vllm._custom_ops = cops
+    vllm.platforms = platforms
+    return vllm
+
+
+def gen_attention():
+    """ref_paged_attn of the reference's own flash-attn test, run on CPU.
+
+    Two outputs per case: `ref16` = the function on fp16 tensors exactly as the reference test calls it (its test bar
+    against flash-attn is atol 2e-2 / rtol 1e-2, test_flash_attn.py:155-156,  because S and P are rounded to fp16 in
+    it), and `ref32` = the same function on the same fp16-representable values held as fp32 tensors, which makes it
+    the exact statement of the paged / GQA / causal-varlen semantics the 1e-3 comparisons need."""
+    _vllm_shell()
+    fa = load_by_path("ref_test_flash_attn", f"{REF}/tests/kernels/test_flash_attn.py")
+    out = {}
+    g = torch.Generator().manual_seed(4)
+    # (query heads, kv heads, head size, block size, num blocks, kv_lens, query_lens)
+    cases = [(8, 2, 128, 16, 24, [70, 18, 133], [4, 1, 6]),       # verify-shaped (k+1 queries) and decode rows, GQA 4
+             (4, 1, 64, 16, 12, [1, 54, 100], [1, 4, 4]),         # head_dim 64 (TinyLlama), first-token row
+             (8, 2, 128, 32, 8, [128, 97], [1, 1])]               # decode only, block size 32
+    for idx, (nq, nkv, d, bs, nb, kv_lens, q_lens) in enumerate(cases):
+        T = sum(q_lens)
+        q = torch.randn(T, nq, d, generator=g).to(torch.float16)
+        kc = torch.randn(nb, bs, nkv, d, generator=g).to(torch.float16)
+        vc = torch.randn(nb, bs, nkv, d, generator=g).to(torch.float16)
+        max_blocks = (max(kv_lens) + bs - 1) // bs
+        bt = torch.stack([torch.randperm(nb, generator=g)[:max_blocks] for _ in kv_lens]).to(torch.int32)
+        scale = d ** -0.5
+        ref16 = fa.ref_paged_attn(q.clone(), kc, vc, q_lens, kv_lens, bt, scale)      # q is scaled in place: clone
+        ref32 = fa.ref_paged_attn(q.float(), kc.float(), vc.float(), q_lens, kv_lens, bt, scale)
+        assert ref16.dtype == torch.float16 and ref32.dtype == torch.float32
+        key = f"c{idx}_"
+        out[key + "q"] = q.numpy()
+        out[key + "key_cache"] = kc.numpy()
+        out[key + "value_cache"] = vc.numpy()
+        out[key + "block_tables"] = bt.numpy()
+        out[key + "kv_lens"] = np.array(kv_lens, np.int32)
+        out[key + "query_lens"] = np.array(q_lens, np.int32)
+        out[key + "scale"] = np.array(scale, np.float32)
+        out[key + "ref16"] = ref16.numpy()
+        out[key + "ref32"] = ref32.numpy()
+    np.savez_compressed(os.path.join(OUT, "attention.npz"), **out)
+
+
+def gen_rope_cache_softmax():
+    _vllm_shell()
+    re_ = load_by_path("vllm.model_executor.layers.rotary_embedding",
+                       f"{REF}/vllm/model_executor/layers/rotary_embedding.py")
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    # ---- RotaryEmbedding._compute_cos_sin_cache + forward_native (neox style, fp16), as quarot_llama.py:106-114 builds it
+    for idx, (d, max_pos, base, nq, nkv, T) in enumerate([(128, 2048, 500000.0, 8, 2, 7), (64, 512, 10000.0, 4, 4, 5)]):
+        rot = re_.RotaryEmbedding(d, d, max_pos, base, True, torch.float16)
+        pos = torch.randint(0, max_pos, (T,), generator=g)
+        pos[0], pos[-1] = 0, max_pos - 1
+        q = torch.randn(T, nq * d, generator=g).to(torch.float16)
+        k = torch.randn(T, nkv * d, generator=g).to(torch.float16)
+        qo, ko = rot.forward_native(pos, q.clone(), k.clone())
+        key = f"rope{idx}_"
+        out[key + "cfg"] = np.array([d, max_pos, nq, nkv], np.int64)
+        out[key + "base"] = np.array(base, np.float64)
+        # the whole table is a function of (d, max_pos, base): keep a strided sample of rows + the rows `pos` uses
+        rows = torch.unique(torch.cat([torch.arange(0, max_pos, 37), pos]))
+        out[key + "cache_rows"] = rows.numpy()
+        out[key + "cache"] = rot.cos_sin_cache[rows].numpy()
+        out[key + "pos"] = pos.numpy()
+        out[key + "q"], out[key + "k"] = q.numpy(), k.numpy()
+        out[key + "q_out"], out[key + "k_out"] = qo.numpy(), ko.numpy()
+    # ---- reshape_and_cache_flash reference loop (tests/kernels/test_cache.py:295-304)
+    T, nkv, d, bs, nb = 9, 2, 128, 16, 6
+    slot_mapping = torch.randperm(bs * nb, generator=g)[:T]
+    key_t = torch.randn(T, nkv, d, generator=g).to(torch.float16)
+    val_t = torch.randn(T, nkv, d, generator=g).to(torch.float16)
+    kc = torch.randn(nb, bs, nkv, d, generator=g).to(torch.float16)
+    vc = torch.randn(nb, bs, nkv, d, generator=g).to(torch.float16)
+    out["cache_key"], out["cache_value"] = key_t.numpy(), val_t.numpy()
+    out["cache_key_cache_in"], out["cache_value_cache_in"] = kc.numpy().copy(), vc.numpy().copy()
+    out["cache_slot_mapping"] = slot_mapping.numpy()
+    block_idx = torch.div(slot_mapping, bs, rounding_mode="floor").tolist()
+    block_off = (slot_mapping % bs).tolist()
+    for i in range(T):
+        kc[block_idx[i], block_off[i], :, :] = key_t[i]
+        vc[block_idx[i], block_off[i], :, :] = val_t[i]
+    out["cache_key_cache_out"], out["cache_value_cache_out"] = kc.numpy(), vc.numpy()
+    # ---- greedy sampler front end (sampler.py:270-287, 473: argmax of the logprobs; temperature 0 -> 1.0)
+    V = 4099
+    logits = (torch.randn(6, V, generator=g) * 3).to(torch.float16)
+    logits[1, 77] = logits[1].max() + 1           # a clear winner
+    logits[2, 100] = logits[2, 3000] = logits[2].max() + 0.5   # an exact tie: argmax takes the first index
+    logits[3] = 0                                 # uniform row
+    logits[4, 5] = 60000                          # near the fp16 ceiling, everything else underflows
+    lf = logits.to(torch.float)
+    lf.div_(torch.ones(6).unsqueeze(1))
+    probs = torch.softmax(lf, dim=-1, dtype=torch.float)
+    logprobs = torch.log_softmax(lf, dim=-1, dtype=torch.float)
+    out["sm_logits"] = logits.numpy()
+    out["sm_probs"] = probs.numpy()
+    out["sm_logprobs"] = logprobs.numpy()
+    out["sm_argmax"] = torch.argmax(logprobs, dim=-1).numpy()
+    np.savez_compressed(os.path.join(OUT, "rope_cache_softmax.npz"), **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference checkout is only present in the build container"
     gen_pack()
     gen_hadamard()
     gen_w4a4()
     gen_rejection()
+    gen_attention()
+    gen_rope_cache_softmax()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1218,3 +1218,66 @@ def test_attention_partials_long_splits_then_merge_within_1e3(ops, oracle, ctx_l
     ops.heads_hadamard_merged(ws, T, n_splits, T, nq, d, had_scale, out_f16=out)
     # the head transform sums 32 / 64 attention outputs scaled by 1/sqrt(heads): errors of 1e-3 each stay below 1e-3 * sqrt(heads) / sqrt(heads)
     assert_close_1e3(host(out), ref)
+
+
+# ------------------------------------------------------------------ the reference's own pure-torch formulas (fixtures)
+# tests/golden/{attention,rope_cache_softmax}.npz: outputs of ref_paged_attn (tests/kernels/test_flash_attn.py:19-75),
+# RotaryEmbedding.forward_native (rotary_embedding.py:201-229), the reshape_and_cache_flash reference loop
+# (tests/kernels/test_cache.py:295-304) and torch.softmax / log_softmax / argmax (sampler.py:278-287), produced by
+# tests/golden/make_golden.py from /root/reference.  The HIP kernels run on the same inputs.
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+@pytest.mark.parametrize("n_splits", [1, 3])
+def test_paged_attention_reference_fixture_within_1e3(ops, golden_dir, idx, n_splits):
+    from test_oracle_golden import attention_case
+    c = attention_case(np.load(os.path.join(golden_dir, "attention.npz")), idx)
+    nb, bs, nkv, d = c["key_cache"].shape
+    T = c["q"].shape[0]
+    nq = c["q"].shape[1] // d
+    q_lens = np.diff(c["q_start"])
+    if d != 128:
+        n_splits = 1                              # the generic head-size kernel has no context split
+    ws = torch.zeros(ops.paged_attention_workspace_bytes(len(q_lens) * int(q_lens.max()), nq, d, n_splits),
+                     dtype=torch.uint8, device=DEV)
+    out = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
+    ops.paged_attention(dev(c["q"]), nq * d, dev(c["key_cache"]), dev(c["value_cache"]), dev(c["block_tables"]),
+                        dev(c["ctx_lens"]), dev(c["q_start"]), T, int(q_lens.max()), nq, c["scale"], n_splits, ws, out)
+    got = host(out).astype(np.float64)
+    assert np.abs(got - c["ref32"]).max() <= 1e-3, np.abs(got - c["ref32"]).max()
+    assert np.allclose(got, c["ref16"].astype(np.float64), atol=2e-2, rtol=1e-2)   # the reference test's own bar
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_rope_reference_fixture_bit_exact(ops, golden_dir, idx):
+    from qspec_amd.model import make_cos_sin_cache
+    g = np.load(os.path.join(golden_dir, "rope_cache_softmax.npz"))
+    key = f"rope{idx}_"
+    d, max_pos, nq, nkv = (int(v) for v in g[key + "cfg"])
+    cs = make_cos_sin_cache(d, max_pos, float(g[key + "base"])).to(DEV)      # the table the product builds
+    q, k = dev(g[key + "q"]), dev(g[key + "k"])
+    ops.rotary_embedding(dev(g[key + "pos"]), q, k, d, cs)
+    assert np.array_equal(bits(host(q)), bits(g[key + "q_out"]))
+    assert np.array_equal(bits(host(k)), bits(g[key + "k_out"]))
+
+
+def test_reshape_and_cache_flash_reference_fixture_bit_exact(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "rope_cache_softmax.npz"))
+    kc, vc = dev(g["cache_key_cache_in"]), dev(g["cache_value_cache_in"])
+    ops.reshape_and_cache_flash(dev(g["cache_key"]), dev(g["cache_value"]), kc, vc, dev(g["cache_slot_mapping"]))
+    assert np.array_equal(bits(host(kc)), bits(g["cache_key_cache_out"]))
+    assert np.array_equal(bits(host(vc)), bits(g["cache_value_cache_out"]))
+
+
+def test_softmax_argmax_reference_fixture(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "rope_cache_softmax.npz"))
+    logits = g["sm_logits"]
+    T, V = logits.shape
+    probs = torch.empty(T, V, dtype=torch.float32, device=DEV)
+    tok = torch.empty(T, dtype=torch.int64, device=DEV)
+    ops.softmax_argmax(dev(logits), probs, tok)
+    ref = g["sm_probs"].astype(np.float64)
+    got = host(probs)
+    assert np.array_equal(host(tok), g["sm_argmax"])
+    assert np.abs(got - ref).max() <= 1e-3
+    big = ref > 1e-30
+    assert (np.abs(got[big] - ref[big]) / ref[big]).max() < 1e-5

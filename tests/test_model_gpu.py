@@ -95,7 +95,7 @@ def test_forward_matches_oracle_model(tiny, oracle, w4a4, ctx_lens, q_len):
     assert np.quantile(np.abs(logits - ref_logits), 0.99) < (0.1 if w4a4 else 3e-2)
 
 
-def _engine_cycle_check(model, oracle, k, B, prompt_lens, cycles, seed, tv_bars, sync_kv=False):
+def _engine_cycle_check(model, oracle, k, B, prompt_lens, cycles, seed, tv_bars, sync_kv=False, d_q98=None):
     """Three full cycles (k=3, B=4).  Two HIP-vs-oracle differences are legitimate: fp32 summation order inside
     attention / the W4A16 MFMA, and (a consequence) a rare different int4 value downstream.  So:
       * numerics: the oracle engine is teacher-forced with the GPU's draft tokens; its draft / target
@@ -171,6 +171,8 @@ def _engine_cycle_check(model, oracle, k, B, prompt_lens, cycles, seed, tv_bars,
         assert np.array_equal(eng.v_slots.view(B, k + 1).cpu().numpy(), exp_slots)
     # W4A4 is chaotic (a single different int4 can re-scale a row), so the draft distributions are compared
     # statistically: most of them agree to fp32 rounding, none is far off; the W4A16 target must stay close always
+    by_step = np.concatenate(all_tv_d).reshape(-1, k).max(0)      # step 0 runs on identical inputs under sync_kv
+    print("TV draft max by draft step:", " ".join(f"{v:.2e}" for v in by_step))
     tv_d, tv_t = np.concatenate(all_tv_d).ravel(), np.concatenate(all_tv_t).ravel()
     # (measured: a 1e-7 attention difference flips an fp16 ulp in ~20% of rows, the int4 pipeline amplifies it to
     # a total-variation distance of ~0.05-0.08 after two layers)
@@ -178,6 +180,9 @@ def _engine_cycle_check(model, oracle, k, B, prompt_lens, cycles, seed, tv_bars,
     print(f"TV draft median {np.median(tv_d):.4f} max {tv_d.max():.4f} min {tv_d.min():.2e}; "
           f"target median {np.median(tv_t):.5f} max {tv_t.max():.4f}")
     assert np.median(tv_d) < d_med and tv_d.max() < d_max and tv_d.min() < 1e-3, tv_d
+    if d_q98 is not None:
+        print(f"TV draft rows above {d_q98:g}: {int((tv_d >= d_q98).sum())} of {tv_d.size}")
+        assert np.quantile(tv_d, 0.98) < d_q98, np.sort(tv_d)[-8:]
     assert np.median(tv_t) < t_med and tv_t.max() < t_max, tv_t
     assert eng.generated() == gen
     m = eng.metrics()
@@ -191,8 +196,42 @@ def test_engine_cycle_matches_oracle_engine(tiny, oracle):
     _engine_cycle_check(tiny, oracle, 3, 4, (17, 33, 64, 5), 3, 2, (0.12, 0.6, 5e-3, 0.15))
 
 
+# With the KV history teacher-forced as well (sync_kv) the draft pass starts every cycle on IDENTICAL inputs: its
+# distributions are compared at what is measured, not at the chaotic-drift bars: median total variation < 1e-4 (measured
+# 0.0000), 98 % of the rows < 1e-2 (measured: 0 rows above at bs = 4 and bs = 1, 1 of 320 at bs = 32 / k = 5).  The
+# maximum cannot be bounded that tightly: draft steps 2..k attend to K/V the SAME cycle's earlier draft steps wrote, a
+# last-bit attention difference there (hardware v_exp_f32 vs the oracle's qexpf) can flip one int4 and the row-absmax
+# quantiser re-scales that row (measured once: 0.22).  A regression that moved every draft distribution by even 1 %
+# fails the median and the quantile.  Target (W4A16) distributions: measured median 0.5-1.5e-3, max 4e-3.
+SAME_HISTORY_BARS = (1e-4, 0.6, 3e-3, 2e-2)
+
+
 def test_engine_cycle_matches_oracle_engine_same_history(tiny, oracle):
-    _engine_cycle_check(tiny, oracle, 3, 4, (17, 33, 64, 5), 3, 2, (0.12, 0.6, 5e-3, 0.15), sync_kv=True)
+    _engine_cycle_check(tiny, oracle, 3, 4, (17, 33, 64, 5), 3, 2, SAME_HISTORY_BARS, sync_kv=True, d_q98=1e-2)
+
+
+def test_engine_cycle_tinyllama_k3_bs1(oracle):
+    """BASELINE.json configs[0] -- TinyLlama-1.1B, k = 3, bs = 1 -- through the ENGINE on the HIP path at that model's
+    layer width (H = 2048, I = 5632 = had44 (x) H128, 32 heads / 4 kv heads of head_dim 64; 2 layers, small vocabulary):
+    the dispatch that differs from the headline config -- generic head-size attention kernel without context split,
+    un-fused QKV epilogue (rope_kv_write), had44 MLP transform, one sequence (B * kv heads = 4 groups) -- with the
+    same exact-logic assertions (accept masks, recovered ids, layout, counters, KV slot bookkeeping) and the
+    same-history bars on the distributions; then the captured hipGraph of that cycle against the eager cycle."""
+    from qspec_amd.model import QuarotLlamaConfig, QuarotLlamaForCausalLM
+    from qspec_amd.spec_decode import QSpecEngine
+    cfg = QuarotLlamaConfig(2048, 5632, 32, 4, 2, 2048, 1e-5, 10000.0, 512, "tinyllama-1.1b-2layer")
+    model = QuarotLlamaForCausalLM(cfg, DEV).init_synthetic(seed=7, lm_head_std=0.05)
+    assert cfg.head_dim == 64
+    _engine_cycle_check(model, oracle, 3, 1, (23,), 3, 21, SAME_HISTORY_BARS, sync_kv=True, d_q98=1e-2)
+    outs = []
+    prompt = np.random.default_rng(5).integers(0, cfg.vocab_size, 37).tolist()
+    for use_graph in (False, True):
+        eng = QSpecEngine(model, 3, 1, max_model_len=256, block_size=16, max_new_tokens=64, use_graph=use_graph, seed=9)
+        eng.add_sequences([prompt])
+        for _ in range(5):
+            eng.step()
+        outs.append((eng.generated(), eng.metrics()))
+    assert outs[0] == outs[1] and len(outs[0][0][0]) >= 6
 
 
 def test_engine_cycle_k5_bs32_llama3_8b_width(oracle):
@@ -205,7 +244,68 @@ def test_engine_cycle_k5_bs32_llama3_8b_width(oracle):
     model = QuarotLlamaForCausalLM(cfg, DEV).init_synthetic(seed=3, lm_head_std=0.05)
     lens = [5 + (7 * i) % 29 for i in range(32)]
     # with the history teacher-forced as well, the draft pass is (nearly always) bit-identical to the oracle
-    _engine_cycle_check(model, oracle, 5, 32, lens, 2, 12, (0.12, 0.6, 5e-3, 0.15), sync_kv=True)
+    _engine_cycle_check(model, oracle, 5, 32, lens, 2, 12, SAME_HISTORY_BARS, sync_kv=True, d_q98=1e-2)
+
+
+def test_full_depth_llama3_8b_verify_forward_and_cycle(oracle):
+    """The headline config at FULL depth and vocabulary (32 layers, H = 4096, I = 14336, V = 128256; BASELINE.json
+    configs[1]) on the HIP path against the CPU oracle -- the widest comparison elsewhere is 3 layers / V = 1024.
+      1. one verify forward (W4A16, T = 16 = 4 sequences x (k+1)) over a random paged KV history: the error of the
+         final normed hidden state and of the fp16 logits is printed against north_star's 1e-3 and bounded;
+      2. one k = 3 / bs = 4 cycle through the engine, teacher-forced (draft tokens, KV history), with injected draws:
+         accept masks, recovered ids, output layout, counters and slot bookkeeping EXACT given the GPU's distributions;
+         draft / target distributions within the same-history bars.
+    The reference holds nothing at this size either (parity unpinned); the oracle is its restatement."""
+    from oracle.model import OracleModel
+    from qspec_amd.model import CONFIGS, QuarotLlamaForCausalLM, Scratch
+    cfg = CONFIGS["llama-3-8b"]
+    assert (cfg.num_hidden_layers, cfg.vocab_size, cfg.hidden_size) == (32, 128256, 4096)
+    model = QuarotLlamaForCausalLM(cfg, DEV).init_synthetic(seed=0)
+    rng = np.random.default_rng(8)
+    ctx_lens, q_len = [40, 130, 9, 260], 4
+    inp = make_inputs(model, rng, ctx_lens, q_len)
+    om = OracleModel.from_torch_model(model, 16)
+    kv_np = [(k.copy(), v.copy()) for k, v in inp["kv_np"]]
+    ref = om.forward(inp["ids"], inp["pos"], kv_np, inp["slots"], inp["bt"], inp["ctx"], inp["q_start"], False)
+    s = Scratch(cfg, inp["T"], len(ctx_lens), q_len, inp["n_splits"], DEV)
+    out = model.forward(inp["ids_t"], inp["pos_t"], inp["kv_t"], inp["md"], s, w4a4=False)
+    logits = model.compute_logits(out, s)
+    torch.cuda.synchronize()
+    ref_logits = om.logits(ref).astype(np.float64)
+
+    def dist(what, got, ref):
+        r = np.abs(got.astype(np.float64) - ref.astype(np.float64)) / (1e-3 * np.maximum(1.0, np.abs(ref.astype(np.float64))))
+        q = np.quantile(r, [0.5, 0.9, 0.99, 0.999])
+        print(f"full depth, verify T=16, {what}: err / 1e-3  median {q[0]:.3f}  q90 {q[1]:.3f}  q99 {q[2]:.3f}  "
+              f"q99.9 {q[3]:.3f}  max {r.max():.3f};  within 1e-3: {(r <= 1).mean():.4f}")
+        return r
+    r_h = dist("HIP vs oracle, normed hidden", out.cpu().numpy(), ref)
+    r_l = dist("HIP vs oracle, logits", logits.cpu().numpy(), ref_logits)
+    # The noise floor of the comparison: the oracle against ITSELF with its W4A16 GEMMs replaced by a second admissible
+    # implementation (fp32 accumulate in interleaved partial sums; every stage of it meets the 1e-3 bar against the fp64
+    # one, tests/test_oracle_golden.py).  32 layers of fp16 roundings on a residual stream whose ulp is ~1e-3 of its
+    # row norm carry two such implementations this far apart; the HIP path must not be further from the oracle than that
+    # by more than a factor 1.5 (measured on the box: HIP 3.8 / 4.4 x 1e-3 median, see DESIGN.md section 2).
+    om.w4a16_f32acc = True
+    kv_np2 = [(k.copy(), v.copy()) for k, v in inp["kv_np"]]
+    ref2 = om.forward(inp["ids"], inp["pos"], kv_np2, inp["slots"], inp["bt"], inp["ctx"], inp["q_start"], False)
+    om.w4a16_f32acc = False
+    n_h = dist("oracle(f32 acc) vs oracle, normed hidden", ref2, ref)
+    n_l = dist("oracle(f32 acc) vs oracle, logits", om.logits(ref2), ref_logits)
+    assert np.median(r_h) < 1.5 * np.median(n_h) and np.quantile(r_h, 0.99) < 1.5 * np.quantile(n_h, 0.99), \
+        (np.median(r_h), np.median(n_h), np.quantile(r_h, 0.99), np.quantile(n_h, 0.99))
+    assert np.median(r_l) < 1.5 * np.median(n_l) and np.quantile(r_l, 0.99) < 1.5 * np.quantile(n_l, 0.99), \
+        (np.median(r_l), np.median(n_l), np.quantile(r_l, 0.99), np.quantile(n_l, 0.99))
+    assert np.median(r_l) < 10.0 and r_l.max() < 100.0      # and an absolute ceiling: logits within 1e-2 / 1e-1
+    # the greedy token agrees wherever the oracle's two best logits are not a near tie
+    top2 = np.sort(ref_logits, -1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 0.05
+    assert np.array_equal(logits.float().argmax(-1).cpu().numpy()[clear], ref_logits.argmax(-1)[clear])
+    del s, out, logits, inp, kv_np, kv_np2
+    # 32 layers deep the chaotic rows of draft steps 2..k are more frequent (measured: 3 of 12 rows above 1e-2, median
+    # still 0.0000) and the target distributions carry the verify pass's 32-layer drift (measured median 3.6e-3 =
+    # the noise floor above): median bar as everywhere, no quantile bar, target bars 8e-3 / 2e-2
+    _engine_cycle_check(model, oracle, 3, 4, (9, 12, 6, 5), 1, 40, (1e-4, 0.6, 8e-3, 2e-2), sync_kv=True)
 
 def test_graph_replay_equals_eager(tiny):
     """The captured hipGraph of the cycle produces the same tokens as the eager cycle (same Philox stream)."""

@@ -88,6 +88,19 @@ def test_w4a16_matches_dequantised_matmul(oracle):
     assert np.allclose(out, ref, rtol=1e-3, atol=1e-4)
 
 
+def test_w4a16_second_implementation_meets_the_same_bar(oracle):
+    """The fp32-accumulate variant (noise-floor probe of the full-depth GPU test) is itself within 1e-3 of the fp64 one
+    at the decoder's K sizes."""
+    rng = np.random.default_rng(2)
+    for M, N, K in [(4, 96, 4096), (3, 64, 14336)]:
+        x = rng.standard_normal((M, K)).astype(np.float16)
+        w = oracle.pack_i4(rng.integers(-8, 8, (N, K)).astype(np.int8))
+        ws = (rng.random(N) * 0.01 + 0.001).astype(np.float16)
+        a = oracle.gemm_w4a16(x, w, ws).astype(np.float64)
+        b = oracle.gemm_w4a16_f32acc(x, w, ws).astype(np.float64)
+        assert (np.abs(a - b) <= 1e-3 * np.maximum(1.0, np.abs(a))).all()
+
+
 def test_rejection_sampler_matches_reference_run(oracle, golden_dir):
     """The reference RejectionSampler itself, run on CPU with recorded uniform / exponential draws."""
     g = _load(golden_dir, "rejection.npz")
@@ -173,3 +186,78 @@ def test_heads_hadamard_with_table_factor_matches_reference_matmul_hadU(oracle, 
     attn = x.astype(np.float16).reshape(3, heads * d)   # [T, heads, d = 1]
     out = oracle.heads_hadamard(attn, heads, None, hadK, 40).astype(np.float64)
     assert np.allclose(out, y, atol=5e-3, rtol=0), np.abs(out - y).max()
+
+
+# ----------------------------------------------------------------- f1 / a11: attention, RoPE, KV write, greedy softmax
+# Fixtures: the reference's own pure-torch formulas run on CPU by tests/golden/make_golden.py
+# (tests/kernels/test_flash_attn.py:19-75, vllm/model_executor/layers/rotary_embedding.py:47-70,136-150,201-229,
+#  tests/kernels/test_cache.py:295-304, vllm/model_executor/layers/sampler.py:278-287).
+
+def attention_case(g, idx):
+    """One case of attention.npz as the arguments of the paged-attention contract: q [T, nq*d], caches, block tables,
+    context lengths, query starts, softmax scale, and the two reference outputs reshaped to [T, nq*d]."""
+    key = f"c{idx}_"
+    q = g[key + "q"]
+    T, nq, d = q.shape
+    q_lens = g[key + "query_lens"]
+    q_start = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    return dict(q=q.reshape(T, nq * d), key_cache=g[key + "key_cache"], value_cache=g[key + "value_cache"],
+                block_tables=g[key + "block_tables"], ctx_lens=g[key + "kv_lens"], q_start=q_start,
+                scale=float(g[key + "scale"]), ref16=g[key + "ref16"].reshape(T, nq * d),
+                ref32=g[key + "ref32"].reshape(T, nq * d), n_cases=3)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_paged_attention_matches_reference_ref_paged_attn(oracle, golden_dir, idx):
+    """Paged KV through block tables, GQA head mapping, causal mask of a varlen batch with the queries at the END of
+    each context: the oracle against ref_paged_attn.  <= 1e-3 against the function on fp32-held values; against the
+    fp16 call (S and P rounded to fp16 inside it) the reference's own bar for flash-attn, atol 2e-2 / rtol 1e-2
+    (test_flash_attn.py:155-156)."""
+    c = attention_case(_load(golden_dir, "attention.npz"), idx)
+    out = oracle.paged_attention(c["q"], c["key_cache"], c["value_cache"], c["block_tables"], c["ctx_lens"],
+                                 c["q_start"], c["scale"]).astype(np.float64)
+    err = np.abs(out - c["ref32"])
+    assert err.max() <= 1e-3, err.max()          # (includes the oracle's one rounding to fp16: |out| < 2 here)
+    assert np.allclose(out, c["ref16"].astype(np.float64), atol=2e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_rope_matches_reference_forward_native_bit_exact(oracle, golden_dir, idx):
+    """cos/sin table = RotaryEmbedding._compute_cos_sin_cache cast to fp16, rotation = forward_native on fp16 tensors
+    (every operator rounds to fp16, as the CUDA kernel's scalar_t arithmetic does): bit for bit."""
+    g = _load(golden_dir, "rope_cache_softmax.npz")
+    key = f"rope{idx}_"
+    d, max_pos, nq, nkv = (int(v) for v in g[key + "cfg"])
+    cs = oracle.make_cos_sin_cache(d, max_pos, float(g[key + "base"]))
+    rows = g[key + "cache_rows"]
+    assert np.array_equal(cs[rows].view(np.uint16), g[key + "cache"].view(np.uint16))   # the table, bit for bit
+    from qspec_amd.model import make_cos_sin_cache               # the product's table: the same bits
+    assert np.array_equal(make_cos_sin_cache(d, max_pos, float(g[key + "base"])).numpy()[rows].view(np.uint16),
+                          g[key + "cache"].view(np.uint16))
+    full = cs
+    q, k = oracle.rope_neox(g[key + "pos"], g[key + "q"], g[key + "k"], full, d)
+    assert np.array_equal(q.view(np.uint16), g[key + "q_out"].view(np.uint16))
+    assert np.array_equal(k.view(np.uint16), g[key + "k_out"].view(np.uint16))
+
+
+def test_reshape_and_cache_flash_matches_reference_loop(oracle, golden_dir):
+    g = _load(golden_dir, "rope_cache_softmax.npz")
+    kc, vc = g["cache_key_cache_in"].copy(), g["cache_value_cache_in"].copy()
+    oracle.reshape_and_cache_flash(g["cache_key"], g["cache_value"], kc, vc, g["cache_slot_mapping"])
+    assert np.array_equal(kc.view(np.uint16), g["cache_key_cache_out"].view(np.uint16))
+    assert np.array_equal(vc.view(np.uint16), g["cache_value_cache_out"].view(np.uint16))
+
+
+def test_greedy_softmax_argmax_matches_torch(oracle, golden_dir):
+    """probs vs torch.softmax(fp32) <= 1e-3 relative (measured: a few fp32 ulps -- `qexpf` is within 1.4 ulp of expf
+    and the denominator is summed in fp64), token == argmax(log_softmax) on every row incl. an exact tie (first
+    index), a uniform row and a row at the fp16 ceiling."""
+    g = _load(golden_dir, "rope_cache_softmax.npz")
+    probs, tok = oracle.softmax_argmax(g["sm_logits"])
+    ref = g["sm_probs"].astype(np.float64)
+    assert np.array_equal(tok, g["sm_argmax"])
+    assert np.abs(probs - ref).max() <= 1e-3
+    big = ref > 1e-30
+    rel = np.abs(probs[big] - ref[big]) / ref[big]
+    assert rel.max() < 1e-5, rel.max()
+    assert np.allclose(np.log(np.maximum(probs, 1e-45))[big], g["sm_logprobs"][big], atol=1e-4)
