@@ -252,6 +252,9 @@ int qspec_oneshot_local_handle(void* ctx, void* handle_out);
 int qspec_oneshot_open_peers(void* ctx, const void* handles);
 int qspec_oneshot_all_reduce_f32(void* ctx, float* data, int n, void* stream);
 int qspec_oneshot_error(void* ctx);
+/* device address of this rank's sticky error word (int32; for qspec_collect_error_words, so that the engine reads it
+ * with the cycle's output instead of synchronising the device from the host) */
+void* qspec_oneshot_error_word(void* ctx);
 int qspec_oneshot_destroy(void* ctx);
 
 /* lm_head: F.linear(hidden, lm_head.weight)  (vllm/model_executor/layers/logits_processor.py:92-97). w [N,K] fp16. */
@@ -406,6 +409,17 @@ int qspec_spec_prepare_verify(int batch, int k, int block_size, int max_blocks_p
  * last_token = last emitted token. */
 int qspec_spec_commit(int batch, int k, const int64_t* out_tokens, int32_t* seq_lens, int64_t* last_token,
                       int64_t* gen_tokens, int32_t* gen_lens, int gen_capacity, void* stream);
+
+/* Recovery support of the cycle (no reference counterpart: the reference has no device-side hand-offs).
+ * qspec_spec_snapshot: copies the small per-cycle sequence state aside (restore = 0) or back (restore = 1):
+ *   seq_lens / gen_lens [batch] i32 -> snap_i32 [2 * batch]; last_token [batch], the sampler's counters [3]
+ *   (spec_decode_base_sampler.py:29-31) and Philox state [2] i64 -> snap_i64 [batch + 5].
+ * qspec_collect_error_words: out[0] = OR of |*w_i| over up to four sticky int32 error words (NULL = none: the
+ *   hand-off workspaces, the one-shot all-reduce); clear != 0 also zeroes them; out may be NULL then. */
+int qspec_spec_snapshot(int batch, int restore, int32_t* seq_lens, int32_t* gen_lens, int64_t* last_token,
+                        int64_t* counters, int64_t* rng_state, int32_t* snap_i32, int64_t* snap_i64, void* stream);
+int qspec_collect_error_words(int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3, int clear, int64_t* out,
+                              void* stream);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,7 @@ SIGNATURES = {
     "qspec_oneshot_open_peers": (_i, [_vp, _vp]),
     "qspec_oneshot_all_reduce_f32": (_i, [_vp, _vp, _i, _vp]),
     "qspec_oneshot_error": (_i, [_vp]),
+    "qspec_oneshot_error_word": (_vp, [_vp]),
     "qspec_oneshot_destroy": (_i, [_vp]),
     "qspec_linear_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_dequant_w4": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -90,6 +91,8 @@ SIGNATURES = {
     "qspec_spec_advance_draft": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qspec_spec_prepare_verify": (_i, [_i, _i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "qspec_spec_commit": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "qspec_spec_snapshot": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qspec_collect_error_words": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
 }
 
 

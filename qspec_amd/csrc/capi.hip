@@ -52,7 +52,7 @@ static int tiled_min_m() {
 
 extern "C" {
 
-int qspec_abi_version(void) { return 3; }
+int qspec_abi_version(void) { return 4; }
 const char* qspec_last_error(void) { return g_err; }
 
 int qspec_rms_norm_general_fuse_sum_i4(int8_t* out_q, const qspec_half* x, qspec_half* input_sum, qspec_half* scaling,
@@ -414,6 +414,20 @@ int qspec_spec_commit(int batch, int k, const int64_t* out_tokens, int32_t* seq_
     NONNULL(op, out_tokens); NONNULL(op, seq_lens); NONNULL(op, last_token);
     if (gen_tokens) NONNULL(op, gen_lens);
     return finish(op, qspec::spec_commit(batch, k, out_tokens, seq_lens, last_token, gen_tokens, gen_lens, gen_capacity, ST));
+}
+
+int qspec_spec_snapshot(int batch, int restore, int32_t* seq_lens, int32_t* gen_lens, int64_t* last_token,
+                        int64_t* counters, int64_t* rng_state, int32_t* snap_i32, int64_t* snap_i64, void* stream) {
+    const char* op = "qspec_spec_snapshot";
+    if (batch < 0) return fail("%s: batch < 0", op);
+    NONNULL(op, seq_lens); NONNULL(op, gen_lens); NONNULL(op, last_token); NONNULL(op, counters); NONNULL(op, rng_state);
+    NONNULL(op, snap_i32); NONNULL(op, snap_i64);
+    return finish(op, qspec::spec_snapshot(batch, restore, seq_lens, gen_lens, last_token, counters, rng_state, snap_i32, snap_i64, ST));
+}
+int qspec_collect_error_words(int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3, int clear, int64_t* out, void* stream) {
+    const char* op = "qspec_collect_error_words";
+    if (!out && !clear) return fail("%s: nothing to do (out == NULL and clear == 0)", op);
+    return finish(op, qspec::collect_error_words(w0, w1, w2, w3, clear, out, ST));
 }
 
 size_t qspec_xwg_workspace_bytes(void) { return qspec::xwg_workspace_bytes(); }

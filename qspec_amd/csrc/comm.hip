@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void oneshot_all_reduce_f32_kernel(ArPeers pee
         int guard = 0;
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
             __builtin_amdgcn_s_sleep(8);
-            if (++guard > (1 << 21)) {   // ~1 s: a peer is gone; raise the error word, do not hang the GPU
+            // ~20 s: a peer that is merely LATE (a long host step, a collector pause) is not a dead one -- vllm's custom
+            // all-reduce waits without a bound; the bound here only keeps a lost peer from hanging the GPU for good
+            if (++guard > (1 << 25)) {
                 __hip_atomic_store(reinterpret_cast<uint32_t*>(local), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
@@ -185,6 +187,11 @@ int qspec_oneshot_error(void* ctx) {
     uint32_t v = 0;
     if (hipMemcpy(&v, c->local, 4, hipMemcpyDeviceToHost) != hipSuccess) return -2;
     return (int)v;
+}
+
+void* qspec_oneshot_error_word(void* ctx) {
+    OneShotCtx* c = static_cast<OneShotCtx*>(ctx);
+    return c ? static_cast<void*>(c->local) : nullptr;
 }
 
 int qspec_oneshot_destroy(void* ctx) {

@@ -155,6 +155,9 @@ int spec_prepare_draft(int B, int block_size, int max_blocks, const int64_t* las
 int spec_prepare_verify(int B, int k, int block_size, int max_blocks, const int64_t* last_token, const int64_t* draft_ids,
                         int64_t di_sb, int64_t di_sk, const int32_t* seq_lens, const int32_t* block_tables, int64_t bt_stride, int64_t* v_tokens,
                         int64_t* v_positions, int64_t* v_slots, int32_t* v_ctx_lens, hipStream_t st);
+int spec_snapshot(int B, int restore, int32_t* seq_lens, int32_t* gen_lens, int64_t* last_token, int64_t* counters,
+                  int64_t* rng_state, int32_t* snap_i32, int64_t* snap_i64, hipStream_t st);
+int collect_error_words(int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3, int clear, int64_t* out, hipStream_t st);
 int spec_commit(int B, int k, const int64_t* out_tokens, int32_t* seq_lens, int64_t* last_token, int64_t* gen_tokens,
                 int32_t* gen_lens, int gen_cap, hipStream_t st);
 }  // namespace qspec

@@ -476,6 +476,66 @@ __global__ void spec_commit_kernel(int B, int k, const int64_t* __restrict__ out
         if (gen_lens) gen_lens[b] += n;
     }
 }
+// The small per-cycle sequence state, copied aside at the start of a cycle (restore = the same kernel with the
+// arguments swapped): seq_lens / gen_lens [B] i32, last_token [B] i64, counters [3] i64, rng_state [2] i64.
+// snap_i32 [2B], snap_i64 [B + 5].
+__global__ void spec_snapshot_kernel(int B, const int32_t* __restrict__ seq_lens, const int32_t* __restrict__ gen_lens,
+                                     const int64_t* __restrict__ last_token, const int64_t* __restrict__ counters,
+                                     const int64_t* __restrict__ rng_state, int32_t* __restrict__ snap_i32,
+                                     int64_t* __restrict__ snap_i64) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {
+        snap_i32[i] = seq_lens[i];
+        snap_i32[B + i] = gen_lens[i];
+        snap_i64[i] = last_token[i];
+    }
+    if (i < 3) snap_i64[B + i] = counters[i];
+    if (i < 2) snap_i64[B + 3 + i] = rng_state[i];
+}
+__global__ void spec_restore_kernel(int B, int32_t* __restrict__ seq_lens, int32_t* __restrict__ gen_lens,
+                                    int64_t* __restrict__ last_token, int64_t* __restrict__ counters,
+                                    int64_t* __restrict__ rng_state, const int32_t* __restrict__ snap_i32,
+                                    const int64_t* __restrict__ snap_i64) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {
+        seq_lens[i] = snap_i32[i];
+        gen_lens[i] = snap_i32[B + i];
+        last_token[i] = snap_i64[i];
+    }
+    if (i < 3) counters[i] = snap_i64[B + i];
+    if (i < 2) rng_state[i] = snap_i64[B + 3 + i];
+}
+// out[0] = OR of |*w| over up to four sticky error words (hand-off workspaces, one-shot all-reduce; NULL = none): read
+// by the host together with the cycle's output tokens; all-reduced (sum) over the ranks under tensor parallelism.
+// The addresses are kernel arguments (constants of a captured graph), not a device table.
+__global__ void collect_error_words_kernel(int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3, int clear,
+                                           int64_t* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int32_t* ws[4] = {w0, w1, w2, w3};
+    int64_t acc = 0;
+    for (int i = 0; i < 4; i++) {
+        if (!ws[i]) continue;
+        const int32_t v = __hip_atomic_load(ws[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        acc |= (int64_t)(v < 0 ? -(int64_t)v : (int64_t)v);
+        if (clear) __hip_atomic_store(ws[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (out) out[0] = acc;
+}
+int spec_snapshot(int B, int restore, int32_t* seq_lens, int32_t* gen_lens, int64_t* last_token, int64_t* counters,
+                  int64_t* rng_state, int32_t* snap_i32, int64_t* snap_i64, hipStream_t st) {
+    const int n = B > 3 ? B : 3;
+    if (restore)
+        hipLaunchKernelGGL(spec_restore_kernel, dim3((n + 63) / 64), dim3(64), 0, st, B, seq_lens, gen_lens, last_token,
+                           counters, rng_state, snap_i32, snap_i64);
+    else
+        hipLaunchKernelGGL(spec_snapshot_kernel, dim3((n + 63) / 64), dim3(64), 0, st, B, seq_lens, gen_lens, last_token,
+                           counters, rng_state, snap_i32, snap_i64);
+    return 0;
+}
+int collect_error_words(int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3, int clear, int64_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(collect_error_words_kernel, dim3(1), dim3(64), 0, st, w0, w1, w2, w3, clear, out);
+    return 0;
+}
 int spec_prepare_draft(int B, int block_size, int max_blocks, const int64_t* last_token, const int32_t* seq_lens,
                        const int32_t* block_tables, int64_t bt_stride, int64_t* input_tokens, int64_t* positions,
                        int64_t* slot_mapping, int32_t* ctx_lens, hipStream_t st) {

@@ -619,3 +619,33 @@ def spec_commit(out_tokens, seq_lens, last_token, gen_tokens=None, gen_lens=None
     _call("qspec_spec_commit", B, k1 - 1, _chk(out_tokens, "out_tokens", _I64), _chk(seq_lens, "seq_lens", _I32),
           _chk(last_token, "last_token", _I64), _opt(gen_tokens, "gen_tokens", _I64),
           _opt(gen_lens, "gen_lens", _I32), cap, _stream())
+
+
+def spec_snapshot(seq_lens, gen_lens, last_token, counters, rng_state, snap_i32, snap_i64, restore: bool = False):
+    """The small per-cycle sequence state copied aside (or back): what a recovery replay of a cycle starts from."""
+    B = seq_lens.numel()
+    assert snap_i32.numel() >= 2 * B and snap_i64.numel() >= B + 5 and counters.numel() == 3 and rng_state.numel() == 2
+    _call("qspec_spec_snapshot", B, 1 if restore else 0, _chk(seq_lens, "seq_lens", _I32), _chk(gen_lens, "gen_lens", _I32),
+          _chk(last_token, "last_token", _I64), _chk(counters, "counters", _I64), _chk(rng_state, "rng_state", _I64),
+          _chk(snap_i32, "snap_i32", _I32), _chk(snap_i64, "snap_i64", _I64), _stream())
+
+
+def stream_error_words(device, extra=()):
+    """Raw device addresses of the sticky error words of the CURRENT stream's hand-off workspaces (the ones the launches
+    being enqueued on this stream use; a captured graph keeps those of its capture stream) plus `extra` addresses (the
+    one-shot all-reduce's word)."""
+    key = _ws_key(device)
+    ptrs = []
+    if key in _xwg_ws:
+        ptrs.append(_xwg_ws[key][:1].data_ptr())
+    if key in _ln_ws:
+        ptrs.append(_ln_ws[key].view(torch.int32)[31:32].data_ptr())
+    ptrs += [int(p) for p in extra if p]
+    return ptrs
+
+
+def collect_error_words(word_addrs, out=None, clear: bool = False):
+    """out[0] (int64) = OR of the sticky error words at `word_addrs` (stream_error_words; at most four); clear: zero them."""
+    assert len(word_addrs) <= 4, "at most four error words per call"
+    w = list(word_addrs) + [None] * (4 - len(word_addrs))
+    _call("qspec_collect_error_words", w[0], w[1], w[2], w[3], 1 if clear else 0, _opt(out, "out", _I64), _stream())

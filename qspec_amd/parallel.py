@@ -149,7 +149,13 @@ class OneShotComm(TorchDistComm):
         return recv
 
     def error(self) -> int:
+        """Sticky error word read from the host (synchronises the device): out-of-band check."""
         return int(self._lib.qspec_oneshot_error(self._ctx))
+
+    def error_word_address(self) -> int:
+        """Device address of the sticky error word: the engine collects it with the cycle's output (no host sync) and
+        all-reduces the collected word, so that every rank takes the same decision."""
+        return int(self._lib.qspec_oneshot_error_word(self._ctx) or 0)
 
     def close(self):
         if self._ctx is not None:
@@ -171,6 +177,7 @@ class ThreadComm:
             self.barrier = threading.Barrier(world)
             self.slots = [None] * world
             self.result = None
+            self.bcast = None    # broadcast_object's own field: must not alias an in-flight all_reduce result
 
     def __init__(self, shared: "ThreadComm.Shared", rank: int):
         self.sh, self.rank, self.backend = shared, rank, "threads"
@@ -208,9 +215,9 @@ class ThreadComm:
     def broadcast_object(self, obj, src: int = 0):
         sh = self.sh
         if self.rank == src:
-            sh.result = obj
+            sh.bcast = obj
         sh.barrier.wait()
-        out = sh.result
+        out = sh.bcast
         sh.barrier.wait()
         return out
 

@@ -2,5 +2,6 @@
 from .engine import QSpecEngine  # noqa: F401
 from .metrics import AsyncMetricsCollector, SpecDecodeWorkerMetrics  # noqa: F401
 from .rejection_sampler import RejectionSampler  # noqa: F401
-from .worker import (ExecuteModelRequest, SamplerOutput, SequenceGroupMetadata, SpecDecodeWorker,  # noqa: F401
-                     create_spec_worker)
+from .worker import (CompletionSequenceGroupOutput, DeviceHandoffTimeout, ExecuteModelRequest, Logprob,  # noqa: F401
+                     SamplerOutput, SamplingParams, SequenceData, SequenceGroupMetadata, SequenceOutput,
+                     SpecDecodeWorker, SpeculativeConfig, create_spec_worker)

@@ -55,7 +55,7 @@ def n_splits_for(ctx: int, n_groups: int = 0) -> int:
 class QSpecEngine:
     def __init__(self, model: QuarotLlamaForCausalLM, num_speculative_tokens: int = 3, max_batch: int = 4,
                  max_model_len: int = 1024, block_size: int = 16, max_new_tokens: int = 1024, use_graph: bool = True,
-                 seed: int = 0):
+                 seed: int = 0, num_blocks: Optional[int] = None):
         self.model = model
         self.cfg = cfg = model.config
         if max_model_len > cfg.max_position_embeddings:
@@ -70,13 +70,22 @@ class QSpecEngine:
         dev = self.device = model.device
         i64, i32 = torch.int64, torch.int32
         # ---- one KV cache for both passes: [num_blocks, block_size, n_kv, d] per layer
+        # num_blocks: what the worker's initialize_cache(num_gpu_blocks) hands over (the scheduler allocates block ids
+        # below it and sends block tables); default: every slot owns a contiguous range of max_model_len tokens
         self.blocks_per_seq = (max_model_len + block_size - 1) // block_size
-        self.num_blocks = B * self.blocks_per_seq
+        self.num_blocks = B * self.blocks_per_seq if num_blocks is None else int(num_blocks)
+        if self.num_blocks < 1:
+            raise ValueError("the KV cache needs at least one block")
         shape = (self.num_blocks, block_size, cfg.num_key_value_heads, cfg.head_dim)
         self.kv_caches = [(torch.zeros(shape, dtype=torch.float16, device=dev),
                            torch.zeros(shape, dtype=torch.float16, device=dev)) for _ in range(cfg.num_hidden_layers)]
-        self.block_tables = torch.arange(self.num_blocks, dtype=i32, device=dev).view(B, self.blocks_per_seq).contiguous()
-        self._capacity = [self.blocks_per_seq * block_size] * B    # tokens the slot's block table covers (host)
+        if self.num_blocks >= B * self.blocks_per_seq:
+            self.block_tables = torch.arange(B * self.blocks_per_seq, dtype=i32, device=dev).view(B, self.blocks_per_seq).contiguous()
+            self._capacity = [self.blocks_per_seq * block_size] * B    # tokens the slot's block table covers (host)
+        else:   # fewer blocks than max_num_seqs x max_model_len (vLLM's normal case): every request brings its table
+            self.block_tables = torch.zeros(B, self.blocks_per_seq, dtype=i32, device=dev)
+            self._capacity = [0] * B
+        self._bt_host: List[Optional[List[int]]] = [None] * B      # the table last uploaded per slot (None: the default)
         self._len_ub = [0] * B                                     # host upper bound of seq_lens (0 = empty slot)
         self._gen_ub = [0] * B                                     # host upper bound of gen_lens
         # ---- sequence state (seq_lens[b] == 0: empty slot)
@@ -109,7 +118,15 @@ class QSpecEngine:
         self.v_qstart = (torch.arange(B + 1, dtype=i32, device=dev) * (k + 1)).contiguous()
         self.target_probs = torch.zeros(B, k + 1, V, dtype=torch.float32, device=dev)
         self.target_tokens = torch.zeros(B, k + 1, dtype=i64, device=dev)
-        self.out_tokens = torch.full((B, k + 1), -1, dtype=i64, device=dev)
+        # the cycle's output and its error word in ONE buffer: the worker's single host read per cycle
+        self._out_err = torch.full((B * (k + 1) + 1,), -1, dtype=i64, device=dev)
+        self._out_err[-1] = 0
+        self.out_tokens = self._out_err[:B * (k + 1)].view(B, k + 1)
+        self.err_word = self._out_err[B * (k + 1):]               # OR of the sticky device-side error words (0 = fine)
+        self._out_err_host = torch.empty(B * (k + 1) + 1, dtype=i64, pin_memory=(dev.type == "cuda"))
+        self._snap_i32 = torch.zeros(2 * B, dtype=i32, device=dev)  # sequence state at the start of the last cycle
+        self._snap_i64 = torch.zeros(B + 5, dtype=i64, device=dev)
+        self.recoveries = 0                                         # cycles re-run without device-side hand-offs
         self.accepted = torch.zeros(B, k, dtype=torch.uint8, device=dev)
         self.recovered = torch.zeros(B, k, dtype=i64, device=dev)
         self.sampler = RejectionSampler(seed=seed)
@@ -143,6 +160,21 @@ class QSpecEngine:
         n = len(slots)
         if n == 0:
             return
+        # Validate EVERY slot, prompt and block table before the first forward: a later request that does not fit must
+        # not leave earlier ones of the same call admitted (their slots would be occupied here and free in the worker).
+        if len(set(slots)) != n:
+            raise ValueError("a slot appears twice in one admission")
+        for i, b in enumerate(slots):
+            if not 0 <= b < self.B or self._len_ub[b] != 0:
+                raise ValueError(f"slot {b} is not an empty slot of this engine")
+            table = None if block_tables is None else block_tables[i]
+            if table is not None:
+                self._validate_block_table(table)
+            cap = self._capacity[b] if table is None else len(table) * self.block_size
+            T = len(prompts[i])
+            if T < 1 or T + 1 > min(cap, self.max_model_len):
+                raise ValueError(f"prompt of {T} tokens does not fit slot {b} (capacity {cap} tokens, max_model_len "
+                                 f"{self.max_model_len})" + ("" if cap else ": the request brought no block table"))
         if n == 1:
             self.add_sequence(slots[0], prompts[0], None if block_tables is None else block_tables[0])
             return
@@ -160,13 +192,8 @@ class QSpecEngine:
                     tokens += len(prompts[i])
             return
         for i, b in enumerate(slots):
-            if not 0 <= b < self.B or self._len_ub[b] != 0:
-                raise ValueError(f"slot {b} is not an empty slot of this engine")
             if block_tables is not None and block_tables[i] is not None:
                 self.set_block_table(b, block_tables[i])
-            T = len(prompts[i])
-            if T < 1 or T + 1 > min(self._capacity[b], self.max_model_len):
-                raise ValueError(f"prompt of {T} tokens does not fit slot {b}")
         lens = [len(p) for p in prompts]
         Ttot, Tmax = sum(lens), max(lens)
         s = Scratch(cfg, Ttot, n, Tmax, 1, dev, logits_rows=n)
@@ -244,16 +271,25 @@ class QSpecEngine:
 
     def set_block_table(self, slot: int, blocks: Sequence[int]) -> None:
         """The scheduler's block table of the request in `slot` (vLLM SequenceGroupMetadata.block_tables); it must
-        cover every position a cycle can touch (vLLM allocates them as num_lookahead_slots)."""
+        cover every position a cycle can touch (vLLM allocates them as num_lookahead_slots).  The scheduler resends
+        the table on every step: it is uploaded only when it differs from the one the slot already has."""
+        blocks = [int(b) for b in blocks]
+        if self._bt_host[slot] == blocks:
+            return
+        self._validate_block_table(blocks)
+        n = len(blocks)
+        row = torch.zeros(self.blocks_per_seq, dtype=torch.int32)
+        row[:n] = torch.tensor(blocks, dtype=torch.int32)
+        self.block_tables[slot].copy_(row.to(self.device))
+        self._capacity[slot] = n * self.block_size
+        self._bt_host[slot] = blocks
+
+    def _validate_block_table(self, blocks: Sequence[int]) -> None:
         n = len(blocks)
         if n > self.blocks_per_seq:
             raise ValueError(f"{n} blocks > {self.blocks_per_seq} per sequence (max_model_len {self.max_model_len})")
         if n and (min(blocks) < 0 or max(blocks) >= self.num_blocks):
             raise ValueError("block id outside the KV cache")
-        row = torch.zeros(self.blocks_per_seq, dtype=torch.int32)
-        row[:n] = torch.tensor(list(blocks), dtype=torch.int32)
-        self.block_tables[slot].copy_(row.to(self.device))
-        self._capacity[slot] = n * self.block_size
 
     def active_slots(self) -> List[int]:
         return [b for b in range(self.B) if self._len_ub[b] > 0]
@@ -293,8 +329,28 @@ class QSpecEngine:
 
     # ------------------------------------------------------------------ one speculative cycle (:758-858)
     def _cycle_body(self):
+        # the small sequence state aside: what recover() restarts the cycle from if a device-side hand-off timed out
+        ops.spec_snapshot(self.seq_lens, self.gen_lens, self.last_token, self.sampler.counters, self.sampler.rng_state,
+                          self._snap_i32, self._snap_i64)
         self._draft_body()
         self._verify_body()
+        self._collect_errors()
+
+    def _comm(self):
+        tp = getattr(self.model, "tp", None)
+        return tp if tp is not None and tp.world > 1 else None
+
+    def _collect_errors(self):
+        """Last launches of a cycle: err_word = OR of the sticky error words of this stream's hand-off workspaces and of
+        the one-shot all-reduce, summed over the ranks under tensor parallelism -- every rank reads the SAME word with
+        its output tokens, so the decision to re-run (or to give up) is collective by construction."""
+        tp = self._comm()
+        extra = []
+        if tp is not None and hasattr(tp.comm, "error_word_address"):
+            extra.append(tp.comm.error_word_address())
+        ops.collect_error_words(ops.stream_error_words(self.device, extra), out=self.err_word)
+        if tp is not None:
+            tp.all_reduce(self.err_word)
 
     def _draft_body(self):
         m, k, B, bs = self.model, self.k, self.B, self.block_size
@@ -454,10 +510,55 @@ class QSpecEngine:
             room.append((self.gen_tokens.shape[1] - self._gen_ub[b]) // (self.k + 1))
         return max(0, min(room)) if room else 0
 
+    def read_outputs(self):
+        """The worker's ONE host read per cycle: (out_tokens [B, k+1] on the host, error word).  A non-zero error word
+        means a device-side hand-off (spread Hadamard, norm hand-off, one-shot all-reduce) timed out somewhere in the
+        cycle on some rank: the tokens are invalid; see recover()."""
+        self._out_err_host.copy_(self._out_err, non_blocking=True)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        host = self._out_err_host
+        return host[:-1].view(self.B, self.k + 1), int(host[-1])
+
+    @torch.no_grad()
+    def recover(self) -> None:
+        """Re-run the cycle that has just failed (read_outputs() returned a non-zero error word) from the state
+        snapshot taken at its start, eagerly and WITHOUT the kernels that wait for partner workgroups: the spread MLP
+        Hadamard and the norm hand-off fall back to their one-workgroup / recompute forms, which are bit-identical
+        (tests/test_kernels_gpu.py), so the replayed cycle emits exactly what the failed one should have.  The KV slots
+        the failed cycle wrote are the ones the replay rewrites.  The caller reads the outputs again; a second failure
+        (e.g. a lost tensor-parallel peer) is final."""
+        ops.spec_snapshot(self.seq_lens, self.gen_lens, self.last_token, self.sampler.counters, self.sampler.rng_state,
+                          self._snap_i32, self._snap_i64, restore=True)
+        self.clear_error_words()
+        saved = ops.XWG_SPREAD, ops.LN_HANDOFF
+        ops.XWG_SPREAD = ops.LN_HANDOFF = False
+        try:
+            self._cycle_body()
+        finally:
+            ops.XWG_SPREAD, ops.LN_HANDOFF = saved
+        self.recoveries += 1
+
+    def clear_error_words(self) -> None:
+        dev = self.device
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        for key, ws in ops._xwg_ws.items():
+            if key[:2] == (dev.type, idx):
+                ws[:1].zero_()
+        for key, ws in ops._ln_ws.items():
+            if key[:2] == (dev.type, idx):
+                ws.view(torch.int32)[31:32].zero_()
+        tp = self._comm()
+        if tp is not None and hasattr(tp.comm, "error_word_address"):
+            ops.collect_error_words([tp.comm.error_word_address()], clear=True)
+        self.err_word.zero_()
+
     def error_flag(self) -> int:
-        """Sticky device-side error word of the kernels that hand data between workgroups (0 = fine)."""
-        flag = 0
-        for w in (ops.xwg_error_word(self.device), ops.ln_linear_error_word(self.device)):
-            if w is not None:
-                flag |= int(w.abs().max().item())
+        """Sticky device-side error words of EVERY hand-off workspace of the device and of the one-shot all-reduce, read
+        from the host (0 = fine).  The cycle itself reports through read_outputs(); this is the out-of-band check."""
+        words = [w for w in (ops.xwg_error_word(self.device), ops.ln_linear_error_word(self.device)) if w is not None]
+        flag = int(torch.cat(words).abs().max().item()) if words else 0
+        tp = self._comm()
+        if tp is not None and hasattr(tp.comm, "error"):
+            flag |= int(tp.comm.error())
         return flag

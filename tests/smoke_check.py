@@ -1,5 +1,5 @@
-"""Body of __graft_entry__.smoke(): imports the oracle, so it lives outside the product modules' import graph
-(nothing in qspec_amd imports this file)."""
+"""Body of __graft_entry__.smoke(): one small invocation of the hot path on cuda:0 checked against the CPU oracle.
+It imports the oracle, so it lives under tests/ (the package `qspec_amd` never touches `oracle/`)."""
 import numpy as np
 import torch
 

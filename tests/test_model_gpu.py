@@ -333,20 +333,25 @@ def test_worker_api(tiny):
                            max_num_seqs=4, max_model_len=256, block_size=16, device=DEV)
     w.init_device()
     assert w.proposer_model is w.scorer_model                     # shared module
-    nb, _ = w.determine_num_available_blocks()
-    w.initialize_cache(nb, 0)
+    nb, _ = w.determine_num_available_blocks()                    # profiled: a prompt pass + one captured cycle
+    prof = w.memory_profile
+    assert nb > 64 and nb * prof["cache_block_size"] <= prof["free"] and prof["torch_peak_increase"] > 0
+    assert prof["available_kv_cache_memory"] <= prof["total"] * 0.9 - (prof["total"] - prof["free"]) - 3 * prof["torch_peak_increase"] + 1
+    w.initialize_cache(64, 0)                                     # (not the whole card: other tests share it)
+    assert w.engine.num_blocks == 64 and w.engine.kv_caches[0][0].shape[0] == 64
     with pytest.raises(NotImplementedError):
         w.get_cache_block_size_bytes()
     sg = [SequenceGroupMetadata(f"r{i}", True, {i: SequenceData(rng.integers(0, 2048, 10 + i).tolist())}) for i in range(4)]
     out = w.execute_model(ExecuteModelRequest(sg, num_lookahead_slots=0))
-    assert len(out) == 1 and out[0].sampled_token_ids.shape == (4,) and (out[0].sampled_token_ids >= 0).all()
+    assert len(out) == 1 and len(out[0].outputs) == 4 and all(t >= 0 for t in out[0].token_ids())
+    assert [o.samples[0].parent_seq_id for o in out[0].outputs] == [0, 1, 2, 3]
     for s in sg:
         s.is_prompt = False
     req = ExecuteModelRequest(sg, num_lookahead_slots=3)
     outs = w.execute_model(req)
     assert req.w4a4 is False and w.proposer_calls == 3 and w.scorer_calls == 2
     assert 1 <= len(outs) <= 4
-    toks = torch.stack([o.sampled_token_ids for o in outs], 1)    # [B, steps]
+    toks = torch.tensor([o.token_ids() for o in outs]).t()        # [B, steps]
     assert (toks[:, 0] != -1).all()                               # every sequence emits at least one token
     for row in toks.tolist():                                     # -1 only as a suffix
         seen = False
@@ -412,8 +417,7 @@ def test_worker_decode_step_with_speculation_disabled(tiny):
     w = create_spec_worker(model_config=tiny.config, model=tiny, speculative_config=SpeculativeConfig(3, speculative_disable_by_batch_size=2),
                            max_num_seqs=4, max_model_len=256, block_size=16, device=DEV)
     w.init_device()
-    nb, _ = w.determine_num_available_blocks()
-    w.initialize_cache(nb, 0)
+    w.initialize_cache(64, 0)
     lens = [10, 23, 5, 40]
     sg = [SequenceGroupMetadata(f"r{i}", True, {i: SequenceData(rng.integers(0, 2048, n).tolist())}) for i, n in enumerate(lens)]
     w.execute_model(ExecuteModelRequest(sg, num_lookahead_slots=0))
@@ -432,11 +436,11 @@ def test_worker_decode_step_with_speculation_disabled(tiny):
     calls = (w.proposer_calls, w.scorer_calls)
     # (a) the scheduler asks for no lookahead slots; (b) the running queue reaches speculative_disable_by_batch_size
     outs = w.execute_model(ExecuteModelRequest(sg, num_lookahead_slots=0))
-    assert len(outs) == 1 and torch.equal(outs[0].sampled_token_ids, expect.cpu())
+    assert len(outs) == 1 and outs[0].token_ids() == expect.cpu().tolist()
     assert (w.proposer_calls, w.scorer_calls) == (calls[0], calls[1] + 1)
     assert torch.equal(eng.seq_lens, seq0 + 1) and torch.equal(eng.last_token, expect)
     outs = w.execute_model(ExecuteModelRequest(sg, num_lookahead_slots=3, running_queue_size=2))
-    assert len(outs) == 1 and (outs[0].sampled_token_ids >= 0).all() and w.proposer_calls == calls[0]
+    assert len(outs) == 1 and all(t >= 0 for t in outs[0].token_ids()) and w.proposer_calls == calls[0]
     # and a speculative step still works afterwards
     outs = w.execute_model(ExecuteModelRequest(sg, num_lookahead_slots=3))
     assert 1 <= len(outs) <= 4 and w.proposer_calls == calls[0] + 3
@@ -785,19 +789,21 @@ def test_worker_variable_batch_on_the_gpu(tiny):
     w = create_spec_worker(model_config=tiny.config, model=tiny, speculative_config=SpeculativeConfig(3),
                            max_num_seqs=4, max_model_len=256, block_size=16, device=DEV)
     w.init_device()
-    nb, _ = w.determine_num_available_blocks()
-    w.initialize_cache(nb, 0)
+    w.initialize_cache(64, 0)
     eng = w.engine
     toks = {}
+    rid_of = {}
 
     def mk(rid, n):
-        return SequenceGroupMetadata(rid, True, {hash(rid) % 1000: SequenceData(rng.integers(0, 2048, n).tolist())})
+        rid_of[ord(rid)] = rid
+        return SequenceGroupMetadata(rid, True, {ord(rid): SequenceData(rng.integers(0, 2048, n).tolist())})
 
     def absorb(outs):
         for o in outs:
-            for rid, t in zip(o.request_ids, o.sampled_token_ids.tolist()):
-                if t != -1:
-                    toks.setdefault(rid, []).append(t)
+            for grp in o.outputs:                       # request order; the sequence id names the request
+                smp = grp.samples[0]
+                if smp.output_token != -1:
+                    toks.setdefault(rid_of[smp.parent_seq_id], []).append(smp.output_token)
         torch.cuda.synchronize()
         assert eng._len_ub == eng.seq_lens.tolist()
 
@@ -822,6 +828,88 @@ def test_worker_variable_batch_on_the_gpu(tiny):
         assert toks[rid] == gen[w._slots[rid]], rid
     assert len(toks["a"]) >= 3
     assert w.execute_model(None) == []
+
+
+def test_cycle_recovery_replay_is_bit_identical(tiny):
+    """A cycle whose error word is non-zero (a device-side hand-off timed out) is re-run from the state snapshot taken at
+    its start, without hand-offs (engine.recover): the replay must emit exactly what an undisturbed engine emits --
+    sequence state, sampler counters and the Philox state restored, the one-workgroup kernel forms bit-identical."""
+    from qspec_amd import ops
+    from qspec_amd.spec_decode import QSpecEngine
+    rng = np.random.default_rng(14)
+    prompts = [rng.integers(0, tiny.config.vocab_size, n).tolist() for n in (20, 31, 8, 50)]
+    runs = []
+    for poke in (False, True):
+        eng = QSpecEngine(tiny, 3, 4, max_model_len=256, block_size=16, max_new_tokens=64, use_graph=False, seed=11)
+        eng.add_sequences(prompts)
+        eng.step()
+        out0, err = eng.read_outputs()
+        assert err == 0
+        eng.note_emitted([int((out0[b] != -1).sum()) for b in range(4)])
+        if poke:   # raise this stream's sticky exchange-workspace error word: the next cycle reports it
+            ops.xwg_workspace(DEV)[:1].fill_(1)
+        eng.step()
+        out, err = eng.read_outputs()
+        assert (err != 0) == poke
+        if poke:
+            eng.recover()
+            out, err = eng.read_outputs()
+            assert err == 0 and eng.recoveries == 1
+        eng.note_emitted([int((out[b] != -1).sum()) for b in range(4)])
+        eng.step()                                                # and the engine carries on from the recovered state
+        out2, err2 = eng.read_outputs()
+        assert err2 == 0
+        runs.append((out.clone(), out2.clone(), eng.generated(), eng.metrics(), eng.sampler.rng_state.tolist()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][2:] == runs[1][2:]
+
+
+def test_worker_from_vllm_config_loads_a_checkpoint_directory(tiny, tmp_path):
+    """create_spec_worker(vllm_config=...) -> init_device loads `model_config.model` (a directory in the reference's
+    on-disk format) through qspec_amd/checkpoint.py, and the worker then emits what the in-memory model emits."""
+    from types import SimpleNamespace
+    from qspec_amd import checkpoint
+    from qspec_amd.spec_decode import ExecuteModelRequest, SamplingParams, SequenceData, SequenceGroupMetadata, create_spec_worker
+    checkpoint.save_qspec_checkpoint(tiny, str(tmp_path))
+    c = tiny.config
+    hf = SimpleNamespace(model_type="llama_quarot", hidden_size=c.hidden_size, intermediate_size=c.intermediate_size,
+                         num_attention_heads=c.num_attention_heads, num_key_value_heads=c.num_key_value_heads,
+                         num_hidden_layers=c.num_hidden_layers, vocab_size=c.vocab_size, rms_norm_eps=c.rms_norm_eps,
+                         rope_theta=c.rope_theta, max_position_embeddings=c.max_position_embeddings)
+    cfg = SimpleNamespace(
+        model_config=SimpleNamespace(hf_config=hf, max_model_len=256, model=str(tmp_path), seed=0, max_logprobs=5),
+        cache_config=SimpleNamespace(block_size=16, gpu_memory_utilization=0.9, swap_space_bytes=0),
+        scheduler_config=SimpleNamespace(max_num_seqs=2, max_num_batched_tokens=512),
+        parallel_config=SimpleNamespace(tensor_parallel_size=1, pipeline_parallel_size=1),
+        load_config=SimpleNamespace(load_format="auto"),
+        speculative_config=SimpleNamespace(num_speculative_tokens=3, speculative_disable_by_batch_size=None,
+                                           disable_log_stats=False, disable_logprobs=False,
+                                           draft_token_acceptance_method="rejection_sampler"))
+    rng = np.random.default_rng(6)
+    prompts = [rng.integers(0, c.vocab_size, n).tolist() for n in (9, 14)]
+    results = []
+    for kw in (dict(vllm_config=cfg, local_rank=0, rank=0, distributed_init_method=None, is_driver_worker=True),
+               dict(vllm_config=cfg, local_rank=0, rank=0, model=tiny)):
+        w = create_spec_worker(**kw)
+        w.init_device()
+        w.load_model()
+        assert w.get_model() is not None and (w.get_model() is tiny) == ("model" in kw)
+        w.initialize_cache(32, 0)
+        sp = SamplingParams(logprobs=2)
+        sgs = [SequenceGroupMetadata(f"r{i}", True, {i: SequenceData(p)}, sampling_params=sp) for i, p in enumerate(prompts)]
+        out = w.execute_model(ExecuteModelRequest(sgs, num_lookahead_slots=0))
+        seq = [out[0].token_ids()]
+        dec = [SequenceGroupMetadata(s.request_id, False, s.seq_data, sampling_params=sp) for s in sgs]
+        outs = w.execute_model(ExecuteModelRequest(dec, num_lookahead_slots=3))
+        seq += [o.token_ids() for o in outs]
+        # disable_logprobs=False: real target logprobs -- the sampled token's entry + the two best, ranks from 1
+        lp = outs[0].outputs[0].samples[0].logprobs
+        tok = outs[0].outputs[0].samples[0].output_token
+        assert tok in lp and lp[tok].rank >= 1 and lp[tok].logprob <= 0.0 and 2 <= len(lp) <= 3
+        assert 1 in [v.rank for v in lp.values()]
+        assert outs[0].spec_decode_worker_metrics is None or outs[0].spec_decode_worker_metrics.num_spec_tokens == 3
+        results.append(seq)
+    assert results[0] == results[1]
 
 
 # ------------------------------------------------------------------ checkpoint on disk -> HIP path

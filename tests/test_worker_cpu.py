@@ -10,8 +10,11 @@ import pytest
 import torch
 
 from qspec_amd.model import QuarotLlamaConfig
-from qspec_amd.spec_decode.worker import (ExecuteModelRequest, SequenceData, SequenceGroupMetadata, SpeculativeConfig,
-                                          create_spec_worker)
+from types import SimpleNamespace
+
+from qspec_amd.spec_decode.worker import (CompletionSequenceGroupOutput, DeviceHandoffTimeout, ExecuteModelRequest,
+                                          Logprob, SamplingParams, SequenceData, SequenceGroupMetadata, SequenceOutput,
+                                          SpeculativeConfig, create_spec_worker)
 
 
 class FakeSampler:
@@ -25,8 +28,11 @@ class FakeSampler:
 class FakeEngine:
     """The QSpecEngine surface the worker uses, with scripted outputs: out_script(step_index, slots) -> [B, k+1]."""
 
-    def __init__(self, model, k, B, max_model_len, block_size, seed=0):
+    def __init__(self, model, k, B, max_model_len, block_size, seed=0, num_blocks=None):
         self.k, self.B = k, B
+        self.num_blocks = num_blocks
+        self.err_script = []          # error words the next read_outputs() calls return (then 0)
+        self.recoveries = 0
         self.sampler = FakeSampler()
         self.out_tokens = torch.full((B, k + 1), -1, dtype=torch.int64)
         self.gen_tokens = torch.full((B, 64), -1, dtype=torch.int64)
@@ -85,15 +91,30 @@ class FakeEngine:
     def error_flag(self):
         return 0
 
+    def read_outputs(self):
+        return self.out_tokens.clone(), (self.err_script.pop(0) if self.err_script else 0)
+
+    def recover(self):
+        self.calls.append(("recover",))
+        self.recoveries += 1
+
 
 CFG = QuarotLlamaConfig(1024, 3584, 8, 2, 2, 2048, 1e-5, 10000.0, 512, "tiny")
 
 
-def make_worker(k=3, B=4, disable_by_batch_size=None, model=None, rank=0):
+GiB = 1 << 30
+
+
+def fake_memory_probe():
+    """(free bytes with the weights loaded, total bytes, torch peak increase of the profiled prompt pass + cycle)."""
+    return 200 * GiB, 288 * GiB, 2 * GiB
+
+
+def make_worker(k=3, B=4, disable_by_batch_size=None, model=None, rank=0, **kw):
     w = create_spec_worker(model_config=CFG, model=model if model is not None else object(),
                            speculative_config=SpeculativeConfig(k, speculative_disable_by_batch_size=disable_by_batch_size),
                            max_num_seqs=B, max_model_len=256, block_size=16, device="cpu", engine_factory=FakeEngine,
-                           disable_log_stats=True, rank=rank)
+                           disable_log_stats=True, rank=rank, memory_probe=fake_memory_probe, **kw)
     w.init_device()
     nb, _ = w.determine_num_available_blocks()
     w.initialize_cache(nb, 0)
@@ -113,8 +134,8 @@ def test_prefill_assigns_slots_and_honours_block_tables():
     w = make_worker()
     sg = [prompt("a", 10, 5, [3, 4]), prompt("b", 11, 9)]
     out = w.execute_model(ExecuteModelRequest(sg, num_lookahead_slots=0))
-    assert len(out) == 1 and out[0].request_ids == ["a", "b"]
-    assert out[0].sampled_token_ids.tolist() == [1000, 1001]          # the target's first token of each prompt
+    assert len(out) == 1 and [o.samples[0].parent_seq_id for o in out[0].outputs] == [10, 11]
+    assert out[0].token_ids() == [1000, 1001]                         # the target's first token of each prompt
     assert w.engine.calls == [("add", 0, 5, (3, 4)), ("add", 1, 9, None)]
     assert w.proposer_calls == 0 and w.scorer_calls == 1              # the proposer never runs on prefill (:699)
     with pytest.raises(AssertionError):
@@ -135,13 +156,13 @@ def test_output_format_order_and_subset():
     outs = w.execute_model(req)
     assert w.engine.calls[-1] == ("step", (2, 0, 1))
     assert req.w4a4 is False and w.proposer_calls == k                # toggled around the proposer only (:797-812)
-    assert [o.request_ids for o in outs] == [["c", "a", "b"]] * 3     # step 4 is all -1 for these three: dropped
-    assert [o.sampled_token_ids.tolist() for o in outs] == [[31, 11, 21], [32, 12, -1], [33, -1, -1]]
+    assert [[g.samples[0].parent_seq_id for g in o.outputs] for o in outs] == [[2, 0, 1]] * 3   # request order; step 4
+    assert [o.token_ids() for o in outs] == [[31, 11, 21], [32, 12, -1], [33, -1, -1]]          # is all -1: dropped
     assert w.engine._len_ub[3] == 4 + 3 + 1                           # "d" did not advance
     assert w.engine._len_ub[2] == 4 + 2 + 1 + 3                       # "c": three tokens emitted
     # all four, bonus token for "d": four steps come back
     outs = w.execute_model(ExecuteModelRequest([decode(s) for s in sgs], num_lookahead_slots=k))
-    assert len(outs) == 4 and outs[3].sampled_token_ids.tolist() == [-1, -1, -1, 44]
+    assert len(outs) == 4 and outs[3].token_ids() == [-1, -1, -1, 44]
 
 
 def test_bonus_token_tracking_and_finished_requests():
@@ -164,7 +185,7 @@ def test_bonus_token_tracking_and_finished_requests():
     out = w.execute_model(ExecuteModelRequest([prompt("c", 300, 3)], num_lookahead_slots=0, finished_requests_ids=["b"]))
     assert ("free", 1) in w.engine.calls and w._slots == {"a": 0, "c": 1}
     assert w._seq_with_bonus_token_in_last_step == set() and "b" not in w._request_id_seq_id_mapping
-    assert out[0].sampled_token_ids.tolist() == [1001]
+    assert out[0].token_ids() == [1001]
     with pytest.raises(KeyError):
         w.execute_model(ExecuteModelRequest([decode(sgs[1])], num_lookahead_slots=k))     # "b" is gone
 
@@ -177,7 +198,7 @@ def test_speculation_off_paths():
     w.execute_model(ExecuteModelRequest(sgs, num_lookahead_slots=0))
     dec = [decode(s) for s in sgs]
     out = w.execute_model(ExecuteModelRequest(dec, num_lookahead_slots=0))
-    assert len(out) == 1 and out[0].sampled_token_ids.tolist() == [500, 501] and w.engine.calls[-1][0] == "step_no_spec"
+    assert len(out) == 1 and out[0].token_ids() == [500, 501] and w.engine.calls[-1][0] == "step_no_spec"
     out = w.execute_model(ExecuteModelRequest(dec, num_lookahead_slots=3, running_queue_size=3))
     assert len(out) == 1 and w.engine.calls[-1] == ("step_no_spec", (0, 1)) and w.proposer_calls == 0
     for s in dec:
@@ -195,7 +216,7 @@ def test_mixed_prompt_and_decode_batch_without_lookahead():
     a = prompt("a", 1, 4)
     w.execute_model(ExecuteModelRequest([a], num_lookahead_slots=0))
     out = w.execute_model(ExecuteModelRequest([prompt("b", 2, 5), decode(a)], num_lookahead_slots=0))
-    assert out[0].request_ids == ["b", "a"] and out[0].sampled_token_ids.tolist() == [1001, 500]
+    assert [g.samples[0].parent_seq_id for g in out[0].outputs] == [2, 1] and out[0].token_ids() == [1001, 500]
     assert w.engine.calls[-2:] == [("add", 1, 5, None), ("step_no_spec", (0,))]
     assert w.engine._len_ub == [6, 6, 0, 0]
 
@@ -249,3 +270,225 @@ def test_tensor_parallel_control_plane_two_ranks():
     assert workers[1].engine.calls == d.engine.calls
     assert d.engine.calls == [("add", 0, 4, None), ("add", 1, 5, None), ("step", (0, 1)), ("free", 0), ("step_no_spec", (1,))]
     assert workers[1]._slots == d._slots == {"b": 1}
+
+
+# ------------------------------------------------------------------ the reference's binding: vllm_config, output records
+
+def vllm_config(k=3, max_num_seqs=4, tp=1, pp=1, load_format="dummy", model="/nonexistent/Llama3_8B_Instruct_QSpec",
+                disable_logprobs=True, disable_by_batch_size=None):
+    """What vLLM's WorkerWrapper hands to create_spec_worker (spec_decode_worker.py:53-113), duck-typed."""
+    hf = SimpleNamespace(model_type="llama_quarot", hidden_size=1024, intermediate_size=3584, num_attention_heads=8,
+                         num_key_value_heads=2, num_hidden_layers=2, vocab_size=2048, rms_norm_eps=1e-5,
+                         rope_theta=10000.0, max_position_embeddings=512)
+    return SimpleNamespace(
+        model_config=SimpleNamespace(hf_config=hf, max_model_len=256, model=model, seed=0, max_logprobs=5),
+        cache_config=SimpleNamespace(block_size=16, gpu_memory_utilization=0.9, swap_space_bytes=4 * GiB),
+        scheduler_config=SimpleNamespace(max_num_seqs=max_num_seqs, max_num_batched_tokens=2048),
+        parallel_config=SimpleNamespace(tensor_parallel_size=tp, pipeline_parallel_size=pp),
+        load_config=SimpleNamespace(load_format=load_format),
+        speculative_config=SimpleNamespace(num_speculative_tokens=k, speculative_disable_by_batch_size=disable_by_batch_size,
+                                           disable_log_stats=True, disable_logprobs=disable_logprobs,
+                                           draft_token_acceptance_method="rejection_sampler",
+                                           speculative_disable_mqa_scorer=False))
+
+
+def worker_from_vllm_config(**kw):
+    w = create_spec_worker(vllm_config=vllm_config(**kw), local_rank=0, rank=0,
+                           distributed_init_method="tcp://127.0.0.1:29555", is_driver_worker=True,
+                           device="cpu", model=object(), engine_factory=FakeEngine)
+    w._memory_probe = fake_memory_probe
+    w.init_device()
+    nb, ncpu = w.determine_num_available_blocks()
+    w.initialize_cache(nb, ncpu)
+    return w, nb, ncpu
+
+
+def test_factory_binds_vllm_config():
+    """create_spec_worker(*args, **kwargs) reads kwargs["vllm_config"] + local_rank / rank / distributed_init_method /
+    is_driver_worker as the reference's does (:53-113) -- not a bespoke keyword set that would silently build a synthetic
+    8B worker with four slots."""
+    w, nb, ncpu = worker_from_vllm_config(k=2, max_num_seqs=6, disable_by_batch_size=5)
+    c = w.model_config
+    assert (c.hidden_size, c.intermediate_size, c.num_attention_heads, c.num_key_value_heads, c.num_hidden_layers,
+            c.vocab_size, c.max_position_embeddings) == (1024, 3584, 8, 2, 2, 2048, 512)
+    assert (w.max_num_seqs, w.max_model_len, w.block_size, w.engine.k, w.disable_by_batch_size) == (6, 256, 16, 2, 5)
+    assert w.engine.num_blocks == nb and w.rank == 0 and w.max_logprobs == 5
+    with pytest.raises(NotImplementedError, match="pipeline parallelism"):
+        create_spec_worker(vllm_config=vllm_config(pp=2), local_rank=0, rank=0)
+    cfg = vllm_config()
+    cfg.speculative_config = None
+    with pytest.raises(AssertionError):
+        create_spec_worker(vllm_config=cfg, local_rank=0, rank=0)
+    cfg = vllm_config()
+    cfg.model_config.hf_config.model_type = "qwen2_quarot"
+    with pytest.raises(NotImplementedError, match="llama_quarot"):
+        create_spec_worker(vllm_config=cfg, local_rank=0, rank=0)
+
+
+def test_model_path_that_is_no_checkpoint_raises_instead_of_inventing_weights():
+    w = create_spec_worker(vllm_config=vllm_config(load_format="auto"), local_rank=0, rank=0, device="cpu",
+                           engine_factory=FakeEngine)
+    with pytest.raises(FileNotFoundError, match="not a local QSpec checkpoint"):
+        w.init_device()
+
+
+def test_num_available_blocks_from_profiled_memory():
+    """:400-426 over vllm/worker/worker.py:176-265: (total x utilisation - used - peak - 2 x peak) / block bytes, the
+    scorer's count un-split (:421-423); initialize_cache builds ONE cache of exactly that many blocks and refuses a
+    count that cannot hold max_model_len (raise_if_cache_size_invalid, worker.py:541-558)."""
+    w, nb, ncpu = worker_from_vllm_config()
+    block = 2 * 2 * 16 * 2 * 128 * 2                         # K+V x layers x block x kv heads x head_dim x fp16
+    assert w.cache_block_size_bytes() == block
+    available = 288 * GiB * 0.9 - (88 * GiB + 2 * GiB) - 2 * 2 * GiB
+    assert nb == int(available // block) and ncpu == 4 * GiB // block
+    assert w.memory_profile["torch_peak_increase"] == 2 * GiB and w.memory_profile["avoid_oom_memory"] == 4 * GiB
+    assert w.engine.num_blocks == nb
+    with pytest.raises(ValueError, match="No available memory"):
+        w.initialize_cache(0, 0)
+    with pytest.raises(ValueError, match="max seq len"):
+        w.initialize_cache(15, 0)                            # 15 x 16 = 240 tokens < max_model_len 256
+    w._memory_probe = lambda: (1 * GiB, 288 * GiB, 2 * GiB)  # a card that is already full
+    assert w.determine_num_available_blocks()[0] == 0
+
+
+class Sequence:
+    """The slice of vllm.sequence.Sequence the multi-step output processor touches."""
+
+    def __init__(self, seq_id, prompt_len):
+        self.seq_id, self.prompt_len, self.output, self.logprobs = seq_id, prompt_len, [], []
+
+    def get_output_len(self):
+        return len(self.output)
+
+
+def process_outputs(seq, outputs, sampling_params, eos_token_id):
+    """Restatement of MultiStepOutputProcessor.process_outputs / _process_seq_outputs
+    (vllm/engine/output_processor/multi_step.py:100-176): takes `output.samples[0]` of every step, asserts the parent
+    sequence id, drops invalid (-1) tokens, truncates to max_tokens and after EOS, appends."""
+    assert all(isinstance(o, CompletionSequenceGroupOutput) for o in outputs)
+    assert all(seq.seq_id == o.samples[0].parent_seq_id for o in outputs)
+    samples = [o.samples[0] for o in outputs]
+    valid = [s for s in samples if s.output_token != -1]
+    if not valid:
+        return
+    ids = [s.output_token for s in valid]
+    lps = [s.logprobs for s in valid]
+    remaining = sampling_params.max_tokens - (seq.get_output_len() + len(ids))
+    if remaining < 0:
+        ids = ids[:remaining]
+    if not sampling_params.ignore_eos:
+        for i, t in enumerate(ids):
+            if t == eos_token_id:
+                ids = ids[:i + 1]
+                break
+    for t, lp in zip(ids, lps):
+        assert t in lp and isinstance(lp[t], Logprob)            # vLLM logprobs always include the sampled token
+        seq.output.append(t)
+        seq.logprobs.append(lp)
+
+
+def test_outputs_feed_the_multi_step_output_processor():
+    """The worker's List[SamplerOutput] is what LLMEngine hands to MultiStepOutputProcessor per sequence group:
+    outputs[i] of every step (spec_decode_worker.py:1023-1046 -> multi_step.py:100-176)."""
+    EOS = 99
+    w, _, _ = worker_from_vllm_config(k=3)
+    sp = SamplingParams(max_tokens=5)
+    sgs = [SequenceGroupMetadata(r, True, {sid: SequenceData(list(range(n)))}, sampling_params=sp)
+           for r, sid, n in (("a", 7, 4), ("b", 8, 6), ("c", 9, 5))]
+    seqs = {sg.request_id: Sequence(next(iter(sg.seq_data)), 0) for sg in sgs}
+    out = w.execute_model(ExecuteModelRequest(sgs, num_lookahead_slots=0))
+    assert len(out) == 1 and isinstance(out[0].outputs[0], CompletionSequenceGroupOutput)
+    first = out[0].outputs[0].samples[0]
+    assert isinstance(first, SequenceOutput) and first.logprobs == {1000: Logprob(0.0, -1)}     # :652-660
+    assert out[0].sampled_token_ids is None and out[0].sampled_token_probs is None and out[0].logprobs is None
+    for i, sg in enumerate(sgs):
+        process_outputs(seqs[sg.request_id], [o.outputs[i] for o in out], sp, EOS)
+    assert [seqs[r].output for r in "abc"] == [[1000], [1001], [1002]]
+    # one speculative step: "a" gets all k + bonus, "b" hits EOS at its second token, "c" emits one token
+    w.engine.out_script = lambda step, slots: {0: [11, 12, 13, 14], 1: [21, EOS, 23, -1], 2: [31, -1, -1, -1]}
+    dec = [SequenceGroupMetadata(s.request_id, False, s.seq_data, sampling_params=sp) for s in sgs]
+    outs = w.execute_model(ExecuteModelRequest(dec, num_lookahead_slots=3))
+    assert len(outs) == 4 and all(len(o.outputs) == 3 for o in outs)
+    s0 = outs[0].outputs[0].samples[0]
+    assert (s0.parent_seq_id, s0.output_token, s0.logprobs) == (7, 11, {11: Logprob(0.0, -1)})   # dummy logprobs :1083
+    for i, sg in enumerate(dec):
+        process_outputs(seqs[sg.request_id], [o.outputs[i] for o in outs], sp, EOS)
+    assert seqs["a"].output == [1000, 11, 12, 13, 14]            # max_tokens = 5 reached exactly
+    assert seqs["b"].output == [1001, 21, EOS]                   # truncated after EOS
+    assert seqs["c"].output == [1002, 31]
+    # a step in which nothing follows position 0: the list stops at the first all-(-1) position (:1023-1026)
+    w.engine.out_script = lambda step, slots: {2: [32, -1, -1, -1]}
+    outs = w.execute_model(ExecuteModelRequest([dec[2]], num_lookahead_slots=3, finished_requests_ids=["a", "b"]))
+    assert len(outs) == 1 and outs[0].token_ids() == [32]
+    # max_tokens truncation inside a step
+    seqs["c"].output = [1, 2, 3]
+    w.engine.out_script = lambda step, slots: {2: [41, 42, 43, 44]}
+    outs = w.execute_model(ExecuteModelRequest([dec[2]], num_lookahead_slots=3))
+    process_outputs(seqs["c"], [o.outputs[0] for o in outs], sp, EOS)
+    assert seqs["c"].output == [1, 2, 3, 41, 42]
+
+
+def test_requested_logprobs_with_dummy_lists_and_empty_prompt_chunk():
+    """num_logprobs > 0 while logprobs are disabled during speculation: the top-k entries of the dummy lists are None and
+    are dropped (util.py:78-86); a sequence group with do_sample == False gets an empty output (:625-631); prompt
+    logprobs requested -> one dummy dict per prompt token but the first (:637-650)."""
+    w, _, _ = worker_from_vllm_config(k=2)
+    sp = SamplingParams(logprobs=3, prompt_logprobs=1)
+    a = SequenceGroupMetadata("a", True, {1: SequenceData([5, 6, 7])}, sampling_params=sp)
+    b = SequenceGroupMetadata("b", True, {2: SequenceData([5, 6, 7, 8])}, sampling_params=SamplingParams(), do_sample=False)
+    out = w.execute_model(ExecuteModelRequest([a, b], num_lookahead_slots=0))
+    assert out[0].outputs[1].samples == [] and out[0].outputs[1].prompt_logprobs is None
+    assert out[0].outputs[0].prompt_logprobs == [{6: Logprob(0.0, -1)}, {7: Logprob(0.0, -1)}]
+    w.engine.out_script = lambda step, slots: {0: [9, 10, -1]}
+    outs = w.execute_model(ExecuteModelRequest([SequenceGroupMetadata("a", False, a.seq_data, sampling_params=sp)],
+                                               num_lookahead_slots=2))
+    assert [o.outputs[0].samples[0].logprobs for o in outs] == [{9: Logprob(0.0, -1)}, {10: Logprob(0.0, -1)}]
+
+
+def test_request_without_speculation_inside_a_speculative_step():
+    """A request with num_speculative_tokens == 0 in a speculative batch gets the target's single token (proposal length
+    0, top1_proposer.py:103-135): it sits out the cycle and takes the scorer-only step; the others speculate."""
+    w = make_worker(k=2)
+    sgs = [prompt("a", 1, 4), prompt("b", 2, 6)]
+    w.execute_model(ExecuteModelRequest(sgs, num_lookahead_slots=0))
+    dec = [decode(s) for s in sgs]
+    dec[1].num_speculative_tokens = 0
+    w.engine.out_script = lambda step, slots: {0: [5, 6, 7]} if step == 0 else None
+    outs = w.execute_model(ExecuteModelRequest(dec, num_lookahead_slots=2))
+    assert w.engine.calls[-2:] == [("step", (0,)), ("step_no_spec", (1,))]
+    assert [o.token_ids() for o in outs] == [[5, 501], [6, -1], [7, -1]]
+    with pytest.raises(ValueError, match="captured for"):
+        w.execute_model(ExecuteModelRequest([decode(s) for s in sgs], num_lookahead_slots=4))
+
+
+def test_device_handoff_timeout_replays_once_then_raises():
+    """A non-zero error word read with the cycle's output: the cycle is re-run once without device-side hand-offs
+    (engine.recover); only a second failure raises, and as a distinct exception type."""
+    w = make_worker(k=2)
+    a = prompt("a", 1, 4)
+    w.execute_model(ExecuteModelRequest([a], num_lookahead_slots=0))
+    w.engine.out_script = lambda step, slots: {0: [5, 6, -1]}
+    w.engine.err_script = [1]                                # the first read reports a timed-out hand-off
+    outs = w.execute_model(ExecuteModelRequest([decode(a)], num_lookahead_slots=2))
+    assert ("recover",) in w.engine.calls and [o.token_ids() for o in outs] == [[5], [6]]
+    w.engine.err_script = [1, 1]
+    a.seq_data[1].output_token_ids = []
+    with pytest.raises(DeviceHandoffTimeout):
+        w.execute_model(ExecuteModelRequest([decode(a)], num_lookahead_slots=2))
+
+
+def test_failed_admission_gives_the_slots_back():
+    """If the engine refuses an admission, worker and engine must still agree that the slots are free."""
+    w = make_worker()
+
+    def failing(slots, prompts, block_tables=None):
+        w.engine.add_sequence(slots[0], prompts[0])          # the first request got in ...
+        raise ValueError("prompt does not fit")              # ... the second did not
+    orig = w.engine.add_sequences_to
+    w.engine.add_sequences_to = failing
+    with pytest.raises(ValueError, match="does not fit"):
+        w.execute_model(ExecuteModelRequest([prompt("a", 1, 4), prompt("b", 2, 9)], num_lookahead_slots=0))
+    assert w._slots == {} and w.engine._len_ub == [0, 0, 0, 0]
+    w.engine.add_sequences_to = orig
+    out = w.execute_model(ExecuteModelRequest([prompt("a", 1, 4)], num_lookahead_slots=0))
+    assert out[0].token_ids() == [1000]
