@@ -91,6 +91,22 @@ def make_bench_engine_class():
     return BenchEngine
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run ... bench.py <same flags>` as
+    a CHILD process -- before this process has made any GPU call (never exec from a process that has initialised the
+    GPU) -- relay its output (rank 0 prints the JSON line) and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def dist_setup(n):
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if world > 1:
@@ -229,18 +245,66 @@ def measure_dominant_kernel(model, engine, reps=5):
     return tot_b, tot_t, launches, res
 
 
+def measure_verify_plans(model, eng, world, reps=10):
+    """N > 1: the verify forward (W4A16, T = batch x (k+1)) under BOTH plans -- decoder layers replicated / sharded with
+    three collectives per layer -- timed with events around a replayed hipGraph of that forward alone (eagerly where the
+    communicator cannot be captured), MAX over ranks.  With `tp_collective_us` this is what replaces the planning
+    constants: the plan is chosen from numbers of the job's own hardware."""
+    import gc
+    import torch.distributed as dist
+    res, keep = {}, model.tp.shard_layers
+
+    def fwd():
+        model.forward(eng.v_tokens, eng.v_pos, eng.kv_caches, eng.md_verify, eng.scratch_verify, w4a4=False)
+    for name, plan in (("replicated", False), ("sharded", True)):
+        model.tp.shard_layers = plan
+        fwd()
+        torch.cuda.synchronize()
+        fn, mode = fwd, "eager"
+        try:
+            gc.collect()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fwd()
+            g.replay()
+            fn, mode = g.replay, "graph"
+        except Exception:
+            torch.cuda.synchronize()
+        barrier(world)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([a.elapsed_time(b) / reps], dtype=torch.float64,
+                         device=eng.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        res[name] = {"ms": round(float(t.item()), 4), "mode": mode}
+    model.tp.shard_layers = keep
+    return res
+
+
+PMC_FILES = ("r03_pmc_fetch_size.json", "r03_pmc_fetch_size_bs32_k5.json", "r02_pmc_fetch_size.json")
+PMC_SOURCE = "profiles/r03_pmc_fetch_size*.json"
+
+
 def pmc_traffic_per_launch(model_name, batch, k):
     """HBM read bytes per launch of the dominant kernel from the PMC pass committed under profiles/ (a separate
     `rocprofv3 --pmc FETCH_SIZE --kernel-trace` run of scripts/profile_cycle.py; FETCH_SIZE KiB x 1024 x 2 = the gfx950
     correction for wide streaming reads, MI355X_MICROARCH.md).  The summary is keyed by workload: a number is returned
     only when its (model, batch, k) match this run, else None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_fetch_size.json")
-    try:
-        d = json.load(open(path))
-    except OSError:
-        return None
-    wl = d.get("workload", {})
-    if (wl.get("model"), wl.get("batch"), wl.get("k")) != (model_name, batch, k):
+    d = None
+    for name in PMC_FILES:           # the headline workload's pass, then the other committed workloads
+        try:
+            c = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except OSError:
+            continue
+        wl = c.get("workload", {})
+        if (wl.get("model"), wl.get("batch"), wl.get("k")) == (model_name, batch, k):
+            d = c
+            break
+    if d is None:
         return None
     tot = n = 0
     for name, v in d.get("kernels", {}).items():
@@ -308,6 +372,8 @@ def cpu_baseline(model, args, rho):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank, world, local = dist_setup(args.gpus)
     dev = f"cuda:{local}"
     torch.cuda.set_device(dev)
@@ -316,7 +382,9 @@ def main():
     cfg = CONFIGS[args.model]
     if world > 1:
         from qspec_amd import parallel
-        model = parallel.build_tp_model(cfg, dev, world, rank, seed=args.seed, lm_head_std=args.lm_head_std)
+        # the plan of the verify pass (shard the decoder layers or not) comes from the collectives' cost MEASURED here
+        model = parallel.build_tp_model(cfg, dev, world, rank, seed=args.seed, lm_head_std=args.lm_head_std,
+                                        tokens=args.batch * (args.k + 1))
     else:
         model = QuarotLlamaForCausalLM(cfg, dev).init_synthetic(args.seed, args.lm_head_std)
     rho = None if args.agreement.lower() == "none" else float(args.agreement)
@@ -403,9 +471,11 @@ def main():
                                 "verify pass: vocab-parallel lm_head + all-gather; decoder layers replicated (their collectives "
                                 "would cost more than the weight stream they save at this size); draft pass replicated")),
                    "tp_collective": (None if world == 1 else model.tp.backend),
-                   "tp_plan_basis": (None if world == 1 else "collective cost is an ESTIMATE (parallel.COLLECTIVE_US), not "
-                                     "measured on a multi-GPU box; QSPEC_TP_LAYERS=0/1 forces either plan"),
+                   "tp_plan_basis": (None if world == 1 else getattr(model.tp, "plan_basis", None)),
+                   "tp_collective_us": (None if world == 1 else getattr(model.tp, "collective_us", None)),
                    "agreement": rho,
+                   # what THIS run did: "graph" = the whole cycle incl. its collectives was captured and replayed (one rank
+                   # per GPU: the only configuration in which an RCCL-in-graph claim means anything)
                    "capture": ("graph" if eng._graph is not None else
                                ("draft-graph+eager-verify" if eng._graph_draft is not None else "eager"))},
         "draft_acceptance_rate": round(rate, 4), "system_efficiency": round(eff, 4),
@@ -430,11 +500,15 @@ def main():
                                    "cycles": cycles, "wall_s": round(wall, 4),
                                    "what": "demo.py:139-160: generated tokens / (prompt pass + decode) wall time, requests "
                                            "leave the batch at max_tokens"}
+    if world > 1:
+        out["config"]["tp_verify_forward"] = measure_verify_plans(model, eng, world)
     if rank == 0 and not args.no_roofline:   # the draft pass is replicated under TP: rank 0's launches are every rank's
         tot_b, tot_t, n, per_shape = measure_dominant_kernel(model, eng)
         achieved = tot_b / tot_t / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                            "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic_per_launch(cfg.name, args.batch, args.k),
+                           "traffic_source": PMC_SOURCE + " (builder's separate `rocprofv3 --pmc FETCH_SIZE` pass of the same "
+                                             "workload, committed; not collected in this run)",
                            "kernel": "qspec::gemm_w4a4_stream_kernel (the four decoder GEMM launches of a draft forward, M = batch, in "
                                      "the forms the cycle launches for this shape: LN+int4-quant prologue -> qkv+RoPE+KV-write / "
                                      "gate_up+silu*up and o_proj / down_proj + residual add where built, the plain (xq, xs) forms otherwise)",

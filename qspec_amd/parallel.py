@@ -309,10 +309,99 @@ def init_from_env(device: str) -> TensorParallel:
     return TensorParallel(rank, world, None)
 
 
-def build_tp_model(cfg, device: str, world: int, rank: int, seed: int = 0, lm_head_std: float = 0.02):
-    """Same synthetic weights on every rank (same seed), TP context attached."""
+def measure_collective_us(tp: "TensorParallel", T: int, H: int, I: int, device, iters: int = 20) -> dict:
+    """Time the three per-layer collectives of the sharded verify pass on THIS job's communicator, as they run in the
+    cycle (same shapes, same stream, back to back inside a captured graph where the backend allows it): the fp32
+    all-reduce of a [T, H] row-parallel partial (o_proj, down_proj) and the all-gather of the column-parallel gate_up
+    channels.  MAX over ranks, so that every rank plans from the same numbers.  Returns microseconds per collective."""
+    dev = torch.device(device)
+    part = torch.zeros(T, H, dtype=torch.float32, device=dev)
+    act = torch.zeros(T, I, dtype=torch.float16, device=dev)
+
+    def body():
+        tp.all_reduce(part)
+        tp.all_gather_channels(act, I)
+        tp.all_reduce(part)
+
+    def timed(fn, n):
+        if dev.type != "cuda":
+            import time
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            return (time.perf_counter() - t0) / n * 1e6
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) * 1e3 / n
+
+    body()
+    mode, fn = "eager", body
+    if dev.type == "cuda" and not tp.backend.endswith("gloo") and tp.backend != "threads":
+        try:   # the cycle replays its collectives from a hipGraph: measure them the same way
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            g.replay()
+            mode, fn = "graph", g.replay
+        except Exception:
+            torch.cuda.synchronize(dev)
+            mode, fn = "eager", body
+    per3 = timed(fn, iters)
+    ar = timed((lambda: tp.all_reduce(part)), iters) if mode == "eager" else None
+    t = torch.tensor([per3, ar if ar is not None else 0.0], dtype=torch.float64,
+                     device=dev if dev.type == "cuda" and not tp.backend.endswith("gloo") and tp.backend != "threads" else "cpu")
+    if tp.backend != "threads" and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=tp.group)
+    per3 = float(t[0])
+    out = {"three_collectives_per_layer_us": round(per3, 2), "per_collective_us": round(per3 / 3.0, 2), "mode": mode,
+           "backend": tp.backend, "all_reduce_f32_shape": [T, H], "all_gather_f16_shape": [T, I // tp.world]}
+    if ar is not None:
+        out["all_reduce_alone_us"] = round(float(t[1]), 2)
+    return out
+
+
+def shard_layers_pays_measured(layer_weight_bytes: int, world: int, three_collectives_us: float) -> bool:
+    """The plan from MEASURED collective cost: sharding saves (1 - 1/world) of the layer's weight stream and costs the
+    three collectives (plus their launch boundaries, already inside the measurement)."""
+    saved = layer_weight_bytes * (1.0 - 1.0 / world) / STREAM_BYTES_PER_US
+    return saved > three_collectives_us
+
+
+def attach_tp(m, rank: int, world: int, tokens: Optional[int] = None, group=None):
+    """Attach the tensor-parallel context to a model every rank holds in full.  The plan (shard the decoder layers of the
+    verify pass or keep them replicated) comes from the collectives' cost MEASURED on this job's communicator when
+    `tokens` (the verify pass's T) is given; QSPEC_TP_LAYERS=0/1 forces either plan; without a measurement the
+    planning constants decide."""
+    import os
+    cfg = m.config
+    layer_bytes = sum(lin.weight.numel() for lin in m.layers[0].linears())
+    m.tp = TensorParallel(rank, world, group, shard_layers=shard_layers_pays(layer_bytes, world))
+    m.tp.plan_basis = "forced by QSPEC_TP_LAYERS" if os.environ.get("QSPEC_TP_LAYERS") is not None else \
+        "planning constants (parallel.COLLECTIVE_US): no measurement requested"
+    m.tp.collective_us = None
+    if world > 1 and tokens is not None:
+        m.tp.collective_us = measure_collective_us(m.tp, tokens, cfg.hidden_size, cfg.intermediate_size, m.device)
+        if os.environ.get("QSPEC_TP_LAYERS") is None:
+            m.tp.shard_layers = shard_layers_pays_measured(layer_bytes, world,
+                                                           m.tp.collective_us["three_collectives_per_layer_us"])
+            m.tp.plan_basis = "collective cost measured in this job (parallel.measure_collective_us)"
+    return m
+
+
+def build_tp_model(cfg, device: str, world: int, rank: int, seed: int = 0, lm_head_std: float = 0.02,
+                   tokens: Optional[int] = None):
+    """Same synthetic weights on every rank (same seed), TP context attached (attach_tp)."""
     from .model import QuarotLlamaForCausalLM
     m = QuarotLlamaForCausalLM(cfg, device).init_synthetic(seed, lm_head_std)
-    layer_bytes = sum(lin.weight.numel() for lin in m.layers[0].linears())
-    m.tp = TensorParallel(rank, world, None, shard_layers=shard_layers_pays(layer_bytes, world))
-    return m
+    return attach_tp(m, rank, world, tokens)

@@ -351,10 +351,9 @@ class SpecDecodeWorker:
             raise FileNotFoundError(f"model_config.model = {self._model_path!r} is not a local QSpec checkpoint directory "
                                     "(no hub access here); pass load_format='dummy' for synthetic weights")
         if self._tp_size > 1:
-            from ..parallel import TensorParallel, shard_layers_pays
-            layer_bytes = sum(lin.weight.numel() for lin in model.layers[0].linears())
-            model.tp = TensorParallel(self._rank, self._tp_size, None,
-                                      shard_layers=shard_layers_pays(layer_bytes, self._tp_size))
+            from ..parallel import attach_tp
+            k = self.speculative_config.num_speculative_tokens
+            attach_tp(model, self._rank, self._tp_size, tokens=self.max_num_seqs * (k + 1))
         return model
 
     def load_model(self, *args, **kwargs):
