@@ -262,3 +262,18 @@ def test_batch32_draft_forms_vs_oracle(ops, oracle, M):
         out = torch.empty(M, H, dtype=torch.float16, device=DEV)
         ops.rowwise_scaled_linear_cutlass_s4s4_unified(dev(xq), dev(xs), dev(w), dev(wsc), None, out)
         assert np.array_equal(bits(host(out)), bits(oracle.gemm_w4a4(xq, xs, w, wsc)))
+
+
+def test_loader_consumer_engine_forms_are_bit_identical():
+    """The LDS-DMA loader / consumer forms of the draft GEMMs (gemm_stream.hip, `gemm_w4a4_engine_kernel`: gate_up + norm,
+    down_proj + residual at M <= 4; opt-in with QSPEC_ENGINE=1, see DESIGN.md "Stage A") against the same oracle
+    comparisons as the register forms: the launch-form tests of this file re-run in a child process with the switch on
+    (the library reads it once per process)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, QSPEC_ENGINE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                        "(gate_up or resid or draft) and not engine_forms"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
