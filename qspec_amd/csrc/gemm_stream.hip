@@ -793,11 +793,17 @@ __global__ __launch_bounds__((QS_ENG_NC + 4 + QS_ENG_NE) * 64) void gemm_w4a4_en
         for (int f = 0; f < FPT; f++) {
             acc[f] = i32x4{0, 0, 0, 0};
             Spec& cur = sp[f & 1];
+#ifdef QS_ENG_STAMPS2
+            if (cw == 0 && n >= 10) QS_ESTAMP(0, 20 + 5 * (n - 10) + 0);   // before confirm
+#endif
             confirm(cur, n, cslot);
             if (cw == 0) QS_ESTAMP(0, 6 + n);     // fill n in registers
             cslot = cslot + 1 == R ? 0 : cslot + 1;
             n++;
             if (n < n_fills) spec_load(sp[(f + 1) & 1], cslot);
+#ifdef QS_ENG_STAMPS2
+            if (cw == 0 && n - 1 >= 10) QS_ESTAMP(0, 20 + 5 * (n - 11) + 1);   // next spec loads issued (+ their wait: the stamp drains lgkmcnt)
+#endif
             u32x4 av[SPF];
             if constexpr (!AF_REGS) {
 #pragma unroll
@@ -811,6 +817,12 @@ __global__ __launch_bounds__((QS_ENG_NC + 4 + QS_ENG_NE) * 64) void gemm_w4a4_en
                 acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc[f], 0, 0, 0);
                 acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc[f], 0, 0, 0);
             }
+#ifdef QS_ENG_STAMPS2
+            if (cw == 0 && n - 1 >= 10) {
+                asm volatile("" :: "v"(acc[f]));   // (the MFMAs have been issued; s_memrealtime does not wait for their results)
+                QS_ESTAMP(0, 20 + 5 * (n - 11) + 2);
+            }
+#endif
         }
 #pragma unroll
         for (int f = 1; f < FPT; f++) acc[0] = acc[0] + acc[f];
@@ -828,6 +840,9 @@ __global__ __launch_bounds__((QS_ENG_NC + 4 + QS_ENG_NE) * 64) void gemm_w4a4_en
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) lds_flag_store(done + cw, ti + 1);
+#ifdef QS_ENG_STAMPS2
+        if (cw == 0 && n - 1 >= 10) QS_ESTAMP(0, 20 + 5 * (n - 11) + 3);   // tile posted
+#endif
     }
     if (cw == 0) QS_ESTAMP_DUMP(0);
 }
@@ -889,9 +904,22 @@ constexpr bool pro_split() { return PRO == PRO_LNS || PRO == PRO_LN1S; }
 #ifndef QS_LN_PF
 #define QS_LN_PF 1
 #endif
-template <int EPI, int PRO, int NW, int UB, int NI, int MT = 1>
-__global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w4a4_stream_kernel(StreamArgs a) {
+// DMA > 0 (split forms, M <= 4): the workgroup's tiles 1 .. DMA are brought in by FOUR LOADER WAVES with LDS-DMA
+// (global_load_lds_dwordx4 nt) from the first microsecond on, beside tile 0 in the stream waves' registers.  What bounds a
+// register-streaming CU is ~32 KB of loads in flight (a wave stalls at the issue beyond that); LDS-DMA loads are not subject
+// to it (scripts/micro/ldsdma.hip: four loader waves keep > 100 KB in flight and reach 7.3 TB/s over the chip), so the
+// bytes of the next tiles travel underneath the norm prologue and tile 0's latency instead of behind them.  The LDS image
+// of a tile is the register image (load j = stream wave j / UB, step j % UB: lane-linear, no swizzle), consumed with
+// ds_read_b128.  No flags: the loaders take part in the stream waves' barriers and wait for their tile's loads
+// (`s_waitcnt vmcnt`) in front of the barrier after which the tile is read -- the barrier IS the publication -- and retire.
+template <int EPI>
+constexpr int finish_barriers() { return (EPI == SEPI_QKV || EPI == SEPI_GATEUP) ? 2 : 1; }
+template <int N>
+__device__ __forceinline__ void vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int EPI, int PRO, int NW, int UB, int NI, int MT = 1, int DMA = 0>
+__global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ? 256 : 0)) void gemm_w4a4_stream_kernel(StreamArgs a) {
     static_assert(MT == 1 || (PRO == PRO_Q && NW >= 8), "two token tiles: (xq, xs) input, >= 512 threads for the epilogue");
+    static_assert(DMA == 0 || (pro_split<PRO>() && MT == 1 && NW * UB == 32 && DMA <= 3), "LDS-DMA tiles: split forms, 32 KiB tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef QS_STREAM_STAMPS
     long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -915,6 +943,37 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w
     f16* ex = reinterpret_cast<f16*>(red + 2 * NW * MT * 256);       // [2][MT * 256]
     float* lnred = reinterpret_cast<float*>(ex + 2 * MT * 256);      // [3][NG][RB][32]
     const int NB = Kb / (64 * NW * UB);                              // batches per tile (exact: checked on the host)
+    unsigned char* dma_lds = reinterpret_cast<unsigned char*>(lnred + 3 * NG * RB * 32);   // [DMA][32 KiB] (1 KiB aligned by the host)
+    dma_lds = smem + (((size_t)(dma_lds - smem) + 1023) & ~(size_t)1023);
+    if constexpr (DMA > 0) {
+        if (tid >= (NW + 4) * 64) {   // ---- loader waves (wave-uniform): issue, mirror the barriers, retire
+            const int lw = wave - (NW + 4);
+            const int mt = (a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+            const int nd = min(DMA, mt - 1);   // tiles this workgroup takes through LDS
+            const u32 base3 = (u32)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)dma_lds;
+            __builtin_amdgcn_s_barrier();   // #0 (the norm waves' row requests are out)
+            for (int d = 1; d <= nd; d++) {
+                const int td = blockIdx.x + d * (int)gridDim.x;
+                const uint8_t* wp = a.wq + (size_t)stile_row<EPI>(td, lane & 15, a.I) * Kb + (lane >> 4) * 16;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int j = lw + 4 * i;   // load j of the tile = (stream wave j / UB, step j % UB)
+                    glds16<1>(wp + step_off<NW, UB>(j / UB, j % UB), base3 + (u32)((d - 1) * 32 + j) * 1024u);
+                }
+            }
+            __builtin_amdgcn_s_barrier();   // #1
+            for (int d = 1; d <= nd; d++) {   // the barriers of finish(tile d - 1); tile d is read behind the last of them
+#pragma unroll
+                for (int b2 = 0; b2 < finish_barriers<EPI>() - 1; b2++) __builtin_amdgcn_s_barrier();
+                const int left = nd - d;      // tiles still allowed in flight (8 loads each)
+                if (left >= 2) vmcnt_le<16>();
+                else if (left == 1) vmcnt_le<8>();
+                else vmcnt_le<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+            return;
+        }
+    }
 
     // epilogue thread (tid < 256) owns accumulator element (token m, tile column c)
     // epilogue thread t owns output (token m = t / 16, tile column c = t % 16): for M <= 4 that is wave 0 alone, the
@@ -1037,7 +1096,9 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w
     Pre pre = {};
     const uint8_t* wp0 = wptr(tile, 0);
     // split forms: tiles beyond the first that the stream waves request underneath the norm (one batch per tile there)
-    constexpr int PF = SPLIT ? QS_LN_PF : 0;
+    constexpr int PF = (SPLIT && DMA == 0) ? QS_LN_PF : 0;
+    constexpr int SKIP = DMA > 0 ? DMA : PF;   // tiles behind tile 0 that do not come through `w`
+    Pre dpre[DMA > 0 ? DMA : 1];
     u32x4 pfw[PF > 0 ? PF : 1][UB];
     Pre pfpre[PF > 0 ? PF : 1];
 
@@ -1201,6 +1262,11 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w
                 load_pre(pfpre[d - 1], tile + d * (int)gridDim.x);
             }
         }
+        if constexpr (DMA > 0) {
+#pragma unroll
+            for (int d = 1; d <= DMA; d++)   // (clamped: no branch around a load; unused beyond my_tiles)
+                load_pre(dpre[d - 1], min(tile + d * (int)gridDim.x, a.ntiles - 1));
+        }
         __builtin_amdgcn_sched_barrier(0);
         QS_SSTAMP(1);
         // #1 (a bare barrier: __syncthreads() is fine too, the loads above are what this wave waits for next anyway; the
@@ -1277,10 +1343,10 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w
     // around a load and the waits hipcc inserts are the exact counted ones.
     QS_SSTAMP(2);
     int n_left = n_units;
-    if constexpr (PF > 0) {   // split forms (one batch per tile): tile 0 from w, tiles 1 .. PF from the prefetched registers
+    if constexpr (SKIP > 0) {   // split forms (one batch per tile): tile 0 from w, tiles 1 .. SKIP from registers / from LDS
         {
-            const bool more = PF + 1 < my_tiles;   // uniform
-            const int tn = tile + (PF + 1) * (int)gridDim.x;
+            const bool more = SKIP + 1 < my_tiles;   // uniform
+            const int tn = tile + (SKIP + 1) * (int)gridDim.x;
             Pre npre = pre;
             if (more) load_pre(npre, tn);          // (a branch around loads: everything in flight has arrived by now)
 #pragma unroll
@@ -1294,19 +1360,35 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w
             par ^= 1;
             pre = npre;
         }
+        if constexpr (DMA > 0) {
 #pragma unroll
-        for (int d = 1; d <= PF; d++) {
-            if (d < my_tiles) {   // uniform; no load inside
+            for (int d = 1; d <= DMA; d++) {
+                if (d < my_tiles) {   // uniform.  Tile d has landed: the loaders waited for it in front of the last barrier
+                    const unsigned char* tl = dma_lds + (size_t)((d - 1) * 32 + wave * UB) * 1024 + lane * 16;
+                    u32x4 lw4[UB];
 #pragma unroll
-                for (int u = 0; u < UB; u++) use(pfw[d - 1][u], 0, u);
-                finish(tile + d * (int)gridDim.x, par, pfpre[d - 1]);
-                par ^= 1;
+                    for (int u = 0; u < UB; u++) lw4[u] = *reinterpret_cast<const u32x4*>(tl + u * 1024);
+#pragma unroll
+                    for (int u = 0; u < UB; u++) use(lw4[u], 0, u);
+                    finish(tile + d * (int)gridDim.x, par, dpre[d - 1]);
+                    par ^= 1;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int d = 1; d <= PF; d++) {
+                if (d < my_tiles) {   // uniform; no load inside
+#pragma unroll
+                    for (int u = 0; u < UB; u++) use(pfw[d - 1][u], 0, u);
+                    finish(tile + d * (int)gridDim.x, par, pfpre[d - 1]);
+                    par ^= 1;
+                }
             }
         }
-        tile += (PF + 1) * (int)gridDim.x;
-        n_left = my_tiles - (PF + 1);
+        tile += (SKIP + 1) * (int)gridDim.x;
+        n_left = my_tiles - (SKIP + 1);
     }
-    if (PF == 0 || n_left > 0) {
+    if (SKIP == 0 || n_left > 0) {
     for (int q = 0; q < n_left - 1; q++) {
         int nb = b + 1, nt = tile;
         if (nb == NB) {
@@ -1357,6 +1439,221 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0)) void gemm_w
         g_wgspan[blockIdx.x][1] = t1;
     }
 #endif
+}
+
+// ------------------------------------------------------------------ self-service LDS-DMA form, M <= 4, K = 4096
+// The register-streaming kernel above with its weight loads replaced by LDS-DMA that every stream wave issues FOR ITSELF:
+// wave w brings its own four 1-KiB pieces of a tile (its K steps of the 16 rows: exactly the bytes its four register loads
+// fetched) into a private quarter of an LDS slot with `global_load_lds_dwordx4 ... nt`, R tiles ahead, and learns that they
+// have landed from its OWN `s_waitcnt vmcnt(4 (R - 1))` -- no loader waves, no flags, no cross-wave hand-off of data.
+// Why it is faster than registers: a register-streaming CU holds ~32 KB of loads in flight (a wave stalls at the issue
+// beyond that) and every tile in flight costs 4 VGPRs x 4 steps; LDS-DMA loads are subject to neither, so R = 4 tiles =
+// 128 KB per CU are requested before the norm prologue has even started, and the stream runs underneath the prologue, the
+// reductions and the epilogues at what the memory system delivers (scripts/micro/ldsdma.hip: 7.3 TB/s with four issuing
+// waves per CU against 6.6 for the register path's pure read).  Why it is simpler than the loader / consumer engine above:
+// the wave that waits for the bytes is the wave that uses them.
+// The stream waves issue NO compiler-visible vector-memory operation after the prologue (hipcc's own vmcnt bookkeeping
+// does not know the asm loads; a tracked load or store in the loop would make it wait for the run-ahead tiles): the
+// epilogue -- channel scales, cos / sin, residual, stores -- belongs to one wave that streams nothing: norm wave 0 after
+// the prologue (split-norm forms) or a wave of its own.  It meets the stream waves at ONE barrier per tile (partial sums
+// posted -> summed; double buffered) and exchanges the rotary / gate partner by a lane shuffle.
+template <int EPI, int PRO, int NI, int R>
+__global__ __launch_bounds__(8 * 64 + 256) void gemm_w4a4_sdma_kernel(StreamArgs a) {
+    static_assert(PRO == PRO_LN1S || PRO == PRO_LNS, "prologues built so far");
+    static_assert(EPI == SEPI_GATEUP || EPI == SEPI_QKV, "epilogues built so far");
+    static_assert(R >= 2 && R <= 4, "tiles in flight");
+    constexpr int NW = 8, UB = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int Kb = a.K >> 1, RS = Kb + 32;
+    unsigned char* xq_lds = smem;                                        // [4][RS]
+    float* xs_lds = reinterpret_cast<float*>(smem + (size_t)4 * RS);     // [16]
+    int* red = reinterpret_cast<int*>(xs_lds + 16);                      // [2][NW][64]: (token m < 4, column c) at m * 16 + c
+    unsigned char* ring = smem + (((size_t)4 * RS + 64 + 2 * NW * 256 + 1023) & ~(size_t)1023);   // [R][32 KiB]
+    const int my_tiles = (a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // >= 1
+    constexpr bool HASD = PRO == PRO_LNS;
+
+    if (tid >= NW * 64) {   // ---------------------------------------------------------------- norm waves; wave NW = epilogue
+        const int row = wave - NW;
+        LnwRegs<NI> rg;
+        lnw_load<NI, HASD>(a, row, rg);
+        // epilogue operands of ALL this workgroup's tiles, requested now (before the stream fills the CU's memory queue)
+        const int c = lane & 15, m = lane >> 4;
+        const int mc = m < a.M ? m : 0;
+        constexpr int MAXT = EPI == SEPI_QKV ? 2 : 8;   // tiles per workgroup (host-checked)
+        f16 swn[MAXT], cf[MAXT], sf[MAXT];
+        int64_t pos_m = 0, slot_m = -1;
+        if (row == 0) {
+            if (EPI == SEPI_QKV) {
+                pos_m = a.positions[mc];
+                slot_m = a.slot_mapping[mc];
+            }
+#pragma unroll
+            for (int i = 0; i < MAXT; i++) {
+                const int tl = min((int)blockIdx.x + i * (int)gridDim.x, a.ntiles - 1);   // clamped: no branch around a load
+                swn[i] = a.ws[stile_row<EPI>(tl, c, a.I)];
+                if (EPI == SEPI_QKV) {
+                    const int o = (tl & 7) * 8 + (c & 7);
+                    const f16* cs = a.cos_sin_cache + pos_m * 128;
+                    cf[i] = cs[o];
+                    sf[i] = cs[64 + o];
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();   // #0: every row request is out before any weight request (in-order L1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (row < a.M) lnw_compute<NI, HASD>(a, row, rg, xq_lds, RS, xs_lds, blockIdx.x == 0 && a.hidden_out != nullptr);
+        __syncthreads();                // #1: publishes xq_lds / xs_lds
+        if (row != 0) return;           // retired waves leave the workgroup's later barriers
+        // ---- the epilogue wave: lane = (token m, tile column c)
+        const bool ethread = m < a.M;
+        const float xs_m = xs_lds[mc];
+        int tile = blockIdx.x, par = 0;
+#pragma unroll
+        for (int i = 0; i < MAXT; i++) {
+            if (i >= my_tiles) break;
+            __syncthreads();            // A(i): the stream waves have posted tile i's partial sums
+            const int* rb = red + par * NW * 64;
+            int sum = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2++) sum += rb[w2 * 64 + lane];
+            const float v = ((float)(sum >> 8) * xs_m) * h2f(swn[i]);  // both operands carried a factor 16
+            const f16 hv = f2h(v);
+            const f16 partner = u2h((uint16_t)__shfl_xor((int)h2u(hv), 8, 64));
+            if (EPI == SEPI_GATEUP) {
+                if (ethread && c < 8) {  // hv = up, partner = gate
+                    const float gt = h2f(partner);
+                    const float act = h2f(f2h(gt / (1.0f + qexpf(-gt))));
+                    a.out[(size_t)m * a.I + tile * 8 + c] = f2h(act * h2f(hv));
+                }
+            } else {   // SEPI_QKV
+                const int head = tile >> 3, o = (tile & 7) * 8 + (c & 7);
+                const int n = head * 128 + (c >> 3) * 64 + o;
+                f16 res = hv;
+                if (head < a.nq + a.nkv) {
+                    const float cff = h2f(cf[i]), sff = h2f(sf[i]);
+                    const float xf = h2f(c < 8 ? hv : partner), yf = h2f(c < 8 ? partner : hv);
+                    res = c < 8 ? f2h(h2f(f2h(xf * cff)) - h2f(f2h(yf * sff))) : f2h(h2f(f2h(yf * cff)) + h2f(f2h(xf * sff)));
+                }
+                if (ethread) {
+                    a.out[(size_t)m * a.N + n] = res;
+                    if (head >= a.nq && slot_m >= 0) {
+                        const bool is_k = head < a.nq + a.nkv;
+                        const int kvh = is_k ? head - a.nq : head - a.nq - a.nkv;
+                        f16* cache = is_k ? a.key_cache : a.value_cache;
+                        cache[(slot_m * a.nkv + kvh) * 128 + (c >> 3) * 64 + o] = res;
+                    }
+                }
+            }
+            par ^= 1;
+            tile += gridDim.x;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- stream waves
+    const u32 ring0 = (u32)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)ring;
+    const u32 my_lds = ring0 + (u32)(wave * UB) * 1024u;    // this wave's quarter-KiB-pieces of slot 0 (+ slot * 32 KiB + u * 1 KiB)
+    auto issue_tile = [&](int ti) {   // this wave's four pieces of the workgroup's ti-th tile
+        const int t = blockIdx.x + ti * (int)gridDim.x;
+        const uint8_t* wp = a.wq + (size_t)stile_row<EPI>(t, r, a.I) * Kb + g * 16;
+        const u32 dst = my_lds + (u32)(ti % R) * 32768u;
+#pragma unroll
+        for (int u = 0; u < UB; u++) glds16<1>(wp + step_off<NW, UB>(wave, u), dst + (u32)u * 1024u);
+    };
+    __builtin_amdgcn_s_barrier();       // #0
+#pragma unroll
+    for (int ti = 0; ti < R; ti++)
+        if (ti < my_tiles) issue_tile(ti);
+    __builtin_amdgcn_s_barrier();       // #1: the packed rows and their scales are in LDS
+    asm volatile("" ::: "memory");
+    // A wave owns the same K steps of every tile: its activation fragments are widened once and stay in registers
+    i32x4 af0[UB], af1[UB];
+    {
+        const unsigned char* arow = xq_lds + (size_t)(r & 3) * RS + g * 16;
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const u32x4 av = *reinterpret_cast<const u32x4*>(arow + step_off<NW, UB>(wave, u));
+            af0[u] = widen16(av[0], av[1]);
+            af1[u] = widen16(av[2], av[3]);
+        }
+    }
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
+    const __attribute__((address_space(3))) unsigned char* my3 =
+        (const __attribute__((address_space(3))) unsigned char*)ring + (size_t)(wave * UB) * 1024 + lane * 16;
+    int par = 0;
+    for (int ti = 0; ti < my_tiles; ti++) {
+        // tile ti's four loads are the oldest of this wave's (4 per tile in flight, in issue order)
+        const int ahead = min(R - 1, my_tiles - 1 - ti);   // tiles issued behind tile ti
+        if (ahead >= 3) vmcnt_le<12>();
+        else if (ahead == 2) vmcnt_le<8>();
+        else if (ahead == 1) vmcnt_le<4>();
+        else vmcnt_le<0>();
+        u32x4 w[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++)
+            w[u] = *reinterpret_cast<const volatile lds_u32x4_t*>(my3 + (size_t)(ti % R) * 32768 + u * 1024);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef QS_SDMA_LATE_ISSUE
+        if (ti + R < my_tiles) issue_tile(ti + R);   // into the slot just read
+#endif
+        i32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const i32x4 b0 = widen16(w[u][0], w[u][1]), b1 = widen16(w[u][2], w[u][3]);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af0[u], b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1[u], b1, acc, 0, 0, 0);
+        }
+        // (the MFMA leaves (token m, column c) in acc[m & 3] of lane (m >> 2) * 16 + c: M <= 4 -> lanes 0..15 hold it all)
+        int* rb = red + par * NW * 64;
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) rb[wave * 64 + i * 16 + lane] = acc[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // A(ti) (raw: a __syncthreads() here would wait for vmcnt(0), i.e. for the run-ahead tiles)
+#ifdef QS_SDMA_LATE_ISSUE
+        if (ti + R < my_tiles) issue_tile(ti + R);   // into the slot read above
+#endif
+        par ^= 1;
+    }
+}
+
+template <int EPI, int PRO, int NI, int R>
+static int launch_sdma_inst(const StreamArgs& a, hipStream_t st) {
+    const size_t lds = (((size_t)4 * (a.K / 2 + 32) + 64 + 2 * 8 * 256 + 1023) & ~(size_t)1023) + (size_t)R * 32768;
+    if (lds > 160 * 1024) return -7;
+    static bool attr_set = false;  // per instantiation
+    auto kern = gemm_w4a4_sdma_kernel<EPI, PRO, NI, R>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -8;
+        attr_set = true;
+    }
+    const int grid = a.ntiles < 256 ? a.ntiles : 256;   // one workgroup per CU
+    if ((a.ntiles + grid - 1) / grid > (EPI == SEPI_QKV ? 2 : 8)) return -9;   // epilogue operands held per workgroup
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(8 * 64 + 256), lds, st, a);
+    return 0;
+}
+#ifndef QS_SDMA_R
+#define QS_SDMA_R 2
+#endif
+// QSPEC_SDMA=1 selects the self-service LDS-DMA forms (gate_up / qkv with the norm prologue, M <= 4, K = 4096).  OFF by
+// default: measured in round 3, launches of ONE shape back to back run 12.9 us (R = 2; 13.5 / 13.9 with R = 3 / 4) against
+// 13.65 for the register kernel, and qkv 5.9-6.3 against 6.7-6.8 -- but inside the cycle (and in bench.py's four-shape
+// graph) gate_up does not gain (13.4-13.7 against 13.2-13.4) and the cycle LOSES 1.5 % (7.73-7.76 against 7.62 ms).
+// More run-ahead is worse, not better: what a CU draws is not raised by requesting more (rounds 1 and 2 found the same
+// for register loads), and the waves that issue the run-ahead loads sit in the issue while the queue is full.
+static int g_sdma = -1;
+static bool sdma_on() {
+    if (g_sdma < 0) {
+        const char* e = getenv("QSPEC_SDMA");
+        g_sdma = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_sdma != 0;
 }
 
 // ------------------------------------------------------------------ W4A16 (verify pass), same streaming skeleton
@@ -1795,12 +2092,12 @@ static int stream_cap() {
     return g_stream_cap;
 }
 
-template <int EPI, int PRO, int NW, int UB, int NI, int MT = 1>
+template <int EPI, int PRO, int NW, int UB, int NI, int MT = 1, int DMA = 0>
 static int launch_stream_inst(const StreamArgs& a, hipStream_t st) {
-    const size_t lds = stream_lds_bytes(a.M, a.K, NW, PRO != PRO_Q, MT);
+    const size_t lds = stream_lds_bytes(a.M, a.K, NW, PRO != PRO_Q, MT) + (DMA > 0 ? 1024 + (size_t)DMA * 32768 : 0);
     if (lds > 160 * 1024) return -7;
     static size_t attr_set = 0;  // per instantiation
-    auto kern = gemm_w4a4_stream_kernel<EPI, PRO, NW, UB, NI, MT>;
+    auto kern = gemm_w4a4_stream_kernel<EPI, PRO, NW, UB, NI, MT, DMA>;
     if (lds > 64 * 1024 && lds > attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -8;
@@ -1813,7 +2110,7 @@ static int launch_stream_inst(const StreamArgs& a, hipStream_t st) {
         const int per = (a.ntiles + cap - 1) / cap;
         grid = (a.ntiles + per - 1) / per;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64 + (pro_split<PRO>() ? 256 : 0)), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ? 256 : 0)), lds, st, a);
     return 0;
 }
 
@@ -1826,6 +2123,15 @@ static bool ln_split() {
     return g_ln_split != 0;
 }
 
+static int g_dma_tiles = -1;   // QSPEC_DMA_TILES=0..3: tiles behind the first that a multi-tile workgroup takes through LDS-DMA
+static int dma_tiles() {
+    if (g_dma_tiles < 0) {
+        const char* e = getenv("QSPEC_DMA_TILES");   // default 0: 1 tile gains 0.6 us on back-to-back gate_up launches
+        g_dma_tiles = e ? atoi(e) : 0;               // (12.9 against 13.5), 2 / 3 tiles lose (13.45 / 13.75): round 3
+        if (g_dma_tiles < 0 || g_dma_tiles > 3) g_dma_tiles = 0;
+    }
+    return g_dma_tiles;
+}
 template <int EPI>
 static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
     StreamShape sh;
@@ -1865,6 +2171,14 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
         if (a.M <= 4 && ln_split()) {   // (K = 8192: the row-wave's 128 values per lane do not fit 168 VGPRs)
             if constexpr (EPI == SEPI_GATEUP)
                 if (a.K == 4096 && engine_on()) return launch_engine_inst<EPI, PRO_LN1S, 4, 2, 8>(a, st);
+            if constexpr (EPI == SEPI_GATEUP || EPI == SEPI_QKV)
+                if (a.K == 4096 && sdma_on()) return launch_sdma_inst<EPI, PRO_LN1S, 4, QS_SDMA_R>(a, st);
+            if (a.K == 4096 && a.ntiles > 256) {   // several tiles per workgroup: the next ones through LDS-DMA
+                const int dt = dma_tiles();
+                if (dt == 3) return launch_stream_inst<EPI, PRO_LN1S, 8, 4, 4, 1, 3>(a, st);
+                if (dt == 2) return launch_stream_inst<EPI, PRO_LN1S, 8, 4, 4, 1, 2>(a, st);
+                if (dt == 1) return launch_stream_inst<EPI, PRO_LN1S, 8, 4, 4, 1, 1>(a, st);
+            }
             if (a.K == 4096) return launch_stream_inst<EPI, PRO_LN1S, 8, 4, 4>(a, st);
             if (a.K == 5120) return launch_stream_inst<EPI, PRO_LN1S, 8, 5, 5>(a, st);
             if (a.K == 2048) return launch_stream_inst<EPI, PRO_LN1S, 4, 4, 2>(a, st);
@@ -1878,6 +2192,8 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
         return -1;
     }
     if (a.M <= 4 && ln_split()) {
+        if constexpr (EPI == SEPI_GATEUP || EPI == SEPI_QKV)
+            if (a.K == 4096 && sdma_on()) return launch_sdma_inst<EPI, PRO_LNS, 4, QS_SDMA_R>(a, st);
         if (a.K == 4096) return launch_stream_inst<EPI, PRO_LNS, 8, 4, 4>(a, st);
         if (a.K == 5120) return launch_stream_inst<EPI, PRO_LNS, 8, 5, 5>(a, st);
         if (a.K == 2048) return launch_stream_inst<EPI, PRO_LNS, 4, 4, 2>(a, st);

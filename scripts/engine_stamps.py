@@ -39,6 +39,11 @@ if lib_path:
         print("consumer wave 0 (us from start): start %.2f | rows requested %.2f | barrier passed %.2f | own row quantised %.2f | all rows %.2f | fragments %.2f"
               % tuple(us(c[i]) for i in range(6)))
         print("   fill in registers:", " ".join("%.2f" % us(c[6 + n]) for n in range(14)))
+        if c[20] > t0:
+            for n in range(10, 14):
+                b = 20 + 5 * (n - 10)
+                print("   fill %d: before confirm %.2f | in registers %.2f | next spec issued+waited %.2f | MFMAs issued %.2f | tile posted %s"
+                      % (n, us(c[b]), us(c[6 + n]), us(c[b + 1]), us(c[b + 2]), ("%.2f" % us(c[b + 3])) if c[b + 3] > t0 else "-"))
         print("epilogue wave, tile done:", " ".join("%.2f" % us(e[n]) for n in range(7)))
         for i, l in enumerate(ld):
             k = [v for v in l[3:8] if v > t0]

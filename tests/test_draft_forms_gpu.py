@@ -264,16 +264,20 @@ def test_batch32_draft_forms_vs_oracle(ops, oracle, M):
         assert np.array_equal(bits(host(out)), bits(oracle.gemm_w4a4(xq, xs, w, wsc)))
 
 
-def test_loader_consumer_engine_forms_are_bit_identical():
-    """The LDS-DMA loader / consumer forms of the draft GEMMs (gemm_stream.hip, `gemm_w4a4_engine_kernel`: gate_up + norm,
-    down_proj + residual at M <= 4; opt-in with QSPEC_ENGINE=1, see DESIGN.md "Stage A") against the same oracle
-    comparisons as the register forms: the launch-form tests of this file re-run in a child process with the switch on
-    (the library reads it once per process)."""
+@pytest.mark.parametrize("switch", ["QSPEC_ENGINE=1", "QSPEC_SDMA=1", "QSPEC_DMA_TILES=2"])
+def test_lds_dma_forms_are_bit_identical(switch):
+    """The three LDS-DMA forms of the draft GEMMs built in round 3 (gemm_stream.hip; all opt-in, see DESIGN.md "Stage A":
+    the loader / consumer engine `gemm_w4a4_engine_kernel`, the self-service form `gemm_w4a4_sdma_kernel`, and the loader
+    waves beside the register stream, `DMA` tiles) against the same oracle comparisons as the register forms: the
+    launch-form tests of this file re-run in a child process with the switch on (the library reads it once per process)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, QSPEC_ENGINE="1")
+    k, v = switch.split("=")
+    env = dict(os.environ)
+    env[k] = v
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
-                        "(gate_up or resid or draft) and not engine_forms"], env=env, capture_output=True, text=True, timeout=600)
+                        "(gate_up or qkv or resid or draft) and not lds_dma_forms"], env=env, capture_output=True, text=True,
+                       timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
