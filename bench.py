@@ -285,7 +285,7 @@ def measure_verify_plans(model, eng, world, reps=10):
     return res
 
 
-PMC_FILES = ("r03_pmc_fetch_size.json", "r03_pmc_fetch_size_bs32_k5.json", "r02_pmc_fetch_size.json")
+PMC_FILES = ("r03_pmc_fetch_size.json", "r03_pmc_fetch_size_llama-3-8b_bs32_k5.json", "r02_pmc_fetch_size.json")
 PMC_SOURCE = "profiles/r03_pmc_fetch_size*.json"
 
 

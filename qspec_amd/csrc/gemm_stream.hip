@@ -1647,13 +1647,14 @@ static int launch_sdma_inst(const StreamArgs& a, hipStream_t st) {
 // graph) gate_up does not gain (13.4-13.7 against 13.2-13.4) and the cycle LOSES 1.5 % (7.73-7.76 against 7.62 ms).
 // More run-ahead is worse, not better: what a CU draws is not raised by requesting more (rounds 1 and 2 found the same
 // for register loads), and the waves that issue the run-ahead loads sit in the issue while the queue is full.
-static int g_sdma = -1;
+static int g_sdma = -1;   // 0 off, 1 both shapes, 2 qkv only, 3 gate_up only
+template <int EPI>
 static bool sdma_on() {
     if (g_sdma < 0) {
         const char* e = getenv("QSPEC_SDMA");
-        g_sdma = (e && e[0] == '1') ? 1 : 0;
+        g_sdma = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0;
     }
-    return g_sdma != 0;
+    return g_sdma == 1 || (g_sdma == 2 && EPI == SEPI_QKV) || (g_sdma == 3 && EPI == SEPI_GATEUP);
 }
 
 // ------------------------------------------------------------------ W4A16 (verify pass), same streaming skeleton
@@ -2172,7 +2173,7 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
             if constexpr (EPI == SEPI_GATEUP)
                 if (a.K == 4096 && engine_on()) return launch_engine_inst<EPI, PRO_LN1S, 4, 2, 8>(a, st);
             if constexpr (EPI == SEPI_GATEUP || EPI == SEPI_QKV)
-                if (a.K == 4096 && sdma_on()) return launch_sdma_inst<EPI, PRO_LN1S, 4, QS_SDMA_R>(a, st);
+                if (a.K == 4096 && sdma_on<EPI>()) return launch_sdma_inst<EPI, PRO_LN1S, 4, QS_SDMA_R>(a, st);
             if (a.K == 4096 && a.ntiles > 256) {   // several tiles per workgroup: the next ones through LDS-DMA
                 const int dt = dma_tiles();
                 if (dt == 3) return launch_stream_inst<EPI, PRO_LN1S, 8, 4, 4, 1, 3>(a, st);
@@ -2193,7 +2194,7 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
     }
     if (a.M <= 4 && ln_split()) {
         if constexpr (EPI == SEPI_GATEUP || EPI == SEPI_QKV)
-            if (a.K == 4096 && sdma_on()) return launch_sdma_inst<EPI, PRO_LNS, 4, QS_SDMA_R>(a, st);
+            if (a.K == 4096 && sdma_on<EPI>()) return launch_sdma_inst<EPI, PRO_LNS, 4, QS_SDMA_R>(a, st);
         if (a.K == 4096) return launch_stream_inst<EPI, PRO_LNS, 8, 4, 4>(a, st);
         if (a.K == 5120) return launch_stream_inst<EPI, PRO_LNS, 8, 5, 5>(a, st);
         if (a.K == 2048) return launch_stream_inst<EPI, PRO_LNS, 4, 4, 2>(a, st);

@@ -830,6 +830,41 @@ def test_worker_variable_batch_on_the_gpu(tiny):
     assert w.execute_model(None) == []
 
 
+@pytest.mark.parametrize("k,batch_size", [(1, 1), (2, 2), (6, 4)])
+def test_correctly_calls_spec_decode_sampler(tiny, k, batch_size):
+    """tests/spec_decode/test_spec_decode_worker.py:148-233 (`test_correctly_calls_spec_decode_sampler`) on the real
+    engine: the rejection sampler must be called ONCE per cycle with target_with_bonus_probs = the scorer's [B, k+1, V]
+    distributions, bonus_token_ids = the scorer's token at the last position, draft_probs / draft_token_ids = the
+    proposer's k steps in [B, k, ...] order -- checked as the reference test does, by stopping the step inside the sampler."""
+    from qspec_amd.spec_decode import QSpecEngine
+    rng = np.random.default_rng(k * 10 + batch_size)
+    eng = QSpecEngine(tiny, k, batch_size, max_model_len=128, block_size=16, max_new_tokens=32, use_graph=False, seed=1)
+    eng.add_sequences([rng.integers(0, tiny.config.vocab_size, 9 + 3 * b).tolist() for b in range(batch_size)])
+    calls = []
+    secret = "artificial stop"
+
+    def spy(target_with_bonus_probs, bonus_token_ids, draft_probs, draft_token_ids, seeded_seqs=None, **kw):
+        calls.append(SimpleNamespace(target_with_bonus_probs=target_with_bonus_probs, bonus_token_ids=bonus_token_ids,
+                                     draft_probs=draft_probs, draft_token_ids=draft_token_ids, kw=kw))
+        raise ValueError(secret)
+    from types import SimpleNamespace
+    eng.sampler.forward = spy
+    with pytest.raises(ValueError, match=secret):
+        eng.step()
+    torch.cuda.synchronize()
+    assert len(calls) == 1
+    a = calls[0]
+    V = tiny.config.vocab_size
+    assert a.target_with_bonus_probs.shape == (batch_size, k + 1, V) and a.target_with_bonus_probs.data_ptr() == eng.target_probs.data_ptr()
+    assert torch.equal(a.bonus_token_ids.reshape(batch_size, 1), eng.target_tokens[:, -1:])
+    assert a.draft_probs.shape == (batch_size, k, V) and torch.equal(a.draft_probs, eng.draft_probs_kbv.transpose(0, 1))
+    assert a.draft_token_ids.shape == (batch_size, k) and torch.equal(a.draft_token_ids, eng.draft_ids_kb.t())
+    # and the distributions are distributions, the proposals their argmax (greedy draft, sampler.py:270-287)
+    assert torch.allclose(a.draft_probs.sum(-1), torch.ones(batch_size, k, device=DEV), atol=1e-4)
+    assert torch.equal(a.draft_probs.argmax(-1), a.draft_token_ids)
+    assert torch.equal(a.target_with_bonus_probs[:, -1].argmax(-1), a.bonus_token_ids.reshape(-1))
+
+
 def test_cycle_recovery_replay_is_bit_identical(tiny):
     """A cycle whose error word is non-zero (a device-side hand-off timed out) is re-run from the state snapshot taken at
     its start, without hand-offs (engine.recover): the replay must emit exactly what an undisturbed engine emits --

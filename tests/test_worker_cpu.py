@@ -492,3 +492,29 @@ def test_failed_admission_gives_the_slots_back():
     w.engine.add_sequences_to = orig
     out = w.execute_model(ExecuteModelRequest([prompt("a", 1, 4)], num_lookahead_slots=0))
     assert out[0].token_ids() == [1000]
+
+
+@pytest.mark.parametrize("k", [1, 2, 6])
+@pytest.mark.parametrize("batch_size", [1, 2, 32])
+def test_correctly_formats_output(k, batch_size):
+    """tests/spec_decode/test_spec_decode_worker.py:236-370 (`test_correctly_formats_output`): a rejection-sampler output
+    [batch, k + 1] with every row's tokens followed by -1 padding comes back as one SamplerOutput per step holding, per
+    sequence, that step's token under the sequence's own id -- transposed, complete up to the last step in which any
+    sequence emitted a token."""
+    gen = torch.Generator().manual_seed(k * 100 + batch_size)
+    w = make_worker(k=k, B=batch_size)
+    sgs = [prompt(f"r{i}", 1000 + i, 3 + i % 5) for i in range(batch_size)]
+    w.execute_model(ExecuteModelRequest(sgs, num_lookahead_slots=0))
+    toks = torch.randint(0, 32000, (batch_size, k + 1), generator=gen)
+    n_emit = torch.randint(1, k + 2, (batch_size,), generator=gen)      # every sequence emits 1 .. k+1 tokens
+    toks[torch.arange(k + 1)[None, :] >= n_emit[:, None]] = -1
+    rows = {b: toks[b].tolist() for b in range(batch_size)}
+    w.engine.out_script = lambda step, slots: rows
+    outs = w.execute_model(ExecuteModelRequest([decode(s) for s in sgs], num_lookahead_slots=k))
+    steps = int(n_emit.max())
+    assert len(outs) == steps
+    for j, o in enumerate(outs):
+        assert [g.samples[0].parent_seq_id for g in o.outputs] == [1000 + i for i in range(batch_size)]
+        assert o.token_ids() == toks[:, j].tolist()
+    # the bonus-token set (:1190-1210): exactly the sequences whose last position holds a token
+    assert w._seq_with_bonus_token_in_last_step == {1000 + i for i in range(batch_size) if int(toks[i, k]) != -1}
