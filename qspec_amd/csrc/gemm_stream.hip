@@ -2019,6 +2019,145 @@ __global__ __launch_bounds__(NW * 64) void gemm_f16_stream_kernel(const f16* __r
     }
 }
 
+// ---- the same lm_head with its 1 GB weight stream through self-service LDS-DMA (K = 4096, M <= 16).
+// The draft GEMMs did not gain from LDS-DMA (what is above their floor is the launch's fixed
+// sequence, not stream time); THIS launch is 99 % stream: 31 tiles of 128 KB per workgroup, where the register path's
+// pure read reaches 6.2 TB/s and four or more issuing waves per CU with `global_load_lds_dwordx4 ... nt` 6.9 TB/s
+// (scripts/micro/ldsdma.hip: 168 -> 151 us for these bytes).  Stream wave w owns the k range [512 w, 512 w + 512) of
+// every weight row (1 KiB per row) and walks it in GROUPS of four 64-byte steps: one group = 16 rows x 256 B = four loads
+// (4 rows x 256 B each, lane l -> row 4 q + l / 16, 16-byte piece (l % 16) ^ row: the LDS image stays lane-linear, the
+// fragment reads are conflict-free).  A wave keeps a rolling window of four groups (16 KiB of its own LDS, 16 loads) in
+// flight -- 128 KB per CU -- and learns that a group has landed from its own `s_waitcnt vmcnt(12)`: no loader waves, no
+// flags.  The epilogue (sum of the eight waves' fp32 partials in wave order, one rounding, store, running row maximum)
+// belongs to four waves that stream nothing; they meet the stream waves at one barrier per tile.
+__global__ __launch_bounds__(12 * 64) void gemm_f16_sdma_kernel(const f16* __restrict__ x, const f16* __restrict__ wt,
+                                                                f16* __restrict__ out, int M, int N, int ntiles,
+                                                                HeadMax* __restrict__ part_max) {
+    constexpr int NW = 8, K = 4096, WIN = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = reinterpret_cast<float*>(smem);                 // [2][NW][256]
+    unsigned char* ring = smem + (size_t)2 * NW * 1024;          // [NW][WIN][4 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+
+    if (wave >= NW) {   // ---------------------------------------------------------------- epilogue waves
+        const int et = tid - NW * 64;                            // 0..255 -> (token m, tile column c)
+        const int c = et & 15, m = et >> 4;
+        const bool ethread = m < M;
+        const int ridx = (m & 3) * 64 + ((m >> 2) & 3) * 16 + c;
+        float best_v = -__builtin_inff();
+        int best_i = 0x7fffffff;
+        int tile = blockIdx.x, par = 0;
+        for (int ti = 0; ti < my_tiles; ti++) {
+            __syncthreads();                                     // A(ti): the stream waves have posted the tile's partials
+            const float* rb = red + par * NW * 256;
+            if (ethread) {
+                float sum = rb[ridx];
+#pragma unroll
+                for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[w2 * 256 + ridx];
+                const f16 hv = f2h(sum);
+                out[(size_t)m * N + tile * 16 + c] = hv;
+                const float fv = h2f(hv);
+                if (fv > best_v) {          // tiles come in increasing column order: a tie keeps the first column
+                    best_v = fv;
+                    best_i = tile * 16 + c;
+                }
+            }
+            par ^= 1;
+            tile += gridDim.x;
+        }
+        if (part_max) {   // the 16 columns of a row sit in 16 consecutive lanes: larger value, then smaller column, wins
+#pragma unroll
+            for (int mk = 1; mk < 16; mk <<= 1) {
+                const float ov = __shfl_xor(best_v, mk, 64);
+                const int oi = __shfl_xor(best_i, mk, 64);
+                if (ov > best_v || (ov == best_v && oi < best_i)) {
+                    best_v = ov;
+                    best_i = oi;
+                }
+            }
+            if (ethread && c == 0) part_max[(size_t)m * gridDim.x + blockIdx.x] = HeadMax{best_v, best_i};
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- stream waves
+    const int r = lane & 15, g = lane >> 4;
+    // activation fragments of this wave's k range: step s = halves [512 w + 32 s + 8 g, + 8) of row r (rows >= M: row 0)
+    f16x8 af[16];
+    {
+        const f16* xrow = x + (size_t)(r < M ? r : 0) * K + wave * 512 + g * 8;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; s2++) af[s2] = *reinterpret_cast<const f16x8*>(xrow + s2 * 32);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // before the first LDS-DMA load: hipcc's own waits do not know them
+    const u32 my0 = (u32)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)ring + (u32)wave * (WIN * 4096);
+    // source of this lane inside a group: row 4 q + (lane >> 4) of the tile, 16-byte piece ((lane & 15) ^ row) of the group's
+    // 256-byte segment of the wave's KiB
+    const int lrow = lane >> 4;
+    auto issue_group = [&](int gi) {   // group gi = (tile gi / 4, segment gi % 4) of this workgroup's sequence
+        const int t = blockIdx.x + (gi >> 2) * (int)gridDim.x;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(wt + (size_t)t * 16 * K) + wave * 1024 + (gi & 3) * 256;
+        const u32 dst = my0 + (u32)(gi & (WIN - 1)) * 4096u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int row = 4 * q + lrow;
+            glds16<1>(base + (size_t)row * (K * 2) + (((lane & 15) ^ row) << 4), dst + (u32)q * 1024u);
+        }
+    };
+    const int n_groups = my_tiles * 4;
+#pragma unroll
+    for (int gi = 0; gi < WIN; gi++)
+        if (gi < n_groups) issue_group(gi);
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
+    const __attribute__((address_space(3))) unsigned char* my3 =
+        (const __attribute__((address_space(3))) unsigned char*)ring + (size_t)wave * (WIN * 4096);
+    // fragment of step q2 (0..3) of a group, lane (r, g): load r / 4, lane (r % 4) * 16 + ((4 q2 + g) ^ r)
+    u32 foff[4];
+#pragma unroll
+    for (int q2 = 0; q2 < 4; q2++) foff[q2] = (u32)(r >> 2) * 1024u + (u32)((((r & 3) << 4) | ((q2 * 4 + g) ^ r)) << 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int par = 0;
+    for (int gi = 0; gi < n_groups; gi++) {
+        const int left = min(WIN - 1, n_groups - 1 - gi);   // groups issued behind group gi
+        if (left >= 3) vmcnt_le<12>();
+        else if (left == 2) vmcnt_le<8>();
+        else if (left == 1) vmcnt_le<4>();
+        else vmcnt_le<0>();
+        u32x4 wv[4];
+#pragma unroll
+        for (int q2 = 0; q2 < 4; q2++)
+            wv[q2] = *reinterpret_cast<const volatile lds_u32x4_t*>(my3 + (size_t)(gi & (WIN - 1)) * 4096 + foff[q2]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (gi + WIN < n_groups) issue_group(gi + WIN);   // into the slot just read
+        const int seg = gi & 3;
+#pragma unroll
+        for (int q2 = 0; q2 < 4; q2++) {
+            // (seg is a loop-carried value 0..3: select the fragment without dynamic register indexing)
+            const f16x8 a0 = seg == 0 ? af[q2] : (seg == 1 ? af[4 + q2] : (seg == 2 ? af[8 + q2] : af[12 + q2]));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, __builtin_bit_cast(f16x8, wv[q2]), acc, 0, 0, 0);
+        }
+        if (seg == 3) {   // tile complete: post the partial sums, meet the epilogue waves
+            float* rb = red + par * NW * 256;
+#pragma unroll
+            for (int i = 0; i < 4; i++) rb[wave * 256 + i * 64 + lane] = acc[i];
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // A (raw: no vmcnt drain)
+            par ^= 1;
+        }
+    }
+}
+static int g_head_sdma = -1;   // QSPEC_HEAD_SDMA=0: the register-streaming lm_head
+static bool head_sdma_on() {
+    if (g_head_sdma < 0) {
+        const char* e = getenv("QSPEC_HEAD_SDMA");
+        g_head_sdma = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_head_sdma != 0;
+}
+
 bool gemm_f16_stream_supported(int M, int N, int K) {
     return M >= 1 && M <= 16 && N % 16 == 0 && (K == 1024 || K == 2048 || K == 4096 || K == 5120);
 }
@@ -2049,6 +2188,17 @@ int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, v
         grid = (ntiles + per - 1) / per;
     }
     HeadMax* pm = reinterpret_cast<HeadMax*>(part_max);
+    if (K == 4096 && ntiles >= 4 * grid && head_sdma_on()) {   // a long stream: LDS-DMA (see gemm_f16_sdma_kernel)
+        const size_t lds = (size_t)2 * 8 * 1024 + (size_t)8 * 4 * 4096;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_sdma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return -8;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_f16_sdma_kernel, dim3(grid), dim3(12 * 64), lds, st, x, w, out, M, N, ntiles, pm);
+        return 0;
+    }
 #define QS_F16S(NWV, UBV) hipLaunchKernelGGL((gemm_f16_stream_kernel<NWV, UBV>), dim3(grid), dim3(NWV * 64), (size_t)2 * NWV * 1024, st, x, w, out, M, N, K, ntiles, pm)
     if (K == 4096) QS_F16S(8, 16);
     else if (K == 2048) QS_F16S(8, 8);

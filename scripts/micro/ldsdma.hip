@@ -91,15 +91,15 @@ float run_dma(const unsigned char* pool, size_t bytes, int L, int Kb, int ntiles
 
 int main() {
     hipStream_t st; CK(hipStreamCreate(&st));
-    const size_t POOL = 640ull << 20;
+    const size_t POOL = 1100ull << 20;
     unsigned char* pool; unsigned* out;
     CK(hipMalloc(&pool, POOL)); CK(hipMalloc(&out, 1 << 20));
     CK(hipMemset(pool, 1, POOL));
-    struct Shape { const char* name; int N, K; } shapes[] = {{"o", 4096, 4096}, {"qkv", 6144, 4096}, {"down", 4096, 14336}, {"gate_up", 28672, 4096}};
+    struct Shape { const char* name; int N, K; } shapes[] = {{"o", 4096, 4096}, {"qkv", 6144, 4096}, {"down", 4096, 14336}, {"gate_up", 28672, 4096}, {"lm_head(fp16 [128256, 4096] as bytes)", 128256, 16384}};
     for (auto& sh : shapes) {
         const int Kb = sh.K / 2, ntiles = sh.N / 16;
         const size_t bytes = (size_t)sh.N * Kb;
-        const int L = (int)(POOL / bytes);
+        const int L = (int)(POOL / bytes) > 0 ? (int)(POOL / bytes) : 1;
         const int grid = ntiles < 256 ? ntiles : 256;
         const int nsteps = 16 * Kb / 1024;   // 1 KiB wave-loads per tile
         float tr = time_graph([&](int i) { hipLaunchKernelGGL(rd<4>, dim3(grid), dim3(512), 0, st, pool + (size_t)(i % L) * bytes, Kb, nsteps / 8, ntiles, out); }, L * 2, st);
@@ -110,8 +110,10 @@ int main() {
             float c = run_dma<0, 2>(pool, bytes, L, Kb, ntiles, grid, ring, out, st);
             float d = run_dma<1, 2>(pool, bytes, L, Kb, ntiles, grid, ring, out, st);
             float e = run_dma<1, 4>(pool, bytes, L, Kb, ntiles, grid, ring, out, st);
-            printf("         LDS-DMA ring %3d KiB: 1 loader %6.2f us (%5.0f GB/s) nt %6.2f (%5.0f) | 2 loaders %6.2f nt %6.2f | 4 loaders nt %6.2f\n",
-                   ring, a, bytes / a / 1e3, b, bytes / b / 1e3, c, d, e);
+            float f8 = run_dma<1, 8>(pool, bytes, L, Kb, ntiles, grid, ring, out, st);
+            float f12 = run_dma<1, 12>(pool, bytes, L, Kb, ntiles, grid, ring, out, st);
+            printf("         LDS-DMA ring %3d KiB: 1 loader %6.2f us (%5.0f GB/s) nt %6.2f (%5.0f) | 2 loaders %6.2f nt %6.2f | 4 loaders nt %6.2f | 8 nt %6.2f | 12 nt %6.2f (%5.0f GB/s)\n",
+                   ring, a, bytes / a / 1e3, b, bytes / b / 1e3, c, d, e, f8, f12, bytes / f12 / 1e3);
         }
     }
     return 0;
