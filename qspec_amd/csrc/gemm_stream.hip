@@ -2030,38 +2030,47 @@ __global__ __launch_bounds__(NW * 64) void gemm_f16_stream_kernel(const f16* __r
 // flight -- 128 KB per CU -- and learns that a group has landed from its own `s_waitcnt vmcnt(12)`: no loader waves, no
 // flags.  The epilogue (sum of the eight waves' fp32 partials in wave order, one rounding, store, running row maximum)
 // belongs to four waves that stream nothing; they meet the stream waves at one barrier per tile.
+template <int MT /* 16-token tiles: M <= 16 MT */>
 __global__ __launch_bounds__(12 * 64) void gemm_f16_sdma_kernel(const f16* __restrict__ x, const f16* __restrict__ wt,
                                                                 f16* __restrict__ out, int M, int N, int ntiles,
                                                                 HeadMax* __restrict__ part_max) {
     constexpr int NW = 8, K = 4096, WIN = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* red = reinterpret_cast<float*>(smem);                 // [2][NW][256]
-    unsigned char* ring = smem + (size_t)2 * NW * 1024;          // [NW][WIN][4 KiB]
+    float* red = reinterpret_cast<float*>(smem);                 // [2][NW][MT][256]
+    unsigned char* ring = smem + (size_t)2 * NW * MT * 1024;     // [NW][WIN][4 KiB]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
     if (wave >= NW) {   // ---------------------------------------------------------------- epilogue waves
-        const int et = tid - NW * 64;                            // 0..255 -> (token m, tile column c)
-        const int c = et & 15, m = et >> 4;
-        const bool ethread = m < M;
-        const int ridx = (m & 3) * 64 + ((m >> 2) & 3) * 16 + c;
-        float best_v = -__builtin_inff();
-        int best_i = 0x7fffffff;
+        const int et = tid - NW * 64;                            // 0..255 -> (token m (+ 16 mt), tile column c)
+        const int c = et & 15, m0 = et >> 4;
+        const int ridx = (m0 & 3) * 64 + ((m0 >> 2) & 3) * 16 + c;
+        float best_v[MT];
+        int best_i[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            best_v[mt] = -__builtin_inff();
+            best_i[mt] = 0x7fffffff;
+        }
         int tile = blockIdx.x, par = 0;
         for (int ti = 0; ti < my_tiles; ti++) {
             __syncthreads();                                     // A(ti): the stream waves have posted the tile's partials
-            const float* rb = red + par * NW * 256;
-            if (ethread) {
-                float sum = rb[ridx];
+            const float* rb = red + par * NW * MT * 256;
 #pragma unroll
-                for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[w2 * 256 + ridx];
-                const f16 hv = f2h(sum);
-                out[(size_t)m * N + tile * 16 + c] = hv;
-                const float fv = h2f(hv);
-                if (fv > best_v) {          // tiles come in increasing column order: a tie keeps the first column
-                    best_v = fv;
-                    best_i = tile * 16 + c;
+            for (int mt = 0; mt < MT; mt++) {
+                const int m = m0 + 16 * mt;
+                if (m < M) {
+                    float sum = rb[mt * 256 + ridx];
+#pragma unroll
+                    for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[(w2 * MT + mt) * 256 + ridx];
+                    const f16 hv = f2h(sum);
+                    out[(size_t)m * N + tile * 16 + c] = hv;
+                    const float fv = h2f(hv);
+                    if (fv > best_v[mt]) {          // tiles come in increasing column order: a tie keeps the first column
+                        best_v[mt] = fv;
+                        best_i[mt] = tile * 16 + c;
+                    }
                 }
             }
             par ^= 1;
@@ -2069,27 +2078,35 @@ __global__ __launch_bounds__(12 * 64) void gemm_f16_sdma_kernel(const f16* __res
         }
         if (part_max) {   // the 16 columns of a row sit in 16 consecutive lanes: larger value, then smaller column, wins
 #pragma unroll
-            for (int mk = 1; mk < 16; mk <<= 1) {
-                const float ov = __shfl_xor(best_v, mk, 64);
-                const int oi = __shfl_xor(best_i, mk, 64);
-                if (ov > best_v || (ov == best_v && oi < best_i)) {
-                    best_v = ov;
-                    best_i = oi;
+            for (int mt = 0; mt < MT; mt++) {
+                float bv = best_v[mt];
+                int bi = best_i[mt];
+#pragma unroll
+                for (int mk = 1; mk < 16; mk <<= 1) {
+                    const float ov = __shfl_xor(bv, mk, 64);
+                    const int oi = __shfl_xor(bi, mk, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) {
+                        bv = ov;
+                        bi = oi;
+                    }
                 }
+                const int m = m0 + 16 * mt;
+                if (m < M && c == 0) part_max[(size_t)m * gridDim.x + blockIdx.x] = HeadMax{bv, bi};
             }
-            if (ethread && c == 0) part_max[(size_t)m * gridDim.x + blockIdx.x] = HeadMax{best_v, best_i};
         }
         return;
     }
 
     // ---------------------------------------------------------------- stream waves
     const int r = lane & 15, g = lane >> 4;
-    // activation fragments of this wave's k range: step s = halves [512 w + 32 s + 8 g, + 8) of row r (rows >= M: row 0)
-    f16x8 af[16];
-    {
-        const f16* xrow = x + (size_t)(r < M ? r : 0) * K + wave * 512 + g * 8;
+    // activation fragments of this wave's k range: step s = halves [512 w + 32 s + 8 g, + 8) of row r + 16 mt (rows >= M: row 0)
+    f16x8 af[MT][16];
 #pragma unroll
-        for (int s2 = 0; s2 < 16; s2++) af[s2] = *reinterpret_cast<const f16x8*>(xrow + s2 * 32);
+    for (int mt = 0; mt < MT; mt++) {
+        const int row = r + 16 * mt;
+        const f16* xrow = x + (size_t)(row < M ? row : 0) * K + wave * 512 + g * 8;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; s2++) af[mt][s2] = *reinterpret_cast<const f16x8*>(xrow + s2 * 32);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // before the first LDS-DMA load: hipcc's own waits do not know them
     const u32 my0 = (u32)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)ring + (u32)wave * (WIN * 4096);
@@ -2117,36 +2134,42 @@ __global__ __launch_bounds__(12 * 64) void gemm_f16_sdma_kernel(const f16* __res
     u32 foff[4];
 #pragma unroll
     for (int q2 = 0; q2 < 4; q2++) foff[q2] = (u32)(r >> 2) * 1024u + (u32)((((r & 3) << 4) | ((q2 * 4 + g) ^ r)) << 4);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int par = 0;
-    for (int gi = 0; gi < n_groups; gi++) {
-        const int left = min(WIN - 1, n_groups - 1 - gi);   // groups issued behind group gi
-        if (left >= 3) vmcnt_le<12>();
-        else if (left == 2) vmcnt_le<8>();
-        else if (left == 1) vmcnt_le<4>();
-        else vmcnt_le<0>();
-        u32x4 wv[4];
+    f32x4 acc[MT];
 #pragma unroll
-        for (int q2 = 0; q2 < 4; q2++)
-            wv[q2] = *reinterpret_cast<const volatile lds_u32x4_t*>(my3 + (size_t)(gi & (WIN - 1)) * 4096 + foff[q2]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (gi + WIN < n_groups) issue_group(gi + WIN);   // into the slot just read
-        const int seg = gi & 3;
+    for (int mt = 0; mt < MT; mt++) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int par = 0, gi = 0;
+    for (int ti = 0; ti < my_tiles; ti++) {
+        const bool last = ti == my_tiles - 1;   // (wave-uniform) the window runs empty behind the last tile
 #pragma unroll
-        for (int q2 = 0; q2 < 4; q2++) {
-            // (seg is a loop-carried value 0..3: select the fragment without dynamic register indexing)
-            const f16x8 a0 = seg == 0 ? af[q2] : (seg == 1 ? af[4 + q2] : (seg == 2 ? af[8 + q2] : af[12 + q2]));
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, __builtin_bit_cast(f16x8, wv[q2]), acc, 0, 0, 0);
-        }
-        if (seg == 3) {   // tile complete: post the partial sums, meet the epilogue waves
-            float* rb = red + par * NW * 256;
+        for (int seg = 0; seg < 4; seg++, gi++) {   // unrolled: the fragment registers are indexed statically
+            if (!last) vmcnt_le<12>();              // three groups issued behind this one
+            else if (seg == 0) vmcnt_le<12>();
+            else if (seg == 1) vmcnt_le<8>();
+            else if (seg == 2) vmcnt_le<4>();
+            else vmcnt_le<0>();
+            u32x4 wv[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) rb[wave * 256 + i * 64 + lane] = acc[i];
-            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q2 = 0; q2 < 4; q2++)
+                wv[q2] = *reinterpret_cast<const volatile lds_u32x4_t*>(my3 + (size_t)seg * 4096 + foff[q2]);   // slot = gi % WIN = seg
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();   // A (raw: no vmcnt drain)
-            par ^= 1;
+            if (gi + WIN < n_groups) issue_group(gi + WIN);   // into the slot just read
+#pragma unroll
+            for (int q2 = 0; q2 < 4; q2++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][seg * 4 + q2], __builtin_bit_cast(f16x8, wv[q2]), acc[mt], 0, 0, 0);
         }
+        // tile complete: post the partial sums, meet the epilogue waves
+        float* rb = red + par * NW * MT * 256;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) rb[(wave * MT + mt) * 256 + i * 64 + lane] = acc[mt][i];
+            acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // A (raw: no vmcnt drain)
+        par ^= 1;
     }
 }
 static int g_head_sdma = -1;   // QSPEC_HEAD_SDMA=0: the register-streaming lm_head
@@ -2158,6 +2181,27 @@ static bool head_sdma_on() {
     return g_head_sdma != 0;
 }
 
+template <int MT>
+static int gemm_f16_sdma_launch_inst(const f16* x, const f16* w, f16* out, int M, int N, int ntiles, int grid, HeadMax* pm,
+                                     hipStream_t st) {
+    const size_t lds = (size_t)2 * 8 * MT * 1024 + (size_t)8 * 4 * 4096;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_sdma_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return -8;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_f16_sdma_kernel<MT>, dim3(grid), dim3(12 * 64), lds, st, x, w, out, M, N, ntiles, pm);
+    return 0;
+}
+// (MT = 2 -- 17..32 tokens as two token tiles over one weight pass -- was built and measured: 240 us against 245 for the M-tiled
+// kernel at M = 32: the second tile's 64 fragment registers push the kernel to 168 VGPRs + scratch at 12 waves, and scratch
+// traffic shares the vmcnt queue with the LDS-DMA window.  Only MT = 1 is launched.)
+static int gemm_f16_sdma_launch(const f16* x, const f16* w, f16* out, int M, int N, int ntiles, int grid, HeadMax* pm,
+                                hipStream_t st) {
+    return gemm_f16_sdma_launch_inst<1>(x, w, out, M, N, ntiles, grid, pm, st);
+}
 bool gemm_f16_stream_supported(int M, int N, int K) {
     return M >= 1 && M <= 16 && N % 16 == 0 && (K == 1024 || K == 2048 || K == 4096 || K == 5120);
 }
@@ -2189,15 +2233,7 @@ int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, v
     }
     HeadMax* pm = reinterpret_cast<HeadMax*>(part_max);
     if (K == 4096 && ntiles >= 4 * grid && head_sdma_on()) {   // a long stream: LDS-DMA (see gemm_f16_sdma_kernel)
-        const size_t lds = (size_t)2 * 8 * 1024 + (size_t)8 * 4 * 4096;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_sdma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return -8;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(gemm_f16_sdma_kernel, dim3(grid), dim3(12 * 64), lds, st, x, w, out, M, N, ntiles, pm);
-        return 0;
+        return gemm_f16_sdma_launch(x, w, out, M, N, ntiles, grid, pm, st);
     }
 #define QS_F16S(NWV, UBV) hipLaunchKernelGGL((gemm_f16_stream_kernel<NWV, UBV>), dim3(grid), dim3(NWV * 64), (size_t)2 * NWV * 1024, st, x, w, out, M, N, K, ntiles, pm)
     if (K == 4096) QS_F16S(8, 16);

@@ -6,7 +6,7 @@ from qspec_amd import ops
 dev = "cuda:0"
 V, H = 128256, 4096
 w = (torch.randn(V, H, device=dev) * 0.02).half()
-for M in (4, 16):
+for M in (4, 16, 32):
     x = torch.randn(M, H, device=dev).half(); out = torch.empty(M, V, dtype=torch.float16, device=dev)
     ops.linear_f16(x, w, out); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()

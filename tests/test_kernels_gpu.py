@@ -1090,6 +1090,24 @@ def test_linear_f16_tiled_within_1e3(ops, oracle, M, N, K):
     assert torch.all(out[M] == 7.0)
 
 
+@pytest.mark.parametrize("M,N", [(4, 16400), (16, 32768), (17, 16384), (32, 32768), (24, 20000)])
+def test_linear_f16_lds_dma_stream_within_1e3(ops, oracle, M, N):
+    """The long-stream lm_head (K = 4096, >= 4 tiles per workgroup) through self-service LDS-DMA (`gemm_f16_sdma_kernel`):
+    one and two 16-token tiles, a vocabulary whose tile count is not a multiple of the grid, rows beyond M untouched.
+    (N = 20000: 1250 tiles on 250 workgroups x 5.)"""
+    K = 4096
+    rng = np.random.default_rng(M + N)
+    x = rand_hidden(rng, M, K)
+    w = (rng.standard_normal((N, K)) * 0.02).astype(np.float16)
+    out = torch.full((M + 1, N), 7.0, dtype=torch.float16, device=DEV)
+    ops.linear_f16(dev(x), dev(w), out[:M])
+    assert_close_1e3(host(out[:M]), oracle.gemm_f16(x, w))
+    assert torch.all(out[M] == 7.0)
+    again = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.linear_f16(dev(x), dev(w), again)
+    assert torch.equal(again.view(torch.int16), out[:M].view(torch.int16))      # deterministic
+
+
 # ------------------------------------------------------------------ W4A4 streaming kernels with two token tiles (M 17..32)
 
 @pytest.mark.parametrize("M", [17, 24, 32])
