@@ -1036,6 +1036,99 @@ __global__ __launch_bounds__(128) void paged_attention_generic_kernel(
     }
 }
 
+// The same arithmetic with vector loads (head_size a multiple of 8; round 3: TinyLlama's bs = 1 cycle spent 47 % of its time
+// in the kernel above, 51 us per launch: its P.V phase ran head_size threads through one DEPENDENT 2-byte load per key).
+// 256 threads: a thread's score is the same e-ascending fma chain over 16-byte pieces of the key row (all pieces of a row
+// in flight together); P.V stages chunks of 256 / (head_size / 8) V rows through LDS with one 16-byte piece per thread
+// (next chunk in flight in registers while the current one is accumulated) and thread e then adds the chunk's keys in
+// ascending order: the output sums are those of the kernel above bit for bit; the softmax denominator is summed in a
+// different (fixed) grouping.
+__global__ __launch_bounds__(256) void paged_attention_generic_vec_kernel(
+    const f16* __restrict__ q, int64_t q_stride, const f16* __restrict__ key_cache, const f16* __restrict__ value_cache,
+    const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
+    const int32_t* __restrict__ q_start, int n_seqs, int nq, int nkv, int d, int block_size, float sm_scale,
+    f16* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) f16 qrow[256];
+    const int t = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    int seq = 0;
+    while (seq + 1 < n_seqs && q_start[seq + 1] <= t) seq++;
+    const int qs = q_start[seq], qlen = q_start[seq + 1] - qs, ctx = ctx_lens[seq];
+    if (t - qs >= qlen) return;   // (uniform)
+    const int pos = ctx - qlen + (t - qs);            // absolute position of this query token
+    const int nvis = pos + 1;                          // causal: keys 0..pos
+    const int kvh = h / (nq / nkv);
+    const int32_t* bt = block_tables + (size_t)seq * max_blocks;
+    const int pieces = d >> 3;                         // 16-byte pieces per row
+    const int KC = 256 / pieces;                       // V rows per chunk
+    float* sc = reinterpret_cast<float*>(smem_raw);   // [nvis rounded up to 4]
+    f16* vt = reinterpret_cast<f16*>(smem_raw + (((size_t)nvis * 4 + 15) & ~(size_t)15));   // [KC][d]
+    if (tid < pieces)
+        *reinterpret_cast<u32x4*>(qrow + tid * 8) = *reinterpret_cast<const u32x4*>(q + (size_t)t * q_stride + (size_t)h * d + tid * 8);
+    __syncthreads();
+    float mx = -__builtin_inff();
+    for (int k = tid; k < nvis; k += 256) {
+        const int64_t slot = (int64_t)bt[k / block_size] * block_size + k % block_size;
+        const f16* kp = key_cache + (slot * nkv + kvh) * d;
+        float acc = 0.0f;
+        for (int p0 = 0; p0 < pieces; p0 += 8) {      // up to 8 pieces of the row in flight
+            u32x4 kr[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) kr[j] = *reinterpret_cast<const u32x4*>(kp + min(p0 + j, pieces - 1) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (p0 + j < pieces) {
+                    const f16x8 k8 = __builtin_bit_cast(f16x8, kr[j]);
+                    const f16x8 q8 = *reinterpret_cast<const f16x8*>(qrow + (p0 + j) * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) acc = __builtin_fmaf(h2f(q8[e]), h2f(k8[e]), acc);
+                }
+            }
+        }
+        acc *= sm_scale;
+        sc[k] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max_f(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.0f;
+    for (int k = tid; k < nvis; k += 256) {
+        const float pv = qexpf(sc[k] - mx);
+        sc[k] = pv;
+        sum += pv;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) sum += shfl_xor_f(sum, m);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+    __syncthreads();
+    const float den = (red[4] + red[5]) + (red[6] + red[7]);
+    // ---- P.V
+    const int vrow = tid / pieces, vpiece = tid - vrow * pieces;   // this thread's (row of the chunk, piece)
+    const bool loader = vrow < KC;
+    auto load_piece = [&](int k0) -> u32x4 {
+        const int k = min(k0 + vrow, nvis - 1);        // clamped: no branch around a load (rows past the end are not used)
+        const int64_t slot = (int64_t)bt[k / block_size] * block_size + k % block_size;
+        return *reinterpret_cast<const u32x4*>(value_cache + (slot * nkv + kvh) * d + vpiece * 8);
+    };
+    u32x4 nxt = u32x4{0, 0, 0, 0};
+    if (loader) nxt = load_piece(0);
+    float acc = 0.0f;
+    for (int k0 = 0; k0 < nvis; k0 += KC) {
+        __syncthreads();                               // the previous chunk has been consumed
+        if (loader) *reinterpret_cast<u32x4*>(vt + (size_t)vrow * d + vpiece * 8) = nxt;
+        __syncthreads();
+        if (loader && k0 + KC < nvis) nxt = load_piece(k0 + KC);
+        if (tid < d) {
+            const int kn = min(KC, nvis - k0);
+            for (int kk = 0; kk < kn; kk++) acc = __builtin_fmaf(sc[k0 + kk], h2f(vt[(size_t)kk * d + tid]), acc);
+        }
+    }
+    if (tid < d) out[((size_t)t * nq + h) * d + tid] = f2h(acc / den);
+}
+
 // float offsets of the partials inside the workspace (shared with hadamard.hip:heads_hadamard_merge)
 size_t paged_attention_ws_o_offset() { return QS_ATT_CNT_SLOTS; }
 size_t paged_attention_ws_ml_offset(int Tmax, int nq, int d, int n_splits) {
@@ -1062,6 +1155,19 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
     if (d != 128) {   // plumbing path (e.g. TinyLlama's 64): no split, no partials -> needs `out`
         if (!out || d > 256 || d % 2) return -1;
         int max_ctx_bytes = 64 * 1024;   // scores of one row in LDS: contexts up to 16 K keys
+        if (d % 8 == 0 && d >= 8) {       // vector loads; + one chunk of V rows (<= 256 x 16 B)
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_generic_vec_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, max_ctx_bytes + 4096 + 16) != hipSuccess)
+                    return -8;
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(paged_attention_generic_vec_kernel, dim3(n_seqs * max_q_len, nq), dim3(256), max_ctx_bytes + 4096 + 16,
+                               st, q, q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, n_seqs, nq,
+                               nkv, d, block_size, sm_scale, out);
+            return 0;
+        }
         hipLaunchKernelGGL(paged_attention_generic_kernel, dim3(n_seqs * max_q_len, nq), dim3(128), max_ctx_bytes, st, q,
                            q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, n_seqs, nq, nkv,
                            d, block_size, sm_scale, out);
