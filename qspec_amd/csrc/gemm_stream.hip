@@ -26,6 +26,12 @@
 //   * Epilogues as in gemm.hip (plain / RoPE + KV-cache write / silu(gate)*up), with their operands (channel
 //     scale, cos/sin, position, slot) prefetched together with the tile's weights.
 //   * Cross-wave K reduction through LDS in wave order: int32, exact, deterministic.
+//
+// Also in this file (round 3), all bit-identical to the register forms:
+//   * gemm_f16_sdma_kernel: the lm_head's 1 GB stream through self-service LDS-DMA -- what the cycle launches;
+//   * three LDS-DMA forms of the draft GEMMs, measured and left OFF ("Stage A"): the loader / consumer
+//     engine (gemm_w4a4_engine_kernel, QSPEC_ENGINE=1), the self-service form (gemm_w4a4_sdma_kernel, QSPEC_SDMA=1..3) and
+//     loader waves beside the register stream (template parameter DMA of the kernel below, QSPEC_DMA_TILES=1..3).
 #include <stdlib.h>
 
 #include "common.cuh"

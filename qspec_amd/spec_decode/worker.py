@@ -325,7 +325,6 @@ class SpecDecodeWorker:
         object (`proposer_worker.load_model(self.scorer_worker.model_runner.model)`, :342)."""
         if self._device.type == "cuda":
             torch.cuda.set_device(self._device)
-            self._free_before_load = torch.cuda.mem_get_info(self._device)[0]
         if self._tp_size > 1 and self._model is None:
             import torch.distributed as dist
             if not dist.is_initialized():     # vllm/worker/worker.py:init_worker_distributed_environment
