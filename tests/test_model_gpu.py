@@ -85,7 +85,12 @@ def test_forward_matches_oracle_model(tiny, oracle, w4a4, ctx_lens, q_len):
         # chaotic by nature: one different int4 (e.g. the abs-max element of a row) re-scales a whole row downstream
         assert np.median(diff) < 1e-3 and np.quantile(diff, 0.99) < 0.1, (np.median(diff), np.quantile(diff, 0.99), diff.max())
     else:
-        assert diff.max() < 2e-2 and np.median(diff) < 1e-3, (np.median(diff), diff.max())
+        # W4A16: against the noise floor of the comparison -- the oracle vs itself with fp32-accumulating W4A16 GEMMs (a second
+        # admissible implementation; see test_full_depth_llama3_8b_verify_forward_and_cycle) -- instead of a fixed 2e-2
+        floor, rel = _w4a16_noise_floor(om, inp, ref), _rel3(got, ref)
+        print(f"w4a16 forward, err / 1e-3: max {rel.max():.2f} q99 {np.quantile(rel, 0.99):.2f}; floor max {floor.max():.2f} q99 {np.quantile(floor, 0.99):.2f}")
+        assert np.quantile(rel, 0.99) < max(1.5 * np.quantile(floor, 0.99), 2.0) and rel.max() < max(2.0 * floor.max(), 4.0), \
+            (np.quantile(rel, 0.99), np.quantile(floor, 0.99), rel.max(), floor.max())
     # layer-0 KV written by the HIP path equals the oracle's exactly for W4A4 (no attention upstream of it)
     if w4a4:
         k_hip = inp["kv_t"][0][0].cpu().numpy()
@@ -93,6 +98,26 @@ def test_forward_matches_oracle_model(tiny, oracle, w4a4, ctx_lens, q_len):
     logits = tiny.compute_logits(out, s).cpu().numpy().astype(np.float64)
     ref_logits = om.logits(ref).astype(np.float64)
     assert np.quantile(np.abs(logits - ref_logits), 0.99) < (0.1 if w4a4 else 3e-2)
+
+
+def _w4a16_noise_floor(om, inp, ref):
+    """|oracle(fp32-accumulate W4A16) - oracle(fp64-accumulate)| on the same inputs: how far two implementations that
+    both meet the per-stage 1e-3 bar are apart at the end of this model's forward."""
+    om.w4a16_f32acc = True
+    try:
+        kv2 = [(k.copy(), v.copy()) for k, v in inp["kv_np"]]
+        ref2 = om.forward(inp["ids"], inp["pos"], kv2, inp["slots"], inp["bt"], inp["ctx"], inp["q_start"], False)
+    finally:
+        om.w4a16_f32acc = False
+    # The floor moves ONE rounding source (the W4A16 accumulate order); the other fp16 rounding points (norm, Hadamard, attention
+    # output) are covered by the fixed minimum of the bars: 2 units at the 99% quantile, 4 units (~4 fp16 ulps) at the max.
+    return _rel3(ref2, ref)
+
+
+def _rel3(got, ref):
+    """|got - ref| in units of 1e-3 x max(1, |ref|): north_star's tolerance, relative above 1 (an fp16 ulp at |x| = 8 is 8e-3)."""
+    got, ref = np.asarray(got).astype(np.float64), np.asarray(ref).astype(np.float64)
+    return np.abs(got - ref) / (1e-3 * np.maximum(1.0, np.abs(ref)))
 
 
 def _engine_cycle_check(model, oracle, k, B, prompt_lens, cycles, seed, tv_bars, sync_kv=False, d_q98=None):
@@ -395,7 +420,10 @@ def test_model_family_layer_matches_oracle(oracle, family, w4a4):
         k_hip = inp["kv_t"][0][0].cpu().numpy()
         assert np.array_equal(k_hip.view(np.uint16), kv_np[0][0].view(np.uint16))
     else:
-        assert diff.max() < 2e-2 and np.median(diff) < 1e-3, (np.median(diff), diff.max())
+        floor, rel = _w4a16_noise_floor(om, inp, ref), _rel3(out.cpu().numpy(), ref)
+        print(f"{family} w4a16 layer, err / 1e-3: max {rel.max():.2f} q99 {np.quantile(rel, 0.99):.2f}; floor max {floor.max():.2f} q99 {np.quantile(floor, 0.99):.2f}")
+        assert np.quantile(rel, 0.99) < max(1.5 * np.quantile(floor, 0.99), 2.0) and rel.max() < max(2.0 * floor.max(), 4.0), \
+            (np.quantile(rel, 0.99), np.quantile(floor, 0.99), rel.max(), floor.max())
     # and the reference-order module-wise path gives the same bits as the fused one
     kv_b = [(torch.from_numpy(k).to(DEV), torch.from_numpy(v).to(DEV)) for k, v in inp["kv_np"]]
     b = model.forward_modulewise(inp["ids_t"], inp["pos_t"], kv_b, inp["md"], w4a4=w4a4)
