@@ -164,6 +164,14 @@ __device__ __forceinline__ u32x2 lds_read_tr_b16(uint32_t lds_byte_addr) {
     return r;
 }
 
+// The same read as a compiler builtin: the register allocator places the two halves of a B fragment next to each other
+// (no v_mov pairs) and the waits are the compiler's (per use, not lgkmcnt(0) behind every read).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ s16x4 lds_tr16(uint32_t lds_byte_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) s16x4*>(lds_byte_addr));
+}
+
 // Eight d tiles of one 32-key step at once (the prompt kernel): 16 transposing reads from one base address with
 // immediate offsets (d tile: +32 B, second key quad: +4 V rows), ONE wait behind all of them.
 __device__ __forceinline__ void lds_read_tr_b16_x16(uint32_t a, u32x2 (&lo)[8], u32x2 (&hi)[8]) {
@@ -190,6 +198,10 @@ __device__ __forceinline__ void lds_read_tr_b16_x16(uint32_t a, u32x2 (&lo)[8], 
 // BT: the sequence's block-table row (<= 128 entries) is fetched into two registers per lane together with the
 // per-sequence metadata, and the chunk lookups become lane permutes: the dependent chain metadata -> table entry -> K / V
 // loses one memory round trip.
+// (A wave-uniform form of the table lookup -- a K tile / the 16-key group of a V row lies in ONE block when block_size >= 16,
+// so v_readlane + SALU instead of 20 ds_bpermute -- is what paged_attention_waves_kernel<.., FAST> uses; HERE it measured
+// slower, 6.16 against 6.05 us per launch and 7.57 against 7.53 ms per cycle: the serial SALU chain is longer than the
+// pipelined permutes.)
 template <bool PF, bool BT>
 __global__ __launch_bounds__(256) void paged_attention_kernel(
     const f16* __restrict__ q, int64_t q_stride, const f16* __restrict__ key_cache, const f16* __restrict__ value_cache,
@@ -265,28 +277,29 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
     // bytes in flight, i.e. a second round trip of the CU's ~32 KB window -- 6.7 us per launch at 8 splits of a 512-key
     // context).  Lanes with equal addresses coalesce inside the wave instruction.
     const int k_last = max(k_end - 1, 0);
+    // Slots hold ELEMENT offsets of the rows' first element of this kv head: (slot * nkv + kvh) * D
     auto lookup = [&](Slots& sl, int kb) {   // block-table entries of the chunk starting at key kb
 #pragma unroll
         for (int t2 = 0; t2 < 2; t2++) {
             const int p = min(kb + (wave * 2 + t2) * 16 + c16, k_last);
-            sl.k[t2] = ((int64_t)bt_get(min(p >> bs_log2, max_blocks - 1)) << bs_log2) + (p & bmask);
+            sl.k[t2] = ((((int64_t)bt_get(min(p >> bs_log2, max_blocks - 1)) << bs_log2) + (p & bmask)) * nkv + kvh) * D;
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int p = min(kb + wave * 4 + g4 + 16 * i, k_last);
-            sl.v[i] = ((int64_t)bt_get(min(p >> bs_log2, max_blocks - 1)) << bs_log2) + (p & bmask);
+            sl.v[i] = ((((int64_t)bt_get(min(p >> bs_log2, max_blocks - 1)) << bs_log2) + (p & bmask)) * nkv + kvh) * D;
         }
     };
     auto fetch = [&](KV& kv, const Slots& sl) {
 #pragma unroll
         for (int t2 = 0; t2 < 2; t2++) {  // lane (key c16 of tile 2w+t2, d slice 8*g4 + 32j)
-            const f16* kp = key_cache + (sl.k[t2] * nkv + kvh) * D + g4 * 8;
+            const f16* kp = key_cache + sl.k[t2] + g4 * 8;
 #pragma unroll
             for (int j = 0; j < 4; j++) kv.kfrag[t2][j] = *reinterpret_cast<const u32x4*>(kp + 32 * j);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++)  // 16 lanes cover one 256-byte V row; wave w, group g4 -> keys 4w+g4 + 16i
-            kv.vraw[i] = *reinterpret_cast<const u32x4*>(value_cache + (sl.v[i] * nkv + kvh) * D + c16 * 8);
+            kv.vraw[i] = *reinterpret_cast<const u32x4*>(value_cache + sl.v[i] + c16 * 8);
     };
     Slots sl_cur, sl_nxt;
     lookup(sl_cur, k_begin);
@@ -558,8 +571,18 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
 // chunk loop of paged_attention_kernel spends 2.7 us in barrier-separated phases per chunk, the waves here overlap
 // each other: large batches and long contexts (more than one chunk per workgroup).  Partials only (out == NULL form).
 #define QS_AW_KEYS 32
-template <bool BT>   // BT: block-table row in registers, lookups as lane permutes (see paged_attention_kernel)
-__global__ __launch_bounds__(256) void paged_attention_waves_kernel(
+// NW waves per workgroup (4; 8 behind QSPEC_ATTN_NW): a wave has ONE slice (16 KB of K + V) in flight beside the one it
+// works on.  A pure read of config 3's 67 MB with 32 KB per CU in flight takes 21.8 us, 13-14 us with twice that
+// (scripts/micro/kvread.hip) -- but eight waves = two per SIMD are SLOWER here (21.6 against 19.1 us): in-kernel stamps
+// (-DQS_ATT_STAMPS, scripts/bench_attn_cold.py) show a wave stuck 0.5-1.8 us per slice at the ISSUE of its refill loads
+// (the CU's request window is full) with its softmax + P.V (1.35 us per slice) behind that.
+// FAST (needs BT, block_size >= 16; a split starts on a 16-key boundary): a 32-key slice is two 16-key halves of ONE
+// block each, so a slice needs two table entries, not ten -- wave-uniform, taken with v_readlane from the table row in
+// registers -- and every K / V address is a uniform 64-bit base (SALU) plus a lane offset that never changes.  The
+// general form spends ~250 of its ~700 loop instructions on lane permutes and 64-bit address arithmetic per slice and
+// needs AGPR copies (291 VGPRs); at one wave per SIMD the instruction count IS the slice time.
+template <bool BT, int NW, bool FAST>   // BT: block-table row in registers, lookups as lane permutes (see paged_attention_kernel)
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void paged_attention_waves_kernel(
     const f16* __restrict__ q, int64_t q_stride, const f16* __restrict__ key_cache, const f16* __restrict__ value_cache,
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
     const int32_t* __restrict__ q_start, int nq, int nkv, int bs_log2, int group_log2, float sm_scale, int n_splits,
@@ -618,6 +641,36 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
             sl.v[i] = ((int64_t)bt_get(min(p >> bs_log2, max_blocks - 1)) << bs_log2) + (p & bmask);
         }
     };
+    // FAST: uniform element offsets of the slice's two 16-key halves, ((slot * nkv) + kvh) * D
+    static_assert(!FAST || BT, "the fast lookup reads the table row from registers");
+    auto ublock = [&](int bi) -> int {   // bi wave-uniform
+        const int i = __builtin_amdgcn_readfirstlane(min(bi, max_blocks - 1));
+        const int a = __builtin_amdgcn_readlane(btv0, i & 63), b2 = __builtin_amdgcn_readlane(btv1, i & 63);
+        return i < 64 ? a : b2;
+    };
+    auto lookup_u = [&](int64_t (&base)[2], int sbu) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int p = sbu + 16 * h;
+            const int64_t slot = ((int64_t)ublock(p >> bs_log2) << bs_log2) + (p & bmask);
+            base[h] = (slot * nkv + kvh) * D;
+        }
+    };
+    const int k_lane = (c16 * nkv) * D + g4 * 8, v_lane = (g4 * nkv) * D + c16 * 8;   // elements; < 2^31 (nkv * 16 * 128)
+    const int v_step = 4 * nkv * D;                                                   // four rows further
+    auto fetch_k_u = [&](KV& kv, const int64_t (&base)[2]) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {
+            const f16* kp = key_cache + base[t2] + k_lane;
+#pragma unroll
+            for (int j = 0; j < 4; j++) kv.kf[t2][j] = *reinterpret_cast<const u32x4*>(kp + 32 * j);
+        }
+    };
+    auto fetch_v_u = [&](KV& kv, const int64_t (&base)[2]) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            kv.vr[i] = *reinterpret_cast<const u32x4*>(value_cache + base[i >> 2] + (int64_t)((i & 3) * v_step) + v_lane);
+    };
     auto fetch = [&](KV& kv, const Slots& sl) {
 #pragma unroll
         for (int t2 = 0; t2 < 2; t2++) {   // lane (key c16 of tile t2, d slice 8 g4 + 32 j)
@@ -629,10 +682,25 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
         for (int i = 0; i < 8; i++)   // 16 lanes cover one 256-byte V row: key 4 i + g4 of the slice
             kv.vr[i] = *reinterpret_cast<const u32x4*>(value_cache + (sl.v[i] * nkv + kvh) * D + c16 * 8);
     };
-    int sb = k_begin + wave * QS_AW_KEYS;
+#ifdef QS_ATT_STAMPS
+    long long awst[24];
+    int awn = 0;
+#define QS_AWST() do { if (awn < 24) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(awst[awn])::"memory"); awn++; } } while (0)
+#define QS_AWST_NW() do { if (awn < 24) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(awst[awn])::"memory"); awn++; } } while (0)
+#else
+#define QS_AWST()
+#define QS_AWST_NW()
+#endif
+    QS_AWST_NW();   // 0: metadata here
+    int sb = (FAST ? __builtin_amdgcn_readfirstlane(k_begin) : k_begin) + wave * QS_AW_KEYS;
     Slots sl_cur, sl_nxt;
-    lookup(sl_cur, sb);
-    lookup(sl_nxt, sb + 4 * QS_AW_KEYS);
+    int64_t ub[2];
+    if constexpr (FAST) {
+        lookup_u(ub, sb);
+    } else {
+        lookup(sl_cur, sb);
+        lookup(sl_nxt, sb + NW * QS_AW_KEYS);
+    }
     u32x4 qfrag[4];
     {
         const int r = r0 + (c16 < R ? c16 : 0);
@@ -642,7 +710,12 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
         for (int j = 0; j < 4; j++) qfrag[j] = *reinterpret_cast<const u32x4*>(qp + 32 * j);
     }
     KV cur;
-    fetch(cur, sl_cur);
+    if constexpr (FAST) {
+        fetch_k_u(cur, ub);
+        fetch_v_u(cur, ub);
+    } else {
+        fetch(cur, sl_cur);
+    }
     int pos[4];
     float row_m[4], row_l[4];
     f32x4 o[8];
@@ -656,8 +729,10 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
     for (int dt = 0; dt < 8; dt++) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const uint32_t vl_base = (uint32_t)(uintptr_t)vl;
     const int qd = c16 >> 2, pq = c16 & 3;
+    QS_AWST_NW();   // 1: first slice requested
 
-    for (int s2 = wave; s2 < n_sl; s2 += 4) {
+    for (int s2 = wave; s2 < n_sl; s2 += NW) {
+        QS_AWST();  // loop top: the slice's K and V have arrived (stamp build only: waits for everything)
         const int nkeys = max(0, min(k_end - sb, QS_AW_KEYS));
         // ---- S = Q K^T: lane holds rows 4 g4 + reg, key column t2 * 16 + c16.  Each K register is refilled with the
         // wave's NEXT slice right behind its last use (as the weight ring of gemm_stream.hip): the loads never stop.
@@ -675,26 +750,42 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
                 sacc[t2][reg] = (kk < nkeys && p <= pos[reg]) ? acc[reg] * sm_scale : -__builtin_inff();
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FAST) {
+            lookup_u(ub, sb + NW * QS_AW_KEYS);   // the wave's next slice (clamped to the table: no load behind a branch)
+            fetch_k_u(cur, ub);
+        } else {
 #pragma unroll
-        for (int t2 = 0; t2 < 2; t2++) {
-            const f16* kp = key_cache + (sl_nxt.k[t2] * nkv + kvh) * D + g4 * 8;
+            for (int t2 = 0; t2 < 2; t2++) {
+                const f16* kp = key_cache + (sl_nxt.k[t2] * nkv + kvh) * D + g4 * 8;
 #pragma unroll
-            for (int j = 0; j < 4; j++) cur.kf[t2][j] = *reinterpret_cast<const u32x4*>(kp + 32 * j);
+                for (int j = 0; j < 4; j++) cur.kf[t2][j] = *reinterpret_cast<const u32x4*>(kp + 32 * j);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         // V rows -> the wave's LDS tile (zeros past the end keep the MFMA clean), registers refilled the same way
+        if (nkeys == QS_AW_KEYS) {   // uniform; LDS stores only (no global load sits behind this branch)
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int kk = i * 4 + g4;
-            const u32x4 vz = kk < nkeys ? cur.vr[i] : u32x4{0, 0, 0, 0};
-            *reinterpret_cast<u32x4*>(vl + kk * QS_ATT_VSTRIDE + c16 * 8) = vz;
+            for (int i = 0; i < 8; i++)
+                *reinterpret_cast<u32x4*>(vl + (i * 4 + g4) * QS_ATT_VSTRIDE + c16 * 8) = cur.vr[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int kk = i * 4 + g4;
+                const u32x4 vz = kk < nkeys ? cur.vr[i] : u32x4{0, 0, 0, 0};
+                *reinterpret_cast<u32x4*>(vl + kk * QS_ATT_VSTRIDE + c16 * 8) = vz;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FAST) {
+            fetch_v_u(cur, ub);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 8; i++)
-            cur.vr[i] = *reinterpret_cast<const u32x4*>(value_cache + (sl_nxt.v[i] * nkv + kvh) * D + c16 * 8);
+            for (int i = 0; i < 8; i++)
+                cur.vr[i] = *reinterpret_cast<const u32x4*>(value_cache + (sl_nxt.v[i] * nkv + kvh) * D + c16 * 8);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        lookup(sl_nxt, sb + 8 * QS_AW_KEYS);             // table entries of the slice after the next (clamped)
+        QS_AWST_NW();   // QK + refills issued + V in LDS
+        if constexpr (!FAST) lookup(sl_nxt, sb + 2 * NW * QS_AW_KEYS);           // table entries of the slice after the next (clamped)
         // ---- running softmax: the 16 lanes of a g4 group hold the 32 keys of rows 4 g4 + reg
         float alpha[4];
 #pragma unroll
@@ -731,21 +822,26 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
         {
             const f16x8 pa = *reinterpret_cast<const f16x8*>(pl + c16 * PSTR + g4 * 8);
             const f16x8 pb = *reinterpret_cast<const f16x8*>(pl + (16 + c16) * PSTR + g4 * 8);
-            u32x2 lo[8], hi[8];   // all 16 reads behind ONE wait (in two halves: 16 VGPRs fewer, but two waits: slower)
-            lds_read_tr_b16_x16(vl_base + (uint32_t)(((g4 * 8 + qd) * QS_ATT_VSTRIDE + 4 * pq) * 2), lo, hi);
+            const uint32_t va = vl_base + (uint32_t)(((g4 * 8 + qd) * QS_ATT_VSTRIDE + 4 * pq) * 2);
+            s16x8 bw[8];   // d tile dt: +32 B; the fragment's second key quad: +4 V rows
+#pragma unroll
+            for (int dt = 0; dt < 8; dt++)
+                bw[dt] = __builtin_shufflevector(lds_tr16(va + 32 * dt), lds_tr16(va + 32 * dt + 4 * QS_ATT_VSTRIDE * 2), 0, 1, 2,
+                                                 3, 4, 5, 6, 7);
 #pragma unroll
             for (int dt = 0; dt < 8; dt++) {
-                const u32x4 bw = {lo[dt][0], lo[dt][1], hi[dt][0], hi[dt][1]};
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw[dt]), o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw[dt]), o[dt], 0, 0, 0);
             }
         }
-        sb += 4 * QS_AW_KEYS;
+        sb += NW * QS_AW_KEYS;
+        QS_AWST_NW();   // slice done (softmax + P.V)
     }
+    QS_AWST_NW();
     // ---- combine the four waves (wave order), store the split's partial: ws_o [T, nq, n_splits, D], ws_ml [.., 2]
     __syncthreads();   // every wave is done with its private tiles: the same LDS now carries the exchange
-    float* co = reinterpret_cast<float*>(smem_raw);          // [4][16][128]
-    float* cml = co + 4 * 16 * D;                             // [4][16][2]
+    float* co = reinterpret_cast<float*>(smem_raw);          // [NW][16][128]
+    float* cml = co + NW * 16 * D;                            // [NW][16][2]
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
         const int r = 4 * g4 + reg;
@@ -759,13 +855,13 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
     __syncthreads();
     {
         const int r = tid >> 4, c8 = (tid & 15) * 8;
-        if (r < R) {
+        if (r < R) {   // R <= 16: the first 256 threads
             float M = -__builtin_inff();
 #pragma unroll
-            for (int w = 0; w < 4; w++) M = fmaxf(M, cml[(w * 16 + r) * 2]);
+            for (int w = 0; w < NW; w++) M = fmaxf(M, cml[(w * 16 + r) * 2]);
             float l = 0.0f, acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
+            for (int w = 0; w < NW; w++) {
                 const float m = cml[(w * 16 + r) * 2];
                 const float wg = m == -__builtin_inff() ? 0.0f : aexp(m - M);
                 l = __builtin_fmaf(wg, cml[(w * 16 + r) * 2 + 1], l);
@@ -787,6 +883,14 @@ __global__ __launch_bounds__(256) void paged_attention_waves_kernel(
             }
         }
     }
+#ifdef QS_ATT_STAMPS
+    QS_AWST_NW();
+    if (tid == 0 && blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0) {
+        long long* sbp = reinterpret_cast<long long*>(ws_o) - (QS_ATT_CNT_SLOTS / 2) + 1024;   // int slot 2048 of the counters
+        sbp[0] = awn;
+        for (int i = 0; i < awn; i++) sbp[1 + i] = awst[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- prompt-sized queries (flash-attn varlen, head 128)
@@ -1204,15 +1308,37 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
     static const int aw_env = getenv("QSPEC_ATTN_WAVES") ? atoi(getenv("QSPEC_ATTN_WAVES")) : -1;
     const bool long_splits = ((int64_t)max_blocks << bs_log2) > (int64_t)QS_ATT_CHUNK * n_splits;
     if (!out && (aw_env >= 0 ? aw_env != 0 : long_splits)) {
-        const size_t wlds = (size_t)4 * (QS_AW_KEYS * QS_ATT_VSTRIDE * 2 + 2 * 16 * 40 * 2);
-        if (max_blocks <= 128)
-            hipLaunchKernelGGL(paged_attention_waves_kernel<true>, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), wlds, st,
-                               q, q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv,
-                               bs_log2, group_log2, sm_scale, n_splits, n_rb, ws_o, ws_ml);
-        else
-            hipLaunchKernelGGL(paged_attention_waves_kernel<false>, dim3(n_seqs, nkv * n_rb, n_splits), dim3(256), wlds, st,
-                               q, q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, nkv,
-                               bs_log2, group_log2, sm_scale, n_splits, n_rb, ws_o, ws_ml);
+        // QSPEC_ATTN_NW=8 (dev knob): eight waves, two per SIMD -- measured SLOWER (config 3: 21.6 against 19.1 us back to
+        // back): the kernel is not short of bytes in flight
+        static const int nw_env = getenv("QSPEC_ATTN_NW") ? atoi(getenv("QSPEC_ATTN_NW")) : 0;
+        const int nw = nw_env == 8 ? 8 : 4;
+        const size_t wave_lds = QS_AW_KEYS * QS_ATT_VSTRIDE * 2 + 2 * 16 * 40 * 2;
+        const size_t wlds = std::max((size_t)nw * wave_lds, (size_t)nw * 16 * (128 + 2) * 4);
+#define QS_AW_LAUNCH(BTV, NWV, FV)                                                                                           \
+    do {                                                                                                                   \
+        static bool attr_set = false;                                                                                      \
+        if (!attr_set) {                                                                                                   \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_waves_kernel<BTV, NWV, FV>),                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds) != hipSuccess)                  \
+                return -8;                                                                                                 \
+            attr_set = true;                                                                                               \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((paged_attention_waves_kernel<BTV, NWV, FV>), dim3(n_seqs, nkv * n_rb, n_splits), dim3(64 * NWV),   \
+                           wlds, st, q, q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, \
+                           nkv, bs_log2, group_log2, sm_scale, n_splits, n_rb, ws_o, ws_ml);                               \
+    } while (0)
+        static const int fast_env = getenv("QSPEC_ATTN_FAST") ? atoi(getenv("QSPEC_ATTN_FAST")) : 1;   // dev knob
+        if (max_blocks <= 128 && bs_log2 >= 4 && fast_env) {   // two uniform table entries per 32-key slice
+            if (nw == 8) QS_AW_LAUNCH(true, 8, true);
+            else QS_AW_LAUNCH(true, 4, true);
+        } else if (max_blocks <= 128) {
+            if (nw == 8) QS_AW_LAUNCH(true, 8, false);
+            else QS_AW_LAUNCH(true, 4, false);
+        } else {
+            if (nw == 8) QS_AW_LAUNCH(false, 8, false);
+            else QS_AW_LAUNCH(false, 4, false);
+        }
+#undef QS_AW_LAUNCH
         return 0;
     }
     // more workgroups than CUs: occupancy (two per CU) instead of the in-workgroup prefetch

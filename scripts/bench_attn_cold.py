@@ -39,10 +39,11 @@ for q_len in (1, 4):
     st = None
     t_att = run("att")
     stx = ws[2048 * 4:2048 * 4 + 9 * 8].view(torch.int64).cpu().tolist()
-    stw = ws[8192:8192 + 48].view(torch.int64).cpu().tolist()
-    if os.environ.get("QSPEC_ATTN_WAVES") == "1" and any(stw):
-        print("  waves-kernel slice stamps (ticks): K wait+QK %d, refill K %d, V->LDS %d, refill V+lookup+softmax %d, PV %d"
-              % tuple(stw[i + 1] - stw[i] for i in range(5)), flush=True)
+    stw = ws[8192:8192 + 25 * 8].view(torch.int64).cpu().tolist()
+    if 0 < stw[0] <= 24:   # -DQS_ATT_STAMPS build of the waves kernel: wave 0 of workgroup (1, 1, 0)
+        t = stw[1:1 + stw[0]]
+        print("  waves-kernel stamps, ticks since the metadata arrived (per slice: arrived / QK + refills issued + V in LDS / slice done): "
+              + " ".join(str(x - t[0]) for x in t[1:]), flush=True)
     if nq not in (32, 64):
         kvb = B * ctx0 * nkv * d * 2 * 2
         print(f"q_len={q_len}: attention(partials, cold KV) {t_att:.2f} us  ({kvb / t_att / 1e6:.2f} TB/s of KV)", flush=True)

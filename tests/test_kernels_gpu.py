@@ -1238,6 +1238,23 @@ def test_attention_partials_long_splits_then_merge_within_1e3(ops, oracle, ctx_l
     assert_close_1e3(host(out), ref)
 
 
+@pytest.mark.parametrize("switch", ["QSPEC_ATTN_FAST=0", "QSPEC_ATTN_NW=8"])
+def test_attention_waves_kernel_dev_forms(switch):
+    """paged_attention_waves_kernel's other forms (attention.hip: the general per-lane table lookup instead of the two
+    wave-uniform entries per slice; eight waves per workgroup, measured slower and off) against the same oracle comparison:
+    the long-splits test re-run in a child process with the switch on (the library reads it once per process)."""
+    import os
+    import subprocess
+    import sys
+    k, v = switch.split("=")
+    env = dict(os.environ)
+    env[k] = v
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                        "long_splits_then_merge or reference_fixture_within"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 # ------------------------------------------------------------------ the reference's own pure-torch formulas (fixtures)
 # tests/golden/{attention,rope_cache_softmax}.npz: outputs of ref_paged_attn (tests/kernels/test_flash_attn.py:19-75),
 # RotaryEmbedding.forward_native (rotary_embedding.py:201-229), the reshape_and_cache_flash reference loop
