@@ -158,14 +158,9 @@ int rope_kv_write(const int64_t* positions, f16* qkv, const f16* cos_sin_cache, 
 #define QS_ATT_VSTRIDE 144     // halves per V row in LDS (288 B): 4 rows x 4 column quads hit 16 distinct bank pairs
 #define QS_ATT_MAXSPLIT 64
 
-__device__ __forceinline__ u32x2 lds_read_tr_b16(uint32_t lds_byte_addr) {
-    u32x2 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_byte_addr) : "memory");
-    return r;
-}
-
-// The same read as a compiler builtin: the register allocator places the two halves of a B fragment next to each other
-// (no v_mov pairs) and the waits are the compiler's (per use, not lgkmcnt(0) behind every read).
+// ds_read_b64_tr_b16 as a compiler builtin: the register allocator places the two halves of a B fragment next to each
+// other (no v_mov pairs) and the waits are the compiler's (per use, not lgkmcnt(0) behind every read, as the inline-asm
+// form of rounds 1-2 had it).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ s16x4 lds_tr16(uint32_t lds_byte_addr) {
@@ -341,12 +336,20 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
                 sc[r * QS_ATT_CHUNK + kk] = (kk < nkeys && p <= pos) ? acc[reg] * sm_scale : -__builtin_inff();
             }
         }
-        // V rows -> LDS (zeros beyond nkeys keep the MFMA clean)
+        // V rows -> LDS: only the 32-key steps P.V walks (st * 32 < nkeys), zeros beyond nkeys inside the last of them
+        // (uniform branches around LDS stores; no global load sits behind them)
+        if ((nkeys & 31) == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int kk = wave * 4 + g4 + 16 * i;
-            const u32x4 vz = kk < nkeys ? kv.vraw[i] : u32x4{0, 0, 0, 0};
-            *reinterpret_cast<u32x4*>(vl + kk * QS_ATT_VSTRIDE + c16 * 8) = vz;
+            for (int i = 0; i < 8; i++)
+                if (16 * i < nkeys)
+                    *reinterpret_cast<u32x4*>(vl + (wave * 4 + g4 + 16 * i) * QS_ATT_VSTRIDE + c16 * 8) = kv.vraw[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int kk = wave * 4 + g4 + 16 * i;
+                const u32x4 vz = kk < nkeys ? kv.vraw[i] : u32x4{0, 0, 0, 0};
+                if (16 * i < ((nkeys + 31) & ~31)) *reinterpret_cast<u32x4*>(vl + kk * QS_ATT_VSTRIDE + c16 * 8) = vz;
+            }
         }
         __syncthreads();
         // ---- softmax over the 128 keys of a row, folded into the running (max, sum): thread (row = tid>>4, 8 keys)
@@ -412,9 +415,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
                 for (int dt = 0; dt < 2; dt++) {
                     const int d0 = wave * 32 + dt * 16;
                     const uint32_t a0 = vl_base + (uint32_t)((krow * QS_ATT_VSTRIDE + d0 + 4 * pq) * 2);
-                    const u32x2 lo = lds_read_tr_b16(a0);
-                    const u32x2 hi = lds_read_tr_b16(a0 + 4 * QS_ATT_VSTRIDE * 2);
-                    const u32x4 bw = {lo[0], lo[1], hi[0], hi[1]};
+                    const s16x8 bw = __builtin_shufflevector(lds_tr16(a0), lds_tr16(a0 + 4 * QS_ATT_VSTRIDE * 2), 0, 1, 2, 3, 4, 5, 6, 7);
                     if (dt == 0) {
                         o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pb, __builtin_bit_cast(f16x8, bw), o0, 0, 0, 0);
                         o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, __builtin_bit_cast(f16x8, bw), o0, 0, 0, 0);
