@@ -103,26 +103,53 @@ __global__ __launch_bounds__(256) void gemm_w4a16_tiled_kernel(const f16* __rest
     a_store(0);
     __syncthreads();
 
-    // one stage = 2 weight steps; lane (weight row nl, k-group kg), step j, dword dd <-> k = 64 j + 32 kg + 8 dd
+    // one stage = 2 weight steps; lane (weight row nl, k-group kg), step j, dword dd <-> k = 64 j + 32 kg + 8 dd.
+    // The activation fragment of token row mt * 32 + nl for (j, dd) is the 16-byte chunk (8 j + 4 kg + dd) ^ (nl & 15) of
+    // that row: eight per-lane byte offsets computed ONCE (the stage buffer and the token tile are immediates of the
+    // ds_read), and the fragments of sub-step i + 1 are requested BEFORE the matrix instructions of sub-step i: left to the
+    // compiler, every read sat one MFMA in front of its use behind an `s_waitcnt lgkmcnt(1)` -- an LDS round trip (~100
+    // cycles) exposed per 32-cycle MFMA, which is what held the kernel at 0.38 of the dense peak.
+    int aoff[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) aoff[i] = nl * ROWB + ((((i >> 2) * 8 + kg * 4 + (i & 3)) ^ (nl & 15)) << 4);
+    auto a_frag = [&](int buf, int mt, int i) -> f16x8 {
+        return *reinterpret_cast<const f16x8*>(smem + aoff[i] + (buf * BM + mt * 32) * ROWB);
+    };
+    // A wave issues in order: an MFMA behind a busy matrix pipe blocks the VALU work queued after it, so a block of
+    // dequantiser VALU followed by a block of MFMAs executes one AFTER the other (counters of that form, M = 2048:
+    // 43 % of the wave cycles issuing, 42 % stalled at the issue, matrix pipe busy 37 %).  The dequantiser of sub-step
+    // i + 1 is therefore INTERLEAVED with the MFMAs of sub-step i, a few VALU instructions behind each MFMA
+    // (sched_group_barrier), and the fragments of i + 1 are requested in front of them.
+    constexpr int NMF = MT * NT;                             // MFMAs per sub-step
+    constexpr int VPM = (14 * NT + NMF - 1) / NMF;           // dequantiser VALU instructions to place behind each
     auto stage_compute = [&](int buf, const u32x4 (&w0)[NT], const u32x4 (&w1)[NT]) {
-        const unsigned char* b = smem + (size_t)buf * BM * ROWB;
+        f16x8 av[2][MT], bf[2][NT];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int mt = 0; mt < MT; mt++) av[0][mt] = a_frag(buf, mt, 0);
 #pragma unroll
-            for (int dd = 0; dd < 4; dd++) {
-                f16x8 bf[NT];
+        for (int nt = 0; nt < NT; nt++) bf[0][nt] = tdequant_s4x8(w0[nt][0]);
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++) bf[nt] = tdequant_s4x8(j == 0 ? w0[nt][dd] : w1[nt][dd]);
-                const int q = j * 8 + kg * 4 + dd;
+        for (int i = 0; i < 8; i++) {
+            if (i + 1 < 8) {
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++) {
-                    const int row = mt * 32 + nl;
-                    const f16x8 av = *reinterpret_cast<const f16x8*>(b + (size_t)row * ROWB + ((q ^ (row & 15)) << 4));
-#pragma unroll
-                    for (int nt = 0; nt < NT; nt++)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bf[nt], acc[mt][nt], 0, 0, 0);
-                }
+                for (int mt = 0; mt < MT; mt++) av[(i + 1) & 1][mt] = a_frag(buf, mt, i + 1);
             }
+            __builtin_amdgcn_sched_barrier(0);   // the next fragments are requested HERE; below: MFMA / VALU / MFMA / VALU ...
+            if (i + 1 < 8) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) bf[(i + 1) & 1][nt] = tdequant_s4x8(i + 1 < 4 ? w0[nt][(i + 1) & 3] : w1[nt][(i + 1) & 3]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i & 1][mt], bf[i & 1][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < NMF; m++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // the last round is peeled so that no weight refill sits behind a branch
