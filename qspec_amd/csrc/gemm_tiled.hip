@@ -255,7 +255,9 @@ int gemm_w4a16_tiled(const f16* x, const int8_t* wq, const f16* ws, f16* out, in
     // two weight tiles per wave when that still leaves two workgroups per CU (large M): halves the LDS reads per MFMA
     static const int force_nt = env_int("QSPEC_TILED_NT", 0);
     const int mblocks = (M + 32 * MT - 1) / (32 * MT);
-    int NT = (N % 256 == 0 && (long long)(N / 256) * mblocks * S >= 512) ? 2 : 1;
+    // (round 3, with the interleaved inner loop: two tiles per wave win from ~200 workgroups on -- gate_up at M = 192:
+    // 50.9 against 54.2 us, at 512: 126.6 against 132.7 -- not only from two workgroups per CU)
+    int NT = (N % 256 == 0 && (long long)(N / 256) * mblocks * S >= 192) ? 2 : 1;
     if (force_nt == 1 || (force_nt == 2 && N % 256 == 0)) NT = force_nt;
     const dim3 grid(N / (128 * NT), mblocks, S);
     const size_t lds = (size_t)2 * 32 * MT * (QS_T_STAGE_K * 2);   // <= 64 KiB
