@@ -204,6 +204,13 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
     const int32_t* __restrict__ q_start, int nq, int nkv, int bs_log2, int group_log2, float sm_scale, int n_splits,
     int n_rb, int* cnt, float* ws_o, float* ws_ml, f16* __restrict__ out, int merge) {
     constexpr int D = 128;
+#ifdef QS_ATT_STAMPS
+    long long stamp[10];
+#define QS_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i])::"memory")
+#else
+#define QS_STAMP(i)
+#endif
+    QS_STAMP(9);   // entry
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sc = reinterpret_cast<float*>(smem_raw);                          // [16 rows][128 keys] fp32 scores
     f16* pl = reinterpret_cast<f16*>(sc + QS_ATT_MAXR * QS_ATT_CHUNK);       // [16 rows][128 keys] fp16 probabilities
@@ -250,12 +257,6 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
             return bt[bi];
         }
     };
-#ifdef QS_ATT_STAMPS
-    long long stamp[10];
-#define QS_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[i])::"memory")
-#else
-#define QS_STAMP(i)
-#endif
     QS_STAMP(0);
 
     // No load below sits behind a branch (hipcc answers control flow around a load with s_waitcnt vmcnt(0), which
@@ -317,8 +318,11 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
     f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
     QS_STAMP(1);
 
+    int qpos[4];   // absolute position of the query token of this lane's score rows 4 g4 + reg
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) qpos[reg] = ctx - qlen + ((r0 + 4 * g4 + reg) >> group_log2);
     auto process = [&](const KV& kv, int kb, bool last) {
-        const int nkeys = max(0, min(k_end - kb, QS_ATT_CHUNK));
+        const int nkeys = __builtin_amdgcn_readfirstlane(max(0, min(k_end - kb, QS_ATT_CHUNK)));   // uniform: scalar branches below
         // ---- S = Q K^T (fp32 accumulate) -> sc[row][key], masked and scaled
 #pragma unroll
         for (int t2 = 0; t2 < 2; t2++) {
@@ -330,10 +334,9 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
             const int kk = (wave * 2 + t2) * 16 + c16;  // lane holds rows 4*g4 + reg of key column kk
             const int p = kb + kk;
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int r = 4 * g4 + reg;
-                const int pos = ctx - qlen + ((r0 + r) >> group_log2);  // absolute position of this query token
-                sc[r * QS_ATT_CHUNK + kk] = (kk < nkeys && p <= pos) ? acc[reg] * sm_scale : -__builtin_inff();
+            for (int reg = 0; reg < 4; reg++) {   // one compare-and-select per score: no short-circuit branches
+                const bool ok = (kk < nkeys) & (p <= qpos[reg]);
+                sc[(4 * g4 + reg) * QS_ATT_CHUNK + kk] = ok ? acc[reg] * sm_scale : -__builtin_inff();
             }
         }
         // V rows -> LDS: only the 32-key steps P.V walks (st * 32 < nkeys), zeros beyond nkeys inside the last of them
@@ -351,6 +354,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
                 if (16 * i < ((nkeys + 31) & ~31)) *reinterpret_cast<u32x4*>(vl + kk * QS_ATT_VSTRIDE + c16 * 8) = vz;
             }
         }
+        if (last) QS_STAMP(3);
         __syncthreads();
         // ---- softmax over the 128 keys of a row, folded into the running (max, sum): thread (row = tid>>4, 8 keys)
         {
@@ -393,7 +397,9 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
                 row_l[r] = __builtin_fmaf(row_l[r], alpha, sum);   // first chunk: 0 * 0 + sum
             }
         }
+        if (last) QS_STAMP(7);
         __syncthreads();
+        if (last) QS_STAMP(8);
         // ---- O = O * alpha + P V: wave w owns d columns 32w..32w+31 (two 16-wide tiles), k over the 128 keys in 4 steps
         {
 #pragma unroll
@@ -443,6 +449,10 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
         }
         kb += QS_ATT_CHUNK;
     }
+#ifdef QS_ATT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    QS_STAMP(2);   // the (last) chunk's K / V are here
+#endif
     process(cur, kb, true);
     QS_STAMP(4);
     // ---- partial of this split -> workspace: ws_o [T, nq, n_splits, D], ws_ml [T, nq, n_splits, 2]
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(256) void paged_attention_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         QS_STAMP(6);
         long long* sb = reinterpret_cast<long long*>(cnt + 2048);
-        for (int i = 0; i < 9; i++) sb[i] = stamp[i];
+        for (int i = 0; i < 10; i++) sb[i] = stamp[i];
     }
 #endif
     if (!merge) return;

@@ -24,5 +24,6 @@ for kc, vc in eng.kv_caches:      # 32 launches on 32 different caches: the last
                         cfg.num_attention_heads, model.sm_scale, md.n_splits, s.attn_ws, None)
 torch.cuda.synchronize()
 st = s.attn_ws.view(torch.int32)[2048:2048 + 20].view(torch.int64).cpu().tolist()
-print("attention (workgroup 0), cycles from the first stamp: [loads issued / running state set, -, -, chunk done, partials stored, stores drained]:",
-      [st[i] - st[0] for i in (1, 4, 5, 6)])
+print("attention (workgroup 0), ticks: entry -> metadata + table row here %d | -> K / V requested %d | -> K / V here %d | -> QK^T, scores + V in LDS %d | -> "
+      "barrier + softmax + P in LDS %d | -> barrier %d | -> P.V done %d | -> partials stored %d | -> stores drained %d"
+      % (st[0] - st[9], st[1] - st[0], st[2] - st[1], st[3] - st[2], st[7] - st[3], st[8] - st[7], st[4] - st[8], st[5] - st[4], st[6] - st[5]))
