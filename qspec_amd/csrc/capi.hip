@@ -578,9 +578,11 @@ int qspec_w4a16_linear_partial(const qspec_half* x, const int8_t* wq, float* par
     const char* op = "qspec_w4a16_linear_partial";
     if (M == 0 || N == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, part);
-    if (slices < 2 || slices != qspec::gemm_w4a16_stream_partial_slices(M, N, K))
-        return fail("%s: (M=%d N=%d K=%d) takes %d slices (qspec_w4a16_linear_partial_slices), got %d", op, M, N, K,
-                    qspec::gemm_w4a16_stream_partial_slices(M, N, K), slices);
+    // the planned count (qspec_w4a16_linear_partial_slices), or -- for shapes that also run unsliced -- any count whose
+    // slices the streaming kernel takes (the verify pass's o_proj experiment)
+    const int planned = qspec::gemm_w4a16_stream_partial_slices(M, N, K);
+    if (slices < 2 || slices > 8 || K % slices || (planned ? slices != planned : !qspec::gemm_w4a16_stream_supported(M, N, K / slices)))
+        return fail("%s: (M=%d N=%d K=%d) takes %d slices (qspec_w4a16_linear_partial_slices), got %d", op, M, N, K, planned, slices);
     return finish(op, qspec::gemm_w4a16_stream_partial(CH(x), 0, wq, 0, part, M, N, K, slices, ST));
 }
 int qspec_add_rms_norm_fp16_partial(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const float* part,

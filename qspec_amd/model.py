@@ -163,6 +163,7 @@ class QuarotLlamaForCausalLM:
     # Measured in the engine (round 2): bs = 4 fused 8.39 vs separate 8.43 ms per cycle; bs = 16 fused (hand-off form)
     # 14.30 vs separate 13.38 ms -- the standalone norm launch (3.4 us) beats the hand-off from 8 tokens on.
     FUSE_LN_MAX_M = int(__import__("os").environ.get("QSPEC_FUSE_LN_MAX_M", "4"))
+    VERIFY_O_SLICES = int(__import__("os").environ.get("QSPEC_VERIFY_O_SLICES", "0"))   # dev knob, see the o_proj branch below
     FUSE_LN = True
     # draft pass, T <= 4, 32 heads of 128: head Hadamard spread over 8 workgroups per token + the quantiser in o_proj's prologue
     HADAMARD_QUANT_IN_OPROJ = __import__("os").environ.get("QSPEC_HQ_OPROJ", "1") != "0"
@@ -297,6 +298,14 @@ class QuarotLlamaForCausalLM:
                     ops.w4a16_linear_ksliced_raw(had, layer.o_proj.weight, part[0], k0, k1)
                     self.tp.all_reduce(part)
                     ops.add_rms_norm_fp16_partial(normed, hidden, hidden, part, layer.o_proj._scales(), 1, eps)
+                elif self.VERIFY_O_SLICES > 1 and fuse and s.down_part is not None and T <= 16:
+                    # dev knob (QSPEC_VERIFY_O_SLICES = 2 / 4): o_proj as K slices whose raw sums the norm finishes, as
+                    # down_proj's are -- measured, not the default: the slice order of the sum also
+                    # breaks the bit identity with the module-wise path
+                    S = self.VERIFY_O_SLICES
+                    part = s.down_part.view(-1)[:S * T * cfg.hidden_size].view(S, T, cfg.hidden_size)
+                    ops.w4a16_linear_partial(had, layer.o_proj.weight, part, S)
+                    ops.add_rms_norm_fp16_partial(normed, hidden, hidden, part, layer.o_proj._scales(), S, eps)
                 else:
                     self._w4a16(had, layer.o_proj, o)
                     ops.add_rms_norm_fp16(normed, hidden, hidden, o, eps)

@@ -434,6 +434,33 @@ def test_model_family_layer_matches_oracle(oracle, family, w4a4):
         assert (out.float() - b.float()).abs().max().item() < 2e-2
 
 
+def test_verify_o_proj_k_sliced_dev_knob_meets_the_same_bar(oracle, monkeypatch):
+    """QSPEC_VERIFY_O_SLICES (model.py, dev knob; measured in rounds 1 and 3 and left off: DESIGN.md section 4): the verify pass's
+    o_proj as K slices whose raw fp32 sums the following norm finishes, as down_proj's are.  Same comparison and bars as
+    test_model_family_layer_matches_oracle at the Llama-3-8B width, and within two fp16 ulps of the unsliced form."""
+    from oracle.model import OracleModel
+    from qspec_amd.model import QuarotLlamaConfig, QuarotLlamaForCausalLM, Scratch
+    H, I, nh, nkv, theta = FAMILIES["llama-3-8b"]
+    cfg = QuarotLlamaConfig(H, I, nh, nkv, 1, 1024, 1e-5, theta, 512, "llama-3-8b-1layer")
+    model = QuarotLlamaForCausalLM(cfg, DEV).init_synthetic(seed=2, lm_head_std=0.05)
+    rng = np.random.default_rng(4)
+    inp = make_inputs(model, rng, [33, 150], 2)
+    om = OracleModel.from_torch_model(model, 16)
+    ref = om.forward(inp["ids"], inp["pos"], [(k.copy(), v.copy()) for k, v in inp["kv_np"]], inp["slots"], inp["bt"], inp["ctx"],
+                     inp["q_start"], False)
+    outs = {}
+    for S in (0, 2, 4):
+        monkeypatch.setattr(QuarotLlamaForCausalLM, "VERIFY_O_SLICES", S)
+        kv = [(torch.from_numpy(k).to(DEV), torch.from_numpy(v).to(DEV)) for k, v in inp["kv_np"]]
+        s = Scratch(cfg, inp["T"], 2, 2, inp["n_splits"], DEV)
+        outs[S] = model.forward(inp["ids_t"], inp["pos_t"], kv, inp["md"], s, w4a4=False).float().cpu().numpy()
+    floor = _w4a16_noise_floor(om, inp, ref)
+    for S in (2, 4):
+        rel = _rel3(outs[S], ref)
+        assert np.quantile(rel, 0.99) < max(1.5 * np.quantile(floor, 0.99), 2.0) and rel.max() < max(2.0 * floor.max(), 4.0)
+        assert _rel3(outs[S], outs[0]).max() < 4.0
+
+
 def test_worker_decode_step_with_speculation_disabled(tiny):
     """num_lookahead_slots == 0 on a decode batch (or speculative_disable_by_batch_size reached): the scorer alone runs,
     W4A16, one token per sequence (spec_decode_worker.py:497-538,666-720).  The token is cross-checked against the
