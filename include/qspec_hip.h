@@ -150,7 +150,9 @@ int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* 
  * K is cut into `slices` = qspec_w4a16_linear_partial_slices(M, N, K) slices (0: not needed / not built) and the raw
  * fp32 sums of each slice go to part [slices][M][N].  Whoever consumes them forms h((p_0 + p_1 + ...) * f(ws[n])):
  * qspec_w4a16_linear does it with a finishing launch, the verify pass inside the norm that follows
- * (qspec_add_rms_norm_fp16_partial: hidden_out = x + that, out = LN(hidden_out)); same expression, same bits. */
+ * (qspec_add_rms_norm_fp16_partial: hidden_out = x + that, out = LN(hidden_out)); same expression, same bits.
+ * A shape that also runs unsliced (qspec_w4a16_linear_partial_slices = 0) takes any `slices` in 2..8 that divides K
+ * into lengths the streaming kernel supports (K / slices = 128 * waves * steps). */
 int qspec_w4a16_linear_partial_slices(int M, int N, int K);
 int qspec_w4a16_linear_partial(const qspec_half* x, const int8_t* wq, float* part, int M, int N, int K, int slices,
                                void* stream);
