@@ -98,9 +98,28 @@ __device__ __forceinline__ int step_off(int wave, int u) {
     return UE * NW * 64 + wave * 64;
 }
 
+// SEPI_QKV tiles.  A tile is eight RoPE pairs (i, i + 64) of one head: rows 0..7 = the pairs' first halves, 8..15 = their
+// second halves.  Classic: tile t = pairs 8 (t & 7) .. + 7 of head t >> 3.  LEVELLED (I = L > 0, used where N / 16 tiles
+// are 1.5 per workgroup, e.g. Llama-3-8B's 384 on 256 CUs: half the workgroups streamed two tiles, half one): the
+// (heads * 64) pairs are dealt twelve to a workgroup (measured slower, off by default: see qkv_level_workgroups) -- "tile" v < L = pairs 12 v .. 12 v + 7 (a full tile), "tile" L + v =
+// pairs 12 v + 8 .. 12 v + 11 (a HALF tile: slots j >= 4 repeat slots j - 4, their results are never stored; the wave
+// loads coalesce the repeated rows) -- so every workgroup streams 48 KB instead of 64 or 32.
+struct QkvPair {
+    int head, i;
+    bool valid;
+};
+__device__ __forceinline__ QkvPair qkv_pair(int tb, int j, int L) {   // j = 0..7: pair slot of the tile
+    if (L == 0) return QkvPair{tb >> 3, (tb & 7) * 8 + j, true};
+    const bool half = tb >= L;
+    const int p = 12 * (half ? tb - L : tb) + (half ? 8 + (j & 3) : j);
+    return QkvPair{p >> 6, p & 63, !half || j < 4};
+}
 template <int EPI>
 __device__ __forceinline__ int stile_row(int tb, int r, int I) {
-    if (EPI == SEPI_QKV) return (tb >> 3) * 128 + (r >> 3) * 64 + (tb & 7) * 8 + (r & 7);
+    if (EPI == SEPI_QKV) {
+        const QkvPair q = qkv_pair(tb, r & 7, I);
+        return q.head * 128 + (r >> 3) * 64 + q.i;
+    }
     if (EPI == SEPI_GATEUP) return (r >> 3) * I + tb * 8 + (r & 7);
     return tb * 16 + r;
 }
@@ -1003,7 +1022,7 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
         pre.swn = a.ws[stile_row<EPI>(tile, c, a.I)];
         if (EPI == SEPI_RESID) pre.cf = a.resid_in[(size_t)mc * a.N + tile * 16 + c];   // the residual element
         if (EPI == SEPI_QKV) {
-            const int o = (tile & 7) * 8 + (c & 7);
+            const int o = qkv_pair(tile, c & 7, a.I).i;
             const f16* cs = a.cos_sin_cache + pos_m * 128;
             pre.cf = cs[o];
             pre.sf = cs[64 + o];
@@ -1078,7 +1097,9 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
             return;
         }
         // SEPI_QKV
-        const int head = tile >> 3, o = (tile & 7) * 8 + (c & 7);
+        const QkvPair qp = qkv_pair(tile, c & 7, a.I);
+        if (!qp.valid) return;   // a half tile's repeated slots
+        const int head = qp.head, o = qp.i;
         const int n = head * 128 + (c >> 3) * 64 + o;
         f16 res = hv;
         if (head < a.nq + a.nkv) {
@@ -1720,7 +1741,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
     auto load_pre = [&](Pre& pre, int tile) {
         pre.swn = a.ws[stile_row<EPI>(tile, c, a.I)];
         if (EPI == SEPI_QKV) {
-            const int o = (tile & 7) * 8 + (c & 7);
+            const int o = qkv_pair(tile, c & 7, a.I).i;
             const f16* cs = a.cos_sin_cache + pos_m * 128;
             pre.cf = cs[o];
             pre.sf = cs[64 + o];
@@ -1837,7 +1858,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
             }
             return;
         }
-        const int head = tile >> 3, o = (tile & 7) * 8 + (c & 7);
+        const QkvPair qp = qkv_pair(tile, c & 7, a.I);
+        if (!qp.valid) return;   // a half tile's repeated slots
+        const int head = qp.head, o = qp.i;
         const int n = head * 128 + (c >> 3) * 64 + o;
         f16 res = hv;
         if (head < a.nq + a.nkv) {
@@ -2514,6 +2537,18 @@ int gemm_w4a16_partial_finish(const float* part, const f16* ws, f16* out, int M,
     return 0;
 }
 
+// Levelled QKV tiling (qkv_pair): L = workgroups = pairs / 12, or 0 for the classic 16-row tiles.  Only where the classic
+// tiling is uneven (more tiles than workgroups, not a multiple of them) and the pairs divide by twelve: Llama-3-8B's
+// (32 + 8 + 8) heads x 64 pairs = 3072 = 12 x 256.  OFF by default (QSPEC_QKV_LEVEL=1 switches it on): measured in round 3,
+// bit-identical, but the draft qkv launch takes 7.25-7.38 us against 6.89 and the cycle 7.58-7.65 ms against 7.51-7.54 -- two
+// tile iterations (reduction, barriers, epilogue) in EVERY workgroup cost more than the 16 KB less that the slowest ones stream.
+static int qkv_level_workgroups(int nq, int nkv, int N) {
+    static const int on = getenv("QSPEC_QKV_LEVEL") ? atoi(getenv("QSPEC_QKV_LEVEL")) : 0;
+    const int pairs = (nq + 2 * nkv) * 64, cap = stream_cap(), classic = N / 16;
+    if (!on || pairs % 12 || classic <= cap || classic % cap == 0 || pairs / 12 > cap) return 0;
+    return pairs / 12;
+}
+
 int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                                const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
                                const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st) {
@@ -2522,6 +2557,10 @@ int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f1
     a.x = x; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = qkv; a.M = M; a.N = N; a.K = K;
     a.ntiles = N / 16; a.positions = positions; a.cos_sin_cache = cos_sin_cache; a.key_cache = key_cache;
     a.value_cache = value_cache; a.slot_mapping = slot_mapping; a.nq = nq; a.nkv = nkv;
+    if (const int L = qkv_level_workgroups(nq, nkv, N)) {   // twelve RoPE pairs per workgroup: a full + a half tile
+        a.I = L;
+        a.ntiles = 2 * L;
+    }
     return launch_stream16<SEPI_QKV>(a, st);
 }
 
@@ -2585,6 +2624,12 @@ int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* 
     a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = qkv; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
     a.positions = positions; a.cos_sin_cache = cos_sin_cache; a.key_cache = key_cache; a.value_cache = value_cache;
     a.slot_mapping = slot_mapping; a.nq = nq; a.nkv = nkv;
+    if (!sdma_on<SEPI_QKV>()) {   // (the LDS-DMA forms keep the classic tiles)
+        if (const int L = qkv_level_workgroups(nq, nkv, N)) {
+            a.I = L;
+            a.ntiles = 2 * L;
+        }
+    }
     return launch_stream<SEPI_QKV>(a, x.hidden_in != nullptr, st);
 }
 

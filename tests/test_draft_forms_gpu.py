@@ -264,11 +264,12 @@ def test_batch32_draft_forms_vs_oracle(ops, oracle, M):
         assert np.array_equal(bits(host(out)), bits(oracle.gemm_w4a4(xq, xs, w, wsc)))
 
 
-@pytest.mark.parametrize("switch", ["QSPEC_ENGINE=1", "QSPEC_SDMA=1", "QSPEC_DMA_TILES=2"])
+@pytest.mark.parametrize("switch", ["QSPEC_ENGINE=1", "QSPEC_SDMA=1", "QSPEC_DMA_TILES=2", "QSPEC_QKV_LEVEL=1"])
 def test_lds_dma_forms_are_bit_identical(switch):
     """The three LDS-DMA forms of the draft GEMMs built in round 3 (gemm_stream.hip; all opt-in, see DESIGN.md "Stage A":
     the loader / consumer engine `gemm_w4a4_engine_kernel`, the self-service form `gemm_w4a4_sdma_kernel`, and the loader
-    waves beside the register stream, `DMA` tiles) against the same oracle comparisons as the register forms: the
+    waves beside the register stream, `DMA` tiles; and the levelled qkv tiling -- twelve RoPE pairs per workgroup as a full
+    and a half tile, `qkv_pair`) against the same oracle comparisons as the register forms: the
     launch-form tests of this file re-run in a child process with the switch on (the library reads it once per process)."""
     import os
     import subprocess

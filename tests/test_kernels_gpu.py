@@ -1238,19 +1238,24 @@ def test_attention_partials_long_splits_then_merge_within_1e3(ops, oracle, ctx_l
     assert_close_1e3(host(out), ref)
 
 
-@pytest.mark.parametrize("switch", ["QSPEC_ATTN_FAST=0", "QSPEC_ATTN_NW=8"])
-def test_attention_waves_kernel_dev_forms(switch):
-    """paged_attention_waves_kernel's other forms (attention.hip: the general per-lane table lookup instead of the two
-    wave-uniform entries per slice; eight waves per workgroup, measured slower and off) against the same oracle comparison:
-    the long-splits test re-run in a child process with the switch on (the library reads it once per process)."""
+@pytest.mark.parametrize("switch,kexpr", [("QSPEC_ATTN_FAST=0", "(long_splits_then_merge or reference_fixture_within) and not dev_forms"),
+                                          ("QSPEC_ATTN_NW=8", "(long_splits_then_merge or reference_fixture_within) and not dev_forms"),
+                                          ("QSPEC_QKV_LEVEL=1", "qkv and not dev_forms")],
+                         ids=["attn_fast_0", "attn_nw_8", "qkv_level_1"])   # ids without the -k words: the child must not select THIS test
+def test_attention_waves_kernel_dev_forms(switch, kexpr):
+    """Forms that are built, measured and off against the same oracle comparisons as the
+    defaults, re-run in a child process with the switch on (the library reads it once per process):
+    paged_attention_waves_kernel's general per-lane table lookup instead of the two wave-uniform entries per slice, and its
+    eight-wave form; the levelled qkv tiling (twelve RoPE pairs per workgroup, gemm_stream.hip:qkv_pair) in the W4A16 and
+    W4A4 qkv + RoPE + KV-write launches of this file."""
     import os
     import subprocess
     import sys
     k, v = switch.split("=")
     env = dict(os.environ)
     env[k] = v
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
-                        "long_splits_then_merge or reference_fixture_within"], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", kexpr], env=env,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
 
