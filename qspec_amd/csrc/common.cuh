@@ -207,4 +207,25 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 // pack two int4 values (two's complement) into one byte: lo nibble = even index
 __device__ __forceinline__ uint32_t pack_nib(int q0, int q1) { return (uint32_t)(q0 & 0xF) | ((uint32_t)(q1 & 0xF) << 4); }
 
+
+// ---- W4A16 dequantiser: 8 signed int4 of one packed dword -> 8 fp16, k order 0,4,1,5,2,6,3,7 (pairs (0,4) (1,5) (2,6) (3,7)).
+// Offset-binary nibble u = n ^ 8 spliced under the exponent of 1024.0 (0x6400 | u = 1024 + u) or of 64.0 after the x 1/16
+// (0x6400 | u << 4); the sign flip, the nibble mask and the exponent splice are ONE v_bitop3_b32 each: per bit the result is
+// p, ~p, 0 or 1, chosen by two constant words (A: the bit comes from p; B: invert it / the constant bit).  9 VALU per
+// dword instead of the 14 the xor / and / or form compiled to -- the verify pass's streaming GEMMs issue VALU 35-49 % of
+// their wave cycles (scripts/pmc_cycle_sq.sh), most of it this function.
+__device__ __forceinline__ f16x8 dequant_s4x8_bitop(u32 p) {
+    constexpr u32 A0 = 0x000F000Fu, B0 = 0x64086408u, A1 = 0x00F000F0u, B1 = 0x64806480u;
+    constexpr int TT = 0x6A;   // (A & ~B & p) | (A & B & ~p) | (~A & B) with src0 = p, src1 = A, src2 = B
+    const u32 q = p >> 8;
+    const u32 r0 = __builtin_amdgcn_bitop3_b32(p, A0, B0, TT), r1 = __builtin_amdgcn_bitop3_b32(p, A1, B1, TT);
+    const u32 r2 = __builtin_amdgcn_bitop3_b32(q, A0, B0, TT), r3 = __builtin_amdgcn_bitop3_b32(q, A1, B1, TT);
+    const f16x2 c1032 = {(f16)1032.0f, (f16)1032.0f}, c16 = {(f16)0.0625f, (f16)0.0625f}, c72 = {(f16)72.0f, (f16)72.0f};
+    const f16x2 h0 = __builtin_bit_cast(f16x2, r0) - c1032;
+    const f16x2 h1 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, r1), c16, -c72);
+    const f16x2 h2 = __builtin_bit_cast(f16x2, r2) - c1032;
+    const f16x2 h3 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, r3), c16, -c72);
+    return f16x8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+}
+
 }  // namespace qspec

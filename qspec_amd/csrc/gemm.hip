@@ -260,22 +260,7 @@ int gemm_w4a4_gate_up_silu(const int8_t* xq, const f16* xs, const int8_t* wq, co
 //   same on p >> 8                 -> (w2, w6), (w3, w7)
 // so one B fragment (8 fp16) holds k-order 0,4,1,5,2,6,3,7 of its dword; the
 // activation fragment is shuffled into the same order with 4 v_perm_b32.
-__device__ __forceinline__ f16x8 dequant_s4x8(u32 p) {
-    p ^= 0x88888888u;
-    const u32 q = p >> 8;
-    u32 r0 = (p & 0x000F000Fu) | 0x64006400u;
-    u32 r1 = (p & 0x00F000F0u) | 0x64006400u;
-    u32 r2 = (q & 0x000F000Fu) | 0x64006400u;
-    u32 r3 = (q & 0x00F000F0u) | 0x64006400u;
-    const f16x2 c1032 = {(f16)1032.0f, (f16)1032.0f};
-    const f16x2 c16 = {(f16)0.0625f, (f16)0.0625f};
-    const f16x2 c72 = {(f16)72.0f, (f16)72.0f};
-    f16x2 h0 = __builtin_bit_cast(f16x2, r0) - c1032;
-    f16x2 h1 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, r1), c16, -c72);
-    f16x2 h2 = __builtin_bit_cast(f16x2, r2) - c1032;
-    f16x2 h3 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, r3), c16, -c72);
-    return f16x8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
-}
+__device__ __forceinline__ f16x8 dequant_s4x8(u32 p) { return dequant_s4x8_bitop(p); }   // common.cuh (k order 0,4,1,5,2,6,3,7)
 // 8 consecutive fp16 (4 dwords) -> order 0,4,1,5,2,6,3,7
 __device__ __forceinline__ f16x8 shuffle_act8(u32x4 a) {
     u32x4 o;

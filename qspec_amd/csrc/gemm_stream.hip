@@ -1690,18 +1690,7 @@ static bool sdma_on() {
 // (M <= 16 rows x its K slice, 16 * UB registers per lane) are loaded ONCE, pre-shuffled into the nibble order of
 // the dequantiser, and stay in registers for the whole kernel: no LDS tile, no per-step activation traffic (a
 // 16-row weight tile alone would need 4x its own bytes in activations per step).
-__device__ __forceinline__ f16x8 sdequant_s4x8(u32 p) {   // = gemm.hip:dequant_s4x8
-    p ^= 0x88888888u;
-    const u32 q = p >> 8;
-    const u32 r0 = (p & 0x000F000Fu) | 0x64006400u, r1 = (p & 0x00F000F0u) | 0x64006400u;
-    const u32 r2 = (q & 0x000F000Fu) | 0x64006400u, r3 = (q & 0x00F000F0u) | 0x64006400u;
-    const f16x2 c1032 = {(f16)1032.0f, (f16)1032.0f}, c16 = {(f16)0.0625f, (f16)0.0625f}, c72 = {(f16)72.0f, (f16)72.0f};
-    const f16x2 h0 = __builtin_bit_cast(f16x2, r0) - c1032;
-    const f16x2 h1 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, r1), c16, -c72);
-    const f16x2 h2 = __builtin_bit_cast(f16x2, r2) - c1032;
-    const f16x2 h3 = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, r3), c16, -c72);
-    return f16x8{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
-}
+__device__ __forceinline__ f16x8 sdequant_s4x8(u32 p) { return dequant_s4x8_bitop(p); }   // common.cuh (k order 0,4,1,5,2,6,3,7)
 __device__ __forceinline__ f16x8 sshuffle_act8(u32x4 a) {  // 8 consecutive fp16 -> order 0,4,1,5,2,6,3,7
     u32x4 o;
     o[0] = __builtin_amdgcn_perm(a[2], a[0], 0x05040100u);
