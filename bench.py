@@ -260,16 +260,21 @@ def measure_verify_plans(model, eng, world, reps=10):
         model.tp.shard_layers = plan
         fwd()
         torch.cuda.synchronize()
-        fn, mode = fwd, "eager"
+        fn, mode, g = fwd, "eager", None
         try:
             gc.collect()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fwd()
-            g.replay()
-            fn, mode = g.replay, "graph"
         except Exception:
             torch.cuda.synchronize()
+            g = None
+        # graph or eager must be ONE decision of all ranks (a capture records collectives, it issues none): a rank that
+        # replays while another runs eagerly would issue mismatched collectives and hang the job
+        from qspec_amd.parallel import agree_all
+        if agree_all(model.tp, g is not None, eng.device):
+            g.replay()
+            fn, mode = g.replay, "graph"
         barrier(world)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()

@@ -15,7 +15,7 @@
 //     2. store the slice into slot[parity][rank] of EVERY peer (16-byte stores over xGMI; the own copy stays local),
 //        system-scope release, then flag[parity][rank][w] = tag on every peer
 //     3. wait until the local flag[parity][p][w] == tag for every peer p   (bounded: a lost peer raises the error
-//        word instead of hanging the GPU)
+//        word instead of hanging the GPU; a raised word ends every later wait at once)
 //     4. sum the world slices in RANK ORDER in fp32 -> out: every rank computes the same bits, run after run
 //     5. gen[w] = tag
 //   Slots are double buffered by the parity of the tag: a peer can be at most one call ahead (it needs this rank's
@@ -79,12 +79,21 @@ __global__ __launch_bounds__(256) void oneshot_all_reduce_f32_kernel(ArPeers pee
     // 3. wait for every peer's slice
     if (tid < world && tid != rank) {
         const uint32_t* f = reinterpret_cast<const uint32_t*>(local + ar_flags_off()) + ((size_t)par * QS_AR_MAX_WORLD + tid) * QS_AR_GRID + w;
+        // The sticky error word short-circuits the wait: once ONE wait of this rank has timed out (or the host has raised
+        // the word), every later all-reduce of the captured cycle returns at once with an invalid sum -- only the first
+        // collective pays the bound, not 2 per layer x 32-80 layers x 20 s of a busy-spinning GPU.  The cycle's result is
+        // discarded anyway: the word reaches the host with the tokens and the worker re-runs or raises.
+        const uint32_t* errw = reinterpret_cast<const uint32_t*>(local);
+        bool dead = __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
         int guard = 0;
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+        while (!dead && __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
             __builtin_amdgcn_s_sleep(8);
+            ++guard;
+            if ((guard & 1023) == 0 && __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+                dead = true;   // another workgroup's (or an earlier call's) wait has already given up on the peer
             // ~20 s: a peer that is merely LATE (a long host step, a collector pause) is not a dead one -- vllm's custom
             // all-reduce waits without a bound; the bound here only keeps a lost peer from hanging the GPU for good
-            if (++guard > (1 << 25)) {
+            if (guard > (1 << 25)) {
                 __hip_atomic_store(reinterpret_cast<uint32_t*>(local), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }

@@ -341,7 +341,9 @@ def measure_collective_us(tp: "TensorParallel", T: int, H: int, I: int, device, 
 
     body()
     mode, fn = "eager", body
-    if dev.type == "cuda" and not tp.backend.endswith("gloo") and tp.backend != "threads":
+    on_gpu = dev.type == "cuda" and not tp.backend.endswith("gloo") and tp.backend != "threads"
+    if on_gpu:
+        g = None
         try:   # the cycle replays its collectives from a hipGraph: measure them the same way
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -352,23 +354,35 @@ def measure_collective_us(tp: "TensorParallel", T: int, H: int, I: int, device, 
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 body()
-            g.replay()
-            mode, fn = "graph", g.replay
         except Exception:
             torch.cuda.synchronize(dev)
-            mode, fn = "eager", body
+            g = None
+        # The mode decides how many collectives a rank issues from here on: it must be the SAME on every rank, or the
+        # ranks deadlock on mismatched collectives.  A capture records, it does not execute -- so nothing has been
+        # issued yet; agree first (MIN over the ranks of "my capture worked"), replay only if everybody can.
+        if agree_all(tp, g is not None, dev):
+            g.replay()
+            mode, fn = "graph", g.replay
     per3 = timed(fn, iters)
-    ar = timed((lambda: tp.all_reduce(part)), iters) if mode == "eager" else None
-    t = torch.tensor([per3, ar if ar is not None else 0.0], dtype=torch.float64,
-                     device=dev if dev.type == "cuda" and not tp.backend.endswith("gloo") and tp.backend != "threads" else "cpu")
+    ar = timed((lambda: tp.all_reduce(part)), iters)     # on every rank, in every mode: one sequence of collectives
+    t = torch.tensor([per3, ar], dtype=torch.float64, device=dev if on_gpu else "cpu")
     if tp.backend != "threads" and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=tp.group)
     per3 = float(t[0])
     out = {"three_collectives_per_layer_us": round(per3, 2), "per_collective_us": round(per3 / 3.0, 2), "mode": mode,
            "backend": tp.backend, "all_reduce_f32_shape": [T, H], "all_gather_f16_shape": [T, I // tp.world]}
-    if ar is not None:
-        out["all_reduce_alone_us"] = round(float(t[1]), 2)
+    out["all_reduce_alone_us"] = round(float(t[1]), 2)
     return out
+
+
+def agree_all(tp, ok: bool, dev) -> bool:
+    """True iff `ok` holds on EVERY rank of tp's group (one small MIN all-reduce; ThreadComm / single rank: local)."""
+    if tp.backend == "threads" or not dist.is_initialized() or tp.world <= 1:
+        return bool(ok)
+    on_gpu = torch.device(dev).type == "cuda" and not tp.backend.endswith("gloo")
+    f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if on_gpu else "cpu")
+    dist.all_reduce(f, op=dist.ReduceOp.MIN, group=tp.group)
+    return bool(int(f.item()))
 
 
 def shard_layers_pays_measured(layer_weight_bytes: int, world: int, three_collectives_us: float) -> bool:

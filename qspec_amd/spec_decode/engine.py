@@ -267,6 +267,18 @@ class QSpecEngine:
         self.gen_lens[slot] = 0
         self._len_ub[slot] = 0
         self._gen_ub[slot] = 0
+        if self._bt_host[slot] is not None:
+            # the request's blocks go back to the scheduler: the slot must not keep a table (and a capacity) that the
+            # next admission could pass validation against.  Contiguous mode: the slot's own default range again;
+            # brought-table mode (fewer blocks than slots x max_model_len): no table, capacity 0 until one arrives.
+            if self.num_blocks >= self.B * self.blocks_per_seq:
+                lo = slot * self.blocks_per_seq
+                self.block_tables[slot].copy_(torch.arange(lo, lo + self.blocks_per_seq, dtype=torch.int32, device=self.device))
+                self._capacity[slot] = self.blocks_per_seq * self.block_size
+            else:
+                self.block_tables[slot].zero_()
+                self._capacity[slot] = 0
+            self._bt_host[slot] = None
         self.n_active = sum(1 for v in self._len_ub if v > 0)
 
     def set_block_table(self, slot: int, blocks: Sequence[int]) -> None:
@@ -328,10 +340,13 @@ class QSpecEngine:
         return (bt[pos // self.block_size] * self.block_size + pos % self.block_size).contiguous()
 
     # ------------------------------------------------------------------ one speculative cycle (:758-858)
-    def _cycle_body(self):
+    def _snapshot(self):
         # the small sequence state aside: what recover() restarts the cycle from if a device-side hand-off timed out
         ops.spec_snapshot(self.seq_lens, self.gen_lens, self.last_token, self.sampler.counters, self.sampler.rng_state,
                           self._snap_i32, self._snap_i64)
+
+    def _cycle_body(self):
+        self._snapshot()
         self._draft_body()
         self._verify_body()
         self._collect_errors()
@@ -440,9 +455,12 @@ class QSpecEngine:
                 return
         if self._graph is not None:
             self._graph.replay()
-        else:   # the verify pass could not be captured (its collectives): proposer from its graph, scorer eagerly
+        else:   # the verify pass could not be captured (its collectives): proposer from its graph, scorer eagerly.
+            # The same bracket as _cycle_body: the state snapshot sits at the head of the draft graph (_capture), the
+            # error words are collected behind the eager verify pass -- read_outputs() / recover() work in this mode too
             self._graph_draft.replay()
             self._verify_body()
+            self._collect_errors()
 
     def _capture(self):
         # warm up outside capture (lazy module loads, LDS attribute), on a side stream as torch requires.
@@ -471,6 +489,7 @@ class QSpecEngine:
             try:   # the proposer has no collectives (replicated under TP): keep its k forwards in a graph
                 gd = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gd):
+                    self._snapshot()
                     self._draft_body()
                 torch.cuda.synchronize()
                 self._graph_draft = gd

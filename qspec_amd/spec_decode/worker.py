@@ -588,6 +588,7 @@ class SpecDecodeWorker:
         if prompts:
             slots = self._admit([sgml[i] for i in prompts])
             first = self.engine.gen_tokens[:, 0].cpu()
+            self._check_out_of_cycle_errors("the prompt pass")
             for i, slot in zip(prompts, slots):
                 tokens[i] = int(first[slot])
             self.scorer_calls += 1          # one scorer call for the prompt batch, as in the reference
@@ -597,10 +598,18 @@ class SpecDecodeWorker:
                 tokens[i] = tok[slot]
         return [self._serialize_sampler_output_no_logprobs(sgml, tokens)]
 
+    def _check_out_of_cycle_errors(self, what: str) -> None:
+        """Prompt passes and non-speculative steps run outside the captured cycle (other stream, no error-word collection
+        at their end): their launches are followed by a host read anyway, so the sticky words of EVERY hand-off workspace
+        of the device and of the one-shot all-reduce are checked from the host there.  No replay for these: the call fails."""
+        if self.engine.error_flag():
+            raise DeviceHandoffTimeout(f"a device-side hand-off timed out during {what} (results invalid)")
+
     def _no_spec_step(self, dslots: List[int]) -> Dict[int, int]:
         self.engine.step_no_spec(participants=dslots)
         self.scorer_calls += 1
         out = self.engine.out_tokens[:, 0].cpu()
+        self._check_out_of_cycle_errors("a non-speculative decode step")
         self.engine.note_emitted([1 if b in dslots else 0 for b in range(self.max_num_seqs)])
         return {b: int(out[b]) for b in dslots}
 

@@ -19,6 +19,7 @@ What is imported from the reference (by file path; nothing is copied):
   * vllm/model_executor/layers/rotary_embedding.py:47-70,136-150,201-229   RotaryEmbedding._compute_cos_sin_cache,
       forward_native, _apply_rotary_emb -- loaded with a three-line `CustomOp` base (an nn.Module with a `register`
       decorator) and an empty `vllm._custom_ops` (forward_native touches neither)
+  * third-party/QuaRot/quarot/functional/quantization.py   sym_quant / sym_dequant (the a3 / a6 pins, gen_sym_quant_w4a16)
   * tests/kernels/test_cache.py:295-304 (reshape_and_cache_flash's reference loop) and
     vllm/model_executor/layers/sampler.py:278-287 (greedy probs / logprobs / argmax) are a five-line loop and three
     torch calls inside larger functions: restated below with the same torch CPU ops.
@@ -332,6 +333,61 @@ def gen_rope_cache_softmax():
     np.savez_compressed(os.path.join(OUT, "rope_cache_softmax.npz"), **out)
 
 
+def gen_sym_quant_w4a16():
+    """a3 / a6 pins: the reference's OWN Python statements of the row-absmax quantiser and of the W4A16 linear,
+    run here on CPU.
+      * a3: third-party/QuaRot/quarot/nn/quantization.py:10 (the commented form that `fuse_sym_quant` replaced):
+            scales = (max|x| / 7).to(fp16) * clip;  q = quarot.sym_quant(x, scales) = pack_i4(sym_quant(x, scale, 7)[0])
+            -- quarot/functional/quantization.py:29-32 (`x / scale` on fp16 CPU tensors rounds the quotient to fp16,
+            torch.round is ties-to-even, clamp to [-8, 7]) and :42-49 (pack_i4).  Same arithmetic as
+            rowAbsMaxQuantizeKernel (quant.cu:102-167) for every row with a non-zero maximum and a clip ratio that is an
+            fp16 value (the CUDA kernel rounds `clip` to fp16 before the product, Python multiplies by the fp32 scalar; an
+            all-zero row is NaN in Python -- pack_i4's range assert refuses it -- and 0 in the kernel: those two cases stay
+            pinned by the CUDA source alone).
+      * a6: quarot_nn/linear.py:111-119 (commented statement of forward_w4a16): unpack_i4(weight).to(fp16) * scales ->
+            fp16 weight, then the matmul; here with an fp32-accumulate matmul of the fp16 operands (what
+            quarot_nn/qspec_gemm.py:20-88 accumulates in) and with torch's own fp16 CPU matmul."""
+    qz = load_by_path("ref_quantization", f"{REF}/third-party/QuaRot/quarot/functional/quantization.py")
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    maxq = torch.tensor(7)
+    cases = []
+    for idx, (T, K, clip) in enumerate([(6, 256, 1.0), (5, 4096, 1.0), (4, 14336, 1.0), (4, 512, 0.875), (3, 256, 0.5)]):
+        x = (torch.randn(T, K, generator=g) * (0.02 + 3.0 * torch.rand(T, 1, generator=g))).to(torch.float16)
+        if idx == 0:
+            x[0] = 0
+            x[0, :8] = torch.tensor([3.5, 2.5, -2.5, -3.5, 0.5, -0.5, 1.5, 7.0])      # scale 1: exact .5 ties
+            x[1, 0], x[1, 1] = 65504.0, -65504.0                                       # the fp16 ceiling
+            x[2] = (x[2].float() * 1e-4).to(torch.float16)                             # subnormal-range row
+            x[3, 5] = 40.0                                                             # one outlier: everything else -> 0 / +-1
+        scales = (torch.max(torch.abs(x), dim=-1)[0].unsqueeze(1) / 7).to(torch.float16) * clip
+        assert scales.dtype == torch.float16 and (scales > 0).all()
+        q, _ = qz.sym_quant(x, scales, maxq)
+        assert q.dtype == torch.float16
+        packed = qz.pack_i4(q.to(torch.int8))
+        key = f"sq{idx}_"
+        out[key + "x"], out[key + "clip"] = x.numpy(), np.array(clip, np.float32)
+        out[key + "scale"], out[key + "q"] = scales.view(-1).numpy(), packed.numpy().view(np.int8)
+        cases.append((T, K, clip))
+    out["sq_cases"] = np.array(len(cases))
+    for idx, (M, N, K) in enumerate([(1, 64, 128), (4, 96, 4096), (16, 64, 4096), (3, 48, 14336), (16, 32, 13824)]):
+        x = torch.randn(M, K, generator=g).to(torch.float16)
+        wq = torch.randint(-8, 8, (N, K), generator=g, dtype=torch.int8)
+        ws = (torch.rand(N, generator=g) * 0.01 + 0.001).to(torch.float16)
+        packed = qz.pack_i4(wq)                                  # the checkpoint layout (uint8, low nibble = even k)
+        unpacked = qz.unpack_i4(packed)
+        assert torch.equal(unpacked.to(torch.int8), wq)
+        w16 = qz.sym_dequant(unpacked.to(torch.float16), ws.view(-1, 1))      # linear.py:111-119: fp16 weight (one rounding)
+        assert w16.dtype == torch.float16
+        ref32 = (x.float() @ w16.float().t())                    # fp32 accumulate of the fp16 operands
+        ref16 = (x @ w16.t())                                    # torch's fp16 CPU matmul (internal accumulation in fp32)
+        key = f"wa{idx}_"
+        out[key + "x"], out[key + "wq"], out[key + "ws"] = x.numpy(), packed.numpy().view(np.int8), ws.numpy()
+        out[key + "ref_f32"], out[key + "ref_f16"] = ref32.numpy(), ref16.numpy()
+    out["wa_cases"] = np.array(5)
+    np.savez_compressed(os.path.join(OUT, "sym_quant_w4a16.npz"), **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference checkout is only present in the build container"
     gen_pack()
@@ -340,6 +396,7 @@ if __name__ == "__main__":
     gen_rejection()
     gen_attention()
     gen_rope_cache_softmax()
+    gen_sym_quant_w4a16()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

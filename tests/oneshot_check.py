@@ -68,6 +68,28 @@ def main():
         assert all(f == (True, 0) for f in flags), flags
         print("ONESHOT_OK world=%d" % world, flush=True)
     dist.barrier()
+    # A LOST peer: rank 1 stops calling; rank 0's sticky error word is raised (as its first timed-out wait
+    # would) and its next all-reduces must return at once instead of spinning ~20 s each.  Rank 1 keeps its buffer mapped.
+    if rank == 0:
+        import ctypes
+        import time
+        from qspec_amd import ops
+        hip = ctypes.CDLL("libamdhip64.so")
+        one = ctypes.c_uint32(1)
+        assert hip.hipMemcpy(ctypes.c_void_p(comm.error_word_address()), ctypes.byref(one), 4, 1) == 0
+        x = torch.ones(16, 4096, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(6):
+            comm.all_reduce(x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert comm.error() == 1 and dt < 2.0, f"six all-reduces behind a raised error word took {dt:.1f} s"
+        ops.collect_error_words([comm.error_word_address()], clear=True)
+        torch.cuda.synchronize()
+        assert comm.error() == 0
+        print("ONESHOT_DEAD_PEER_OK %.3f s" % dt, flush=True)
+    dist.barrier()
     comm.close()
     dist.destroy_process_group()
 

@@ -954,6 +954,56 @@ def test_cycle_recovery_replay_is_bit_identical(tiny):
     assert runs[0][2:] == runs[1][2:]
 
 
+def test_fallback_mode_reports_and_recovers_errors(tiny):
+    """The draft-graph + eager-verify fallback (taken when the cycle's collectives cannot be captured) carries the same
+    bracket as the captured cycle: the state snapshot at the head of the draft graph, the error words collected behind the
+    eager verify pass.  Forced here by failing the whole-cycle capture once; a poked error word must surface through
+    read_outputs() and the recovery replay must emit what an undisturbed engine emits."""
+    import warnings
+    from qspec_amd import ops
+    from qspec_amd.spec_decode import QSpecEngine
+
+    class FailsWholeCapture(QSpecEngine):
+        fail_once = True
+
+        def _collect_errors(self):
+            if self.fail_once and torch.cuda.is_current_stream_capturing():
+                type(self).fail_once = False
+                raise RuntimeError("forced: this communicator cannot be captured")
+            super()._collect_errors()
+    rng = np.random.default_rng(15)
+    prompts = [rng.integers(0, tiny.config.vocab_size, n).tolist() for n in (12, 25, 7, 40)]
+    runs = []
+    for cls, poke in ((QSpecEngine, False), (FailsWholeCapture, True)):
+        eng = cls(tiny, 3, 4, max_model_len=256, block_size=16, max_new_tokens=64, use_graph=True, seed=12)
+        eng.add_sequences(prompts)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            eng.step()
+        if poke:
+            assert eng._graph is None and eng._graph_draft is not None, "the fallback mode was not taken"
+        out0, err = eng.read_outputs()
+        assert err == 0
+        eng.note_emitted([int((out0[b] != -1).sum()) for b in range(4)])
+        if poke:
+            ops.xwg_workspace(DEV)[:1].fill_(1)
+        eng.step()
+        out, err = eng.read_outputs()
+        assert (err != 0) == poke
+        if poke:
+            eng.recover()
+            out, err = eng.read_outputs()
+            assert err == 0 and eng.recoveries == 1
+        eng.note_emitted([int((out[b] != -1).sum()) for b in range(4)])
+        eng.step()
+        out2, err2 = eng.read_outputs()
+        assert err2 == 0
+        runs.append((out0.clone(), out.clone(), out2.clone(), eng.generated(), eng.metrics()))
+    for a, b in zip(runs[0][:3], runs[1][:3]):
+        assert torch.equal(a, b)
+    assert runs[0][3:] == runs[1][3:]
+
+
 def test_worker_from_vllm_config_loads_a_checkpoint_directory(tiny, tmp_path):
     """create_spec_worker(vllm_config=...) -> init_device loads `model_config.model` (a directory in the reference's
     on-disk format) through qspec_amd/checkpoint.py, and the worker then emits what the in-memory model emits."""

@@ -261,3 +261,44 @@ def test_greedy_softmax_argmax_matches_torch(oracle, golden_dir):
     rel = np.abs(probs[big] - ref[big]) / ref[big]
     assert rel.max() < 1e-5, rel.max()
     assert np.allclose(np.log(np.maximum(probs, 1e-45))[big], g["sm_logprobs"][big], atol=1e-4)
+
+
+# ----------------------------------------------------------------- a3 / a6 pinned to the reference's own Python statements
+
+def test_rowabsmax_quant_matches_reference_sym_quant_bit_exact(oracle, golden_dir):
+    """a3: the oracle's restatement of rowAbsMaxQuantizeKernel (quant.cu:102-167) against the reference's Python statement of
+    the same quantiser -- scales = (max|x| / 7).to(fp16) * clip (quarot/nn/quantization.py:10), sym_quant + pack_i4
+    (quarot/functional/quantization.py:29-49) -- run on CPU by tests/golden/make_golden.py: packed bytes and scales bit for bit."""
+    g = _load(golden_dir, "sym_quant_w4a16.npz")
+    for idx in range(int(g["sq_cases"])):
+        x, clip = g[f"sq{idx}_x"], float(g[f"sq{idx}_clip"])
+        q, scale = oracle.rowabsmax_quant_i4(x, clip)
+        assert np.array_equal(scale.view(np.uint16), g[f"sq{idx}_scale"].view(np.uint16)), idx
+        assert np.array_equal(q.view(np.uint8), g[f"sq{idx}_q"].view(np.uint8)), idx
+
+
+def test_w4a16_against_reference_dequantised_matmul(oracle, golden_dir):
+    """a6: the oracle's W4A16 -- out = h((sum_k x w) * s), fp64 accumulate, ONE rounding -- against the reference's own
+    statement of forward_w4a16: unpack_i4(weight).to(fp16) * scales (an fp16 weight: s * w ROUNDED to fp16, which is also what
+    BitBLAS' with_scaling decode does), then the matmul (quarot_nn/linear.py:111-119; fp32 accumulation as
+    quarot_nn/qspec_gemm.py:20-88), run on CPU by make_golden.py.
+    What the pin shows (and the bars below hold it there): the two statements differ by the fp16 rounding of every s * w --
+    2^-12 relative per weight, ~sqrt(K) 2^-12 of a term on the sum -- i.e. up to 2e-3 of max(1, |out|) at K = 14 k, 0.2-2.5 %
+    of the elements above 1e-3.  Measured against the EXACT value of sum_k x (s w) (fp64, nothing rounded) the oracle's form is
+    the closer one: its only error is the final fp16 rounding.  The product computes the oracle's form."""
+    g = _load(golden_dir, "sym_quant_w4a16.npz")
+    for idx in range(int(g["wa_cases"])):
+        x, wq, ws = g[f"wa{idx}_x"], g[f"wa{idx}_wq"], g[f"wa{idx}_ws"]
+        out = oracle.gemm_w4a16(x, wq, ws).astype(np.float64)
+        w = oracle.unpack_i4(wq).astype(np.float64)
+        exact = x.astype(np.float64) @ (w * ws.astype(np.float64)[:, None]).T
+        den = np.maximum(1.0, np.abs(exact))
+        e_or = np.abs(out - exact) / den
+        assert e_or.max() <= 2.0 ** -11 * 1.01, (idx, e_or.max())                  # the one fp16 rounding, nothing else
+        for name in ("ref_f32", "ref_f16"):
+            ref = g[f"wa{idx}_{name}"].astype(np.float64)
+            r = np.abs(out - ref) / np.maximum(1.0, np.abs(ref))
+            assert (r <= 1e-3).mean() >= 0.97 and r.max() <= 2.5e-3, (idx, name, r.max(), (r > 1e-3).mean())
+            e_ref = np.abs(ref - exact) / den
+            if x.shape[1] >= 4096:   # the reference form's weight rounding shows from K ~ 4 k on
+                assert np.sqrt((e_or ** 2).mean()) <= np.sqrt((e_ref ** 2).mean()) * 1.5, (idx, name)

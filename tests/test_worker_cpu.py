@@ -477,6 +477,47 @@ def test_device_handoff_timeout_replays_once_then_raises():
         w.execute_model(ExecuteModelRequest([decode(a)], num_lookahead_slots=2))
 
 
+def test_out_of_cycle_error_words_fail_prompt_passes_and_no_spec_steps():
+    """Prompt passes and non-speculative steps run outside the captured cycle: the worker checks every hand-off workspace's
+    sticky word from the host behind them (they end in a host read anyway) and fails the call -- no silent invalid tokens."""
+    w = make_worker(k=2)
+    a = prompt("a", 1, 4)
+    w.execute_model(ExecuteModelRequest([a], num_lookahead_slots=0))
+    w.engine.error_flag = lambda: 1
+    with pytest.raises(DeviceHandoffTimeout, match="non-speculative"):
+        w.execute_model(ExecuteModelRequest([decode(a)], num_lookahead_slots=0))
+    with pytest.raises(DeviceHandoffTimeout, match="prompt pass"):
+        w.execute_model(ExecuteModelRequest([prompt("b", 2, 5)], num_lookahead_slots=0))
+
+
+def test_engine_free_slot_forgets_a_brought_block_table():
+    """with fewer KV blocks than max_num_seqs x blocks_per_seq every request brings its table; a finished
+    request's table (and the capacity it gave the slot) must not survive free_slot(), or a later admission WITHOUT a table
+    would pass validation against it and write KV into blocks the scheduler has handed to someone else.  Host-side
+    bookkeeping only: the engine is built on CPU tensors, nothing is launched (validation precedes the first kernel)."""
+    from types import SimpleNamespace
+    from qspec_amd.spec_decode import QSpecEngine
+    cfg = QuarotLlamaConfig(256, 512, 2, 2, 1, 64, 1e-5, 10000.0, 512, "cpu-shell")
+    model = SimpleNamespace(config=cfg, device=torch.device("cpu"), tp=None)
+    eng = QSpecEngine(model, 2, 2, max_model_len=64, block_size=16, max_new_tokens=16, use_graph=False, num_blocks=3)
+    assert eng._capacity == [0, 0]                                   # brought-table mode
+    eng.set_block_table(0, [2, 1])
+    assert eng._capacity[0] == 32 and eng.block_tables[0, :2].tolist() == [2, 1]
+    eng._len_ub[0] = 9                                               # (as an admitted request)
+    eng.free_slot(0)
+    assert eng._capacity[0] == 0 and eng._bt_host[0] is None and eng.block_tables[0].tolist() == [0, 0, 0, 0]
+    with pytest.raises(ValueError, match="no block table|capacity 0"):
+        eng.add_sequence(0, [1, 2, 3])
+    with pytest.raises(ValueError, match="no block table"):
+        eng.add_sequences_to([0, 1], [[1, 2, 3], [4, 5]])
+    # contiguous mode: a slot that was given a table goes back to its own default range
+    eng = QSpecEngine(model, 2, 2, max_model_len=64, block_size=16, max_new_tokens=16, use_graph=False)
+    eng.set_block_table(1, [0, 1])
+    eng._len_ub[1] = 5
+    eng.free_slot(1)
+    assert eng.block_tables[1].tolist() == [4, 5, 6, 7] and eng._capacity[1] == 64 and eng._bt_host[1] is None
+
+
 def test_failed_admission_gives_the_slots_back():
     """If the engine refuses an admission, worker and engine must still agree that the slots are free."""
     w = make_worker()
