@@ -155,8 +155,9 @@ def measure_dominant_kernel(model, engine, reps=5):
                 and ops.rowwise_scaled_linear_s4s4_residual_supported(B, cfg.hidden_size, cfg.intermediate_size))
     gu_out = s.act_buffer_gate_up[:B]
     # o_proj at <= 4 tokens: fp16 head-Hadamard rows + partial row maxima, quantised in the launch's prologue (model.py)
-    hq = (ln_fused and model.HADAMARD_QUANT_IN_OPROJ and model.MERGE_IN_HADAMARD and model.head_had_K == 1
-          and ops.heads_hadamard_merged_spread_supported(B, cfg.num_attention_heads, cfg.head_dim)
+    hq = (ln_fused and model.HADAMARD_QUANT_IN_OPROJ and model.MERGE_IN_HADAMARD
+          and (ops.heads_hadamard_merged_spread_supported(B, cfg.num_attention_heads, cfg.head_dim) if model.head_had_K == 1 else
+               ops.heads_hadamard_mix_merged_spread_supported(B, cfg.num_attention_heads, cfg.head_dim, model.head_had_K))
           and ops.rowwise_scaled_linear_s4s4_residual_hq_supported(B, cfg.hidden_size, cfg.q_size))
 
     def launch(layer, kc, vc, kind):

@@ -328,6 +328,17 @@ int qspec_heads_hadamard_merged_spread(const void* attn_workspace, int max_token
                                        void* stream);
 int qspec_heads_hadamard_merged_spread_supported(int tokens, int heads, int head_dim);
 
+/* The spread form for head counts with a TABLE FACTOR (heads = K * 2^p, hadK [K, K] = get_hadK(heads) of
+ * third-party/QuaRot/quarot/functional/hadamard.py:94-124; Llama-2-13B: 40 heads = had40): split merge + FWHT over 2^p +
+ * h(v * had_scale) + the k-ordered table mix, 8 workgroups per token.  out_f16 [tokens, heads * head_dim]; part_amax
+ * [tokens, 8] or NULL (verify pass: fp16 rows only).  Same bits as qspec_paged_attention(out != NULL) followed by
+ * qspec_heads_hadamard_mix (and, with part_amax, qspec_fuse_sym_quant inside
+ * qspec_rowwise_scaled_linear_s4s4_residual_hq).  head_dim 128. */
+int qspec_heads_hadamard_mix_merged_spread(const void* attn_workspace, int max_tokens, int n_splits, const qspec_half* hadK,
+                                           int K, qspec_half* out_f16, float* part_amax, float had_scale, int tokens,
+                                           int heads, int head_dim, void* stream);
+int qspec_heads_hadamard_mix_merged_spread_supported(int tokens, int heads, int head_dim, int K);
+
 /* ---- token side ------------------------------------------------------------------------------- */
 
 /* nn.Embedding lookup (quarot_llama.py:497). */

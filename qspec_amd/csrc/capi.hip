@@ -44,7 +44,7 @@ static int tiled_min_m() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("QSPEC_TILED_MIN_M");
-        v = e ? atoi(e) : 33;
+        v = e ? atoi(e) : 17;   // (33 until round 4: 17..32 rows ran the 2-D kernel of gemm.hip -- 70B gate_up at 32 rows 83.8 us)
         if (v <= 0) v = 1 << 30;
     }
     return v;
@@ -52,7 +52,7 @@ static int tiled_min_m() {
 
 extern "C" {
 
-int qspec_abi_version(void) { return 4; }
+int qspec_abi_version(void) { return 5; }
 const char* qspec_last_error(void) { return g_err; }
 
 int qspec_rms_norm_general_fuse_sum_i4(int8_t* out_q, const qspec_half* x, qspec_half* input_sum, qspec_half* scaling,
@@ -313,6 +313,22 @@ int qspec_heads_hadamard_merged_spread(const void* attn_workspace, int max_token
         return fail("%s: built for 32 heads of 128 and at most 128 tokens (got %d x %d, %d tokens)", op, heads, head_dim, tokens);
     return finish(op, qspec::heads_hadamard_merge_spread((const float*)attn_workspace, max_tokens, n_splits, H(out_f16),
                                                          part_amax, had_scale, tokens, heads, head_dim, ST));
+}
+int qspec_heads_hadamard_mix_merged_spread_supported(int tokens, int heads, int head_dim, int K) {
+    return qspec::heads_hadamard_mix_merge_spread_supported(tokens, heads, head_dim, K) ? 1 : 0;
+}
+int qspec_heads_hadamard_mix_merged_spread(const void* attn_workspace, int max_tokens, int n_splits, const qspec_half* hadK,
+                                           int K, qspec_half* out_f16, float* part_amax, float had_scale, int tokens,
+                                           int heads, int head_dim, void* stream) {
+    const char* op = "qspec_heads_hadamard_mix_merged_spread";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, attn_workspace); NONNULL(op, hadK); NONNULL(op, out_f16);
+    if (!qspec::heads_hadamard_mix_merge_spread_supported(tokens, heads, head_dim, K))
+        return fail("%s: needs head_dim 128, heads = K * 2^p <= 64 with 2 <= K <= 172, at most 128 tokens (got %d x %d, K = %d, %d tokens)",
+                    op, heads, head_dim, K, tokens);
+    return finish(op, qspec::heads_hadamard_mix_merge_spread((const float*)attn_workspace, max_tokens, n_splits, CH(hadK), H(out_f16),
+                                                             part_amax, had_scale, tokens, heads, head_dim, K, ST));
 }
 int qspec_embedding(const int64_t* ids, const qspec_half* table, qspec_half* out, int tokens, int hidden, int vocab,
                     void* stream) {

@@ -1214,11 +1214,16 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
             }
         }
     } else if (PRO == PRO_RQ) {
-        // thread tid owns the 16-byte chunk tid of every row (K = 4096: 512 chunks per row = the 512 threads)
-        u32x4 xr[4];
+        // thread tid owns the 16-byte chunks tid, tid + 512, ... of every row (K = 4096: 512 chunks per row = the 512
+        // threads; K = 5120: 640 chunks, the first 128 threads take a second one)
+        constexpr int NCH = NI * 128;                          // 16-byte chunks of a row (K = 1024 NI)
+        constexpr int CPT = (NCH + NW * 64 - 1) / (NW * 64);   // chunks per thread
+        u32x4 xr[4][CPT];
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            xr[i] = *reinterpret_cast<const u32x4*>(a.x16 + (size_t)min(i, a.M - 1) * a.K + 8 * tid);
+#pragma unroll
+            for (int cc = 0; cc < CPT; cc++)   // (clamped: no branch around a load; a clamped chunk is never stored)
+                xr[i][cc] = *reinterpret_cast<const u32x4*>(a.x16 + (size_t)min(i, a.M - 1) * a.K + 8 * min(tid + cc * NW * 64, NCH - 1));
         float pv = a.part_amax[min(lane & 31, a.M * 8 - 1)];   // lanes 8 r .. 8 r + 7: the eight partial maxima of row r
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();   // every wave's row requests before any weight request (in-order L1, see PRO_LN)
@@ -1237,24 +1242,26 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const float scf = readlane_f(scfl, 8 * i), rcf = readlane_f(rcfl, 8 * i);
-            const f16x8 x8 = __builtin_bit_cast(f16x8, xr[i]);
-            // rni_sat(h(x / scale), -8, 7) as: clamp, then round to nearest even by adding 1.5 * 2^23 -- the two's
-            // complement integer is the low mantissa bits.  (The quotient of finite values by a non-zero scale is never
-            // NaN; an all-zero row has scale 0, every quotient NaN and the reference's 0 for it: selected per row below.)
-            u32 pk = 0;
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                float dq = h2f(f2h(div3_h(h2f(x8[c]), rcf, scf)));
-                dq = __builtin_amdgcn_fmed3f(dq, -8.0f, 7.0f);
-                float mg = dq + 12582912.0f;
-                asm("" : "+v"(mg));
-                pk |= (__builtin_bit_cast(u32, mg) & 0xFu) << (4 * c);
+            for (int cc = 0; cc < CPT; cc++) {
+                const f16x8 x8 = __builtin_bit_cast(f16x8, xr[i][cc]);
+                // rni_sat(h(x / scale), -8, 7) as: clamp, then round to nearest even by adding 1.5 * 2^23 -- the two's
+                // complement integer is the low mantissa bits.  (The quotient of finite values by a non-zero scale is never
+                // NaN; an all-zero row has scale 0, every quotient NaN and the reference's 0 for it: selected per row below.)
+                u32 pk = 0;
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    float dq = h2f(f2h(div3_h(h2f(x8[c]), rcf, scf)));
+                    dq = __builtin_amdgcn_fmed3f(dq, -8.0f, 7.0f);
+                    float mg = dq + 12582912.0f;
+                    asm("" : "+v"(mg));
+                    pk |= (__builtin_bit_cast(u32, mg) & 0xFu) << (4 * c);
+                }
+                if (scf == 0.0f) pk = 0;   // uniform
+                const int ch = tid + cc * NW * 64;
+                if (i < a.M && (CPT * NW * 64 == NCH || ch < NCH)) *reinterpret_cast<u32*>(xq_lds + (size_t)i * RS + 4 * ch) = pk;
             }
-            if (scf == 0.0f) pk = 0;   // uniform
-            if (i < a.M) {
-                *reinterpret_cast<u32*>(xq_lds + (size_t)i * RS + 4 * tid) = pk;
-                if (tid == 0) xs_lds[i] = scf;
-            }
+            if (i < a.M && tid == 0) xs_lds[i] = scf;
         }
         __syncthreads();   // publishes xq_lds / xs_lds
     } else if (SPLIT) {
@@ -1466,6 +1473,130 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
         g_wgspan[blockIdx.x][1] = t1;
     }
 #endif
+}
+
+// ------------------------------------------------------------------ long rows: several batches per tile
+// K = 28672 (Llama-3-70B's down_proj: 224 steps of 64 bytes per weight row) does not fit the one-batch-per-tile kernel above:
+// 16 waves x 14 steps would hold 112 VGPRs of widened activation fragments per lane against a budget of 128 at 1024 threads.
+// Here a tile is NB batches of NW x UB steps; a wave keeps its activation fragments PACKED (4 VGPRs per step and batch,
+// widened at the use: 8 VALU beside the 2 MFMAs of a step -- this kernel's waves wait for memory 90 % of their cycles) and
+// refills each weight register with the same step of the NEXT batch -- the next tile's first batch behind the last one --
+// right behind its consumer, so UB KiB per wave stay in flight across tile boundaries exactly as above.  (xq, xs) input,
+// M <= 16, plain / residual epilogue; same int32 sums, same epilogue expression, same bits as gemm.hip's kernel.
+template <int EPI, int NW, int UB, int NB>
+__global__ __launch_bounds__(NW * 64) void gemm_w4a4_longk_kernel(StreamArgs a) {
+    static_assert(EPI == SEPI_PLAIN || EPI == SEPI_RESID, "epilogues built so far");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* red = reinterpret_cast<int*>(smem);   // [2][NW][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int Kb = a.K >> 1;
+    const int c = tid & 15, m = tid >> 4;
+    const bool ethread = m < a.M;
+    const int ridx = (m & 3) * 64 + ((m >> 2) & 3) * 16 + c;
+    const int mc = m < a.M ? m : 0;
+    constexpr int BB = UB * NW * 64;           // bytes of a weight row per batch
+    struct Pre {
+        f16 swn, cf;
+    };
+    auto load_pre = [&](Pre& pre, int tile) {
+        pre.swn = a.ws[tile * 16 + c];
+        if (EPI == SEPI_RESID) pre.cf = a.resid_in[(size_t)mc * a.N + tile * 16 + c];
+    };
+    auto wptr = [&](int tile, int b) -> const uint8_t* { return a.wq + (size_t)(tile * 16 + r) * Kb + (size_t)b * BB + g * 16; };
+    u32x4 apk[NB][UB];
+    {
+        const unsigned char* xrow = reinterpret_cast<const unsigned char*>(a.xq) + (size_t)(r < a.M ? r : 0) * Kb + g * 16;
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int u = 0; u < UB; u++) apk[b][u] = *reinterpret_cast<const u32x4*>(xrow + (size_t)b * BB + step_off<NW, UB>(wave, u));
+    }
+    const f16 xsh = a.xs[mc];
+    __builtin_amdgcn_sched_barrier(0);
+    int tile = blockIdx.x, par = 0;
+    const int my_tiles = (a.ntiles - tile + (int)gridDim.x - 1) / (int)gridDim.x;
+    u32x4 w[UB];
+    Pre pre = {};
+    {
+        const uint8_t* wp0 = wptr(tile, 0);
+#pragma unroll
+        for (int u = 0; u < UB; u++) w[u] = wload<u32x4>(wp0 + step_off<NW, UB>(wave, u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_pre(pre, tile);
+    __builtin_amdgcn_sched_barrier(0);
+    const float xs_m = h2f(xsh);
+    i32x4 acc = {0, 0, 0, 0};
+    auto use = [&](const u32x4& wv, const u32x4& av) {
+        u32 p0 = av[0], p1 = av[1], p2 = av[2], p3 = av[3];
+        asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));   // (keeps hipcc from hoisting the loop-invariant widening)
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(widen16(p0, p1), widen16(wv[0], wv[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(widen16(p2, p3), widen16(wv[2], wv[3]), acc, 0, 0, 0);
+    };
+    auto finish = [&](int tile, int par, const Pre& pre) {
+        int* rb = red + par * NW * 256;
+#pragma unroll
+        for (int i = 0; i < 4; i++) rb[wave * 256 + i * 64 + lane] = acc[i];
+        acc = i32x4{0, 0, 0, 0};
+        __syncthreads();
+        if (!ethread) return;
+        int sum = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; w2++) sum += rb[w2 * 256 + ridx];
+        const f16 hv = f2h(((float)(sum >> 8) * xs_m) * h2f(pre.swn));   // both operands carried a factor 16
+        if (EPI == SEPI_PLAIN) a.out[(size_t)m * a.N + tile * 16 + c] = hv;
+        else a.resid_out[(size_t)m * a.N + tile * 16 + c] = f2h(h2f(pre.cf) + h2f(hv));
+    };
+    for (int q = 0; q < my_tiles - 1; q++) {
+        const int nt = tile + (int)gridDim.x;
+        Pre npre;
+        load_pre(npre, nt);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const uint8_t* wp = b + 1 < NB ? wptr(tile, b + 1) : wptr(nt, 0);
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                use(w[u], apk[b][u]);
+                __builtin_amdgcn_sched_barrier(0);   // the refill right behind its consumer (see the kernel above)
+                w[u] = wload<u32x4>(wp + step_off<NW, UB>(wave, u));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        finish(tile, par, pre);
+        par ^= 1;
+        pre = npre;
+        tile = nt;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {   // the last tile: nothing to refill behind its last batch
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            use(w[u], apk[b][u]);
+            if (b + 1 < NB) {
+                __builtin_amdgcn_sched_barrier(0);
+                w[u] = wload<u32x4>(wptr(tile, b + 1) + step_off<NW, UB>(wave, u));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    finish(tile, par, pre);
+}
+
+static int stream_cap();
+static bool longk_shape(int K) { return K == 28672; }   // 224 steps = 16 waves x 7 steps x 2 batches
+template <int EPI>
+static int launch_longk(const StreamArgs& a, hipStream_t st) {
+    if (a.M < 1 || a.M > 16 || !longk_shape(a.K)) return -1;
+    const int cap = stream_cap();
+    int grid = a.ntiles;
+    if (grid > cap) {
+        const int per = (a.ntiles + cap - 1) / cap;
+        grid = (a.ntiles + per - 1) / per;
+    }
+    hipLaunchKernelGGL((gemm_w4a4_longk_kernel<EPI, 16, 7, 2>), dim3(grid), dim3(16 * 64), (size_t)2 * 16 * 1024, st, a);
+    return 0;
 }
 
 // ------------------------------------------------------------------ self-service LDS-DMA form, M <= 4, K = 4096
@@ -2269,7 +2400,10 @@ struct StreamShape {
 static bool stream_shape(int K, StreamShape* sh) {
     const int nsteps = K / 128;
     if (K % 128) return false;
-    static const StreamShape cand[] = {{8, 4, 0}, {16, 7, 0}, {8, 8, 0}, {8, 5, 0}, {4, 4, 0}, {4, 2, 0}, {4, 7, 0}};
+    // K / 128 = 32 (4096), 112 (14336), 64 (8192), 40 (5120), 16 (2048), 8 (1024), 28 (3584), 108 (13824: Llama-2-13B's
+    // down_proj), 44 (5632: TinyLlama's)
+    static const StreamShape cand[] = {{8, 4, 0}, {16, 7, 0}, {8, 8, 0}, {8, 5, 0}, {4, 4, 0}, {4, 2, 0}, {4, 7, 0}, {12, 9, 0},
+                                       {4, 11, 0}};
     // one batch per tile (the activation fragments of a wave's K slice live in registers)
     for (const StreamShape& c : cand) {
         if (nsteps != c.NW * c.UB) continue;
@@ -2347,6 +2481,7 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
         if (sh.NW == 16 && sh.UB == 7) return launch_stream_inst<EPI, PRO_Q, 16, 7, 0, 2>(a, st);
         if (sh.NW == 8 && sh.UB == 8) return launch_stream_inst<EPI, PRO_Q, 8, 8, 0, 2>(a, st);
         if (sh.NW == 8 && sh.UB == 5) return launch_stream_inst<EPI, PRO_Q, 8, 5, 0, 2>(a, st);
+        if (sh.NW == 12 && sh.UB == 9) return launch_stream_inst<EPI, PRO_Q, 12, 9, 0, 2>(a, st);
         return -1;
     }
     if (!ln) {
@@ -2359,6 +2494,8 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
         if (sh.NW == 4 && sh.UB == 4) return launch_stream_inst<EPI, PRO_Q, 4, 4, 0>(a, st);
         if (sh.NW == 4 && sh.UB == 2) return launch_stream_inst<EPI, PRO_Q, 4, 2, 0>(a, st);
         if (sh.NW == 4 && sh.UB == 7) return launch_stream_inst<EPI, PRO_Q, 4, 7, 0>(a, st);
+        if (sh.NW == 12 && sh.UB == 9) return launch_stream_inst<EPI, PRO_Q, 12, 9, 0>(a, st);
+        if (sh.NW == 4 && sh.UB == 11) return launch_stream_inst<EPI, PRO_Q, 4, 11, 0>(a, st);
         return -1;
     }
     // LN prologue: the reference's 1024 virtual threads -> K a multiple of 1024; one batch per tile
@@ -2457,7 +2594,9 @@ static int launch_stream16_inst(const StreamArgs& a, hipStream_t st) {
 static bool stream16_shape(int K, int* NW, int* UB) {
     // (16, 7) = K 14336 is NOT here: 16 rows x 14336 k of fp16 activations (458 KB) do not fit one CU's registers
     // (16 waves x 112 VGPRs would leave nothing else); that layer stays on gemm.hip's 2-D kernel
-    static const int cand[][2] = {{8, 4}, {8, 8}, {8, 5}, {4, 4}, {4, 2}, {8, 7}, {4, 7}, {4, 1}};
+    // (4, 9) = K 4608: a third of Llama-2-13B's down_proj (13824 = 3 x 4608, gemm_w4a16_stream_partial_slices); the
+    // activation staging buffer is 2 x 16 rows x NW x 512 B, so NW stays <= 8 (12 waves x 3 steps would need 222 KB of LDS)
+    static const int cand[][2] = {{8, 4}, {8, 8}, {8, 5}, {4, 4}, {4, 2}, {8, 7}, {4, 7}, {4, 1}, {4, 9}};
     if (K % 128) return false;
     for (const auto& c : cand)
         if (K / 128 == c[0] * c[1]) {
@@ -2478,7 +2617,7 @@ static int launch_stream16(const StreamArgs& a, hipStream_t st) {
     int NW, UB;
     if (a.M < 1 || a.M > 16 || !stream16_shape(a.K, &NW, &UB)) return -1;
 #define QS_S16(NWV, UBV) if (NW == NWV && UB == UBV) return launch_stream16_inst<EPI, NWV, UBV>(a, st);
-    QS_S16(8, 4) QS_S16(8, 8) QS_S16(8, 5) QS_S16(4, 4) QS_S16(4, 2) QS_S16(8, 7) QS_S16(4, 7) QS_S16(4, 1)
+    QS_S16(8, 4) QS_S16(8, 8) QS_S16(8, 5) QS_S16(4, 4) QS_S16(4, 2) QS_S16(8, 7) QS_S16(4, 7) QS_S16(4, 1) QS_S16(4, 9)
 #undef QS_S16
     return -1;
 }
@@ -2564,6 +2703,7 @@ int gemm_w4a16_stream_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws
 
 bool gemm_w4a4_stream_supported(int M, int N, int K, bool ln) {
     StreamShape sh;
+    if (!ln && M >= 1 && M <= 16 && N % 16 == 0 && longk_shape(K)) return true;   // several batches per tile (longk kernel)
     if (M < 1 || M > 32 || N % 16 || K > (1 << 19) || !stream_shape(K, &sh)) return false;
     if (M > 16 && (ln || sh.NW < 8)) return false;   // two token tiles: (xq, xs) input only
     if (ln && !(K == 1024 || K == 2048 || K == 4096 || K == 5120 || K == 8192)) return false;
@@ -2577,6 +2717,7 @@ int gemm_w4a4_stream(const StreamActs& x, const int8_t* wq, const f16* ws, f16* 
     StreamArgs a{};
     a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps; a.sync = x.sync;
     a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = out; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
+    if (longk_shape(K)) return launch_longk<SEPI_PLAIN>(a, st);
     return launch_stream<SEPI_PLAIN>(a, x.hidden_in != nullptr, st);
 }
 
@@ -2588,11 +2729,12 @@ int gemm_w4a4_stream_residual(const StreamActs& x, const int8_t* wq, const f16* 
     a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps; a.sync = x.sync;
     a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
     a.resid_in = resid_in; a.resid_out = resid_out;
+    if (longk_shape(K)) return launch_longk<SEPI_RESID>(a, st);
     return launch_stream<SEPI_RESID>(a, x.hidden_in != nullptr, st);
 }
 
 bool gemm_w4a4_stream_residual_hq_supported(int M, int N, int K, int nparts) {
-    return M >= 1 && M <= 4 && K == 4096 && nparts == 8 && N % 16 == 0 && N > 0;
+    return M >= 1 && M <= 4 && (K == 4096 || K == 5120) && nparts == 8 && N % 16 == 0 && N > 0;
 }
 int gemm_w4a4_stream_residual_hq(const f16* x16, const float* part_amax, int nparts, float clip, const int8_t* wq, const f16* ws,
                                  const f16* resid_in, f16* resid_out, int M, int N, int K, hipStream_t st) {
@@ -2601,6 +2743,7 @@ int gemm_w4a4_stream_residual_hq(const f16* x16, const float* part_amax, int npa
     a.x16 = x16; a.part_amax = part_amax; a.clip = clip;
     a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
     a.resid_in = resid_in; a.resid_out = resid_out;
+    if (K == 5120) return launch_stream_inst<SEPI_RESID, PRO_RQ, 8, 5, 5>(a, st);
     return launch_stream_inst<SEPI_RESID, PRO_RQ, 8, 4, 4>(a, st);
 }
 int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,

@@ -560,6 +560,113 @@ __global__ __launch_bounds__(512) void heads_hadamard_merge_spread32_kernel(cons
     }
 }
 
+// Split merge + head transform for head counts with a TABLE FACTOR (heads = K * P, get_hadK(heads) = hadK; Llama-2-13B: 40
+// heads = had40, P = 1), spread over 8 workgroups per token like the 32-head form above: workgroup (t, y) owns the 16
+// columns [16 y, 16 y + 16) of every head.  Per element the arithmetic of paged_attention(out != NULL) followed by
+// heads_hadamard_mix_kernel (same merge expression, FWHT over p with increasing stride, h(v * scale), then the k-ordered
+// fp32 fma chain over the table), so the same bits -- without the in-kernel split merge of the attention launch (ticket +
+// fences: 6 of its 12 us), without the one-workgroup-per-token transform (17 us for 4 tokens on 4 CUs) and, for the
+// draft pass, without the separate quantiser launch: AMAX leaves max |output| of the workgroup's share in
+// part_amax[t][y] and the row-absmax quantiser runs in the prologue of the o_proj launch (gemm_stream.hip, PRO_RQ).
+// Thread (head = tid / 16, column = tid % 16); LDS: y [heads][16] fp32 + the table as fp32.
+template <bool AMAX>
+__global__ __launch_bounds__(1024) void heads_hadamard_mix_merge_spread_kernel(const float* __restrict__ ws_o,
+                                                                                const float* __restrict__ ws_ml, int S,
+                                                                                const f16* __restrict__ hadK,
+                                                                                f16* __restrict__ out16, float had_scale,
+                                                                                float* __restrict__ part_amax, int heads,
+                                                                                int K) {
+    constexpr int D = 128, SMAX = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* yl = reinterpret_cast<float*>(smem_raw);          // [heads][16]
+    float* had = yl + (size_t)heads * 16;                     // [K][K]
+    float* red = had + (size_t)K * K;                         // [16]
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int head = tid >> 4, col = tid & 15, d = 16 * blockIdx.y + col;
+    const bool act = head < heads;
+    const int hc = act ? head : heads - 1;                    // clamped: every load below is unconditional
+    const size_t th = (size_t)t * heads + hc;
+    const float* ob = ws_o + th * S * D + d;
+    const float* mlb = ws_ml + th * S * 2;
+    float num = 0.0f, den = 0.0f, M = -__builtin_inff();
+    for (int s0 = 0; s0 < S; s0 += SMAX) {   // S <= 8 in one trip: every load in flight before the first use
+        float2 ml[SMAX];
+        float o[SMAX];
+#pragma unroll
+        for (int s2 = 0; s2 < SMAX; s2++) {
+            const int sc = min(s0 + s2, S - 1);
+            ml[s2] = *reinterpret_cast<const float2*>(mlb + sc * 2);
+            o[s2] = ob[(size_t)sc * D];
+        }
+        if (s0 == 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < SMAX; s2++) M = fmaxf(M, s2 < S ? ml[s2].x : -__builtin_inff());
+            for (int s2 = SMAX; s2 < S; s2++) M = fmaxf(M, mlb[s2 * 2]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < SMAX; s2++) {
+            if (s0 + s2 < S) {
+                const float m = ml[s2].x;
+                const float wgt = m == -__builtin_inff() ? 0.0f : aexp(m - M);
+                den = __builtin_fmaf(wgt, ml[s2].y, den);
+                num = __builtin_fmaf(wgt, o[s2], num);
+            }
+        }
+    }
+    for (int i = tid; i < K * K; i += blockDim.x) had[i] = h2f(hadK[i]);
+    float v = h2f(f2h(num / den));                            // the attention output, rounded where flash-attn returns fp16
+    const int P = heads / K;
+    for (int stride = 1; stride < P; stride <<= 1) {          // FWHT over p (head index h = k P + p), increasing stride
+        if (act) yl[head * 16 + col] = v;
+        __syncthreads();
+        const float o = yl[(hc ^ stride) * 16 + col];
+        v = (head & stride) ? (o - v) : (v + o);
+        __syncthreads();
+    }
+    if (act) yl[head * 16 + col] = h2f(f2h(v * had_scale));
+    __syncthreads();
+    const int i = hc / P, pp = hc - i * P;
+    const float* hrow = had + (size_t)i * K;
+    float acc = 0.0f;
+    for (int k = 0; k < K; k++) acc = __builtin_fmaf(hrow[k], yl[(k * P + pp) * 16 + col], acc);   // = heads_hadamard_mix_kernel
+    const f16 y = f2h(acc);
+    if (act) out16[(size_t)t * heads * D + (size_t)head * D + d] = y;
+    if (AMAX) {
+        const float am = wave_max_f(act ? __builtin_fabsf(h2f(y)) : 0.0f);
+        if (lane == 0) red[w] = am;
+        __syncthreads();
+        if (tid == 0) {
+            float m8 = red[0];
+            const int nw = (blockDim.x + 63) >> 6;
+            for (int j = 1; j < nw; j++) m8 = fmaxf(m8, red[j]);
+            part_amax[(size_t)t * 8 + blockIdx.y] = m8;
+        }
+    }
+}
+
+bool heads_hadamard_mix_merge_spread_supported(int T, int heads, int d, int K) {
+    if (d != 128 || K < 2 || K > 172 || heads % K || heads * 16 > 1024 || T < 0 || T * 8 > 1024) return false;
+    const int P = heads / K;
+    return (P & (P - 1)) == 0;
+}
+// fp16 rows + (part_amax != nullptr) 8 partial row maxima per token
+int heads_hadamard_mix_merge_spread(const float* ws, int max_tokens, int n_splits, const f16* hadK, f16* out_f16,
+                                    float* part_amax, float had_scale, int T, int heads, int d, int K, hipStream_t st) {
+    if (T == 0) return 0;
+    if (!heads_hadamard_mix_merge_spread_supported(T, heads, d, K) || n_splits < 1 || T > max_tokens) return -1;
+    const float* ws_o = ws + paged_attention_ws_o_offset();
+    const float* ws_ml = ws + paged_attention_ws_ml_offset(max_tokens, heads, d, n_splits);
+    const int threads = ((heads * 16 + 63) / 64) * 64;
+    const size_t lds = ((size_t)heads * 16 + (size_t)K * K + 16) * sizeof(float);
+    if (part_amax)
+        hipLaunchKernelGGL(heads_hadamard_mix_merge_spread_kernel<true>, dim3(T, 8), dim3(threads), lds, st, ws_o, ws_ml,
+                           n_splits, hadK, out_f16, had_scale, part_amax, heads, K);
+    else
+        hipLaunchKernelGGL(heads_hadamard_mix_merge_spread_kernel<false>, dim3(T, 8), dim3(threads), lds, st, ws_o, ws_ml,
+                           n_splits, hadK, out_f16, had_scale, part_amax, heads, K);
+    return 0;
+}
+
 // partials: the workspace of paged_attention(..., out = nullptr) called for `max_tokens` = n_seqs * max_q_len tokens
 int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out_f16, int8_t* q, f16* scale,
                          float had_scale, float clip, int T, int heads, int d, hipStream_t st) {
@@ -724,7 +831,10 @@ __device__ __forceinline__ float xwg_row_amax(const float* wave_max, int nwaves,
 // NB > 1 (KH > 0, PREACT): NB workgroups per token.  Each repeats the cheap FWHT phase for the whole token and mixes /
 // quantises only its block of P / NB columns of every hadK row (the mix is what bounds the one-workgroup form: 6.3 k
 // cycles of v_pk_fma on ONE CU); the row maximum of the quantiser is exchanged through xwg_row_amax.
-template <int EPL, int KH, bool PREACT, int NB = 1>  // EPL = elements per lane in the FWHT phase = P / 64; KH = K if specialised, else 0
+// PW < EPL * 64 (P = 128 with 16-byte lanes: Llama-2-13B's 13824 = had108 x H128): a wave trip of the FWHT phase covers
+// EPL * 64 / PW rows of P at once -- the lane stages stop below P -- so that the token's row still travels in 1 KiB wave loads,
+// all of them in flight before the first transform (with EPL = P / 64 = 2 a wave took 4-byte lanes and seven dependent trips).
+template <int EPL, int KH, bool PREACT, int NB = 1, int PW = EPL * 64>  // EPL = elements per lane in the FWHT phase; P = PW; KH = K if specialised, else 0
 __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const f16* __restrict__ gate_up,
                                                                             const f16* __restrict__ hadK,
                                                                             f16* __restrict__ out16,
@@ -732,8 +842,10 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
                                                                             f16* __restrict__ scale, float had_scale,
                                                                             float clip, int I, int K, uint32_t* xws) {
     constexpr bool pre_activated = PREACT;   // the input is already g = silu(gate)*up, [T, I] (gate_up GEMM epilogue)
-    constexpr int P = EPL * 64;
+    constexpr int P = PW, CHUNK = EPL * 64;   // row length of the transform; elements per wave trip of phase A
+    static_assert(CHUNK % P == 0 && P >= EPL, "a wave trip covers whole rows");
     constexpr int NT = QS_SMH_THREADS, NW = NT / 64;
+    const int nchk = I / CHUNK;               // (K rows of P = nchk wave trips; the host checks I % CHUNK == 0)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // all LDS in the one dynamic region so every carve stays 16-byte aligned
     float* red = reinterpret_cast<float*>(smem_raw);  // [16]
@@ -761,12 +873,12 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
         for (int tr = 0; tr < 2; tr++)
 #pragma unroll
             for (int b = 0; b < NB8; b++)
-                pre8[tr][b] = *reinterpret_cast<const f16x8*>(up + min(wave + tr * NW, K - 1) * P + lane * EPL + 8 * b);
+                pre8[tr][b] = *reinterpret_cast<const f16x8*>(up + min(wave + tr * NW, nchk - 1) * CHUNK + lane * EPL + 8 * b);
     }
     int trip = 0;
-    for (int c = wave; c < K; c += NW, trip++) {
+    for (int c = wave; c < nchk; c += NW, trip++) {
         float v[EPL];
-        const int e0 = c * P + lane * EPL;
+        const int e0 = c * CHUNK + lane * EPL;
         if (PF && trip < 2) {
 #pragma unroll
             for (int b = 0; b < NB8; b++) {
@@ -818,7 +930,7 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
         }
         // lane-exchange stages: xor 1, 2, 4, 8 as DPP moves (no LDS round trip), 16 and 32 through ds_bpermute
 #define QS_FWHT_STAGE(M, EXCH)                                  \
-        {                                                       \
+        if constexpr (M * EPL < P) {                            \
             const bool hi = lane & M;                           \
             _Pragma("unroll") for (int i = 0; i < EPL; i++) {   \
                 const float o = EXCH;                           \
@@ -838,11 +950,11 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
                 f16x8 o8;
 #pragma unroll
                 for (int i = 0; i < 8; i++) o8[i] = f2h(v[8 * b + i] * had_scale);
-                *reinterpret_cast<f16x8*>(ylds + (size_t)c * P + lane * EPL + 8 * b) = o8;
+                *reinterpret_cast<f16x8*>(ylds + (size_t)c * CHUNK + lane * EPL + 8 * b) = o8;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < EPL; i++) ylds[(size_t)c * P + lane * EPL + i] = f2h(v[i] * had_scale);
+            for (int i = 0; i < EPL; i++) ylds[(size_t)c * CHUNK + lane * EPL + i] = f2h(v[i] * had_scale);
         }
     }
 #ifdef QS_SMH_STAMPS
@@ -907,11 +1019,22 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
             qb[row * PAIRS + jp] = (unsigned char)pack_nib(v0, v1);
         }
         __syncthreads();
-        constexpr int V16 = PAIRS / 16;                        // 16-byte pieces per row block
-        if (tid < KH * V16) {
-            const int r2 = tid / V16, pc = tid % V16;
-            *reinterpret_cast<u32x4*>(q + (size_t)t * (I / 2) + ((size_t)r2 * P + b * CB) / 2 + 16 * pc) =
-                *reinterpret_cast<const u32x4*>(qb + r2 * PAIRS + 16 * pc);
+        if constexpr (PAIRS >= 16) {
+            constexpr int V16 = PAIRS / 16;                    // 16-byte pieces per row block
+            if (tid < KH * V16) {
+                const int r2 = tid / V16, pc = tid % V16;
+                *reinterpret_cast<u32x4*>(q + (size_t)t * (I / 2) + ((size_t)r2 * P + b * CB) / 2 + 16 * pc) =
+                    *reinterpret_cast<const u32x4*>(qb + r2 * PAIRS + 16 * pc);
+            }
+        } else if constexpr (PAIRS == 8) {   // a row block of 16 columns is one 8-byte piece
+            if (tid < KH)
+                *reinterpret_cast<uint64_t*>(q + (size_t)t * (I / 2) + ((size_t)tid * P + b * CB) / 2) =
+                    *reinterpret_cast<const uint64_t*>(qb + tid * PAIRS);
+        } else {
+            static_assert(PAIRS == 4, "a row block of 8 columns is one 4-byte piece");
+            if (tid < KH)
+                *reinterpret_cast<uint32_t*>(q + (size_t)t * (I / 2) + ((size_t)tid * P + b * CB) / 2) =
+                    *reinterpret_cast<const uint32_t*>(qb + tid * PAIRS);
         }
         return;
     }
@@ -1060,8 +1183,13 @@ size_t xwg_workspace_bytes() { return (16 + QS_XWG_MAX_TOKENS) * 4 + (size_t)QS_
 
 // Workgroups per token of the spread form for this shape (1 = the one-workgroup form).
 static int smh_spread(int T, int P, int K, int pre_activated, const void* xws) {
-    if (!xws || !pre_activated || K != 28 || T > QS_XWG_MAX_TOKENS) return 1;
-    const int nb = P == 512 ? 8 : (P == 1024 ? 16 : 1);
+    if (!xws || !pre_activated || T > QS_XWG_MAX_TOKENS) return 1;
+    int nb = 1;
+    if (K == 28) nb = P == 512 ? 8 : (P == 1024 ? 16 : 1);
+    if (K == 108 && P == 128) {            // Llama-2-13B: 13824 = had108 x H128.  The 108-term mix is what bounds a workgroup
+        const int nb108 = 16;   // (measured: 8 workgroups per token 13.16 ms per cycle, 16: 13.06)
+        nb = (nb108 == 8 || T * 16 > 256) ? 8 : 16;
+    }
     return T * nb <= 256 ? nb : 1;     // every workgroup of a token resident: at most one workgroup per CU
 }
 
@@ -1085,6 +1213,17 @@ int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t*
     }
     QS_SMH_SPREAD(8, 8) QS_SMH_SPREAD(16, 16)
 #undef QS_SMH_SPREAD
+#define QS_SMH_108(NBV)                                                                                          \
+    if (nb == NBV && K == 108 && P == 128) {   /* 16-byte lanes, four rows of 128 per wave trip (PW = 128) */       \
+        if (lds > 64 * 1024)                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&silu_mul_hadamard_kernel<8, 108, true, NBV, 128>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+        hipLaunchKernelGGL((silu_mul_hadamard_kernel<8, 108, true, NBV, 128>), dim3(T * NBV), dim3(QS_SMH_THREADS), lds, st, \
+                           gate_up, hadK, out_f16, q, scale, had_scale, clip, I, K, reinterpret_cast<uint32_t*>(xws)); \
+        return 0;                                                                                                \
+    }
+    QS_SMH_108(8) QS_SMH_108(16)
+#undef QS_SMH_108
 #define QS_SMH2(EPLV, KHV)                                                                                      \
     {                                                                                                            \
         if (pre_activated) QS_SMH3(EPLV, KHV, true)                                                              \

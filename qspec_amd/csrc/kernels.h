@@ -77,6 +77,9 @@ int gemm_w4a4_stream_residual(const StreamActs& x, const int8_t* wq, const f16* 
 int gemm_w4a4_stream_residual_hq(const f16* x16, const float* part_amax, int nparts, float clip, const int8_t* wq, const f16* ws,
                                  const f16* resid_in, f16* resid_out, int M, int N, int K, hipStream_t st);
 bool gemm_w4a4_stream_residual_hq_supported(int M, int N, int K, int nparts);
+int heads_hadamard_mix_merge_spread(const float* ws, int max_tokens, int n_splits, const f16* hadK, f16* out_f16,
+                                    float* part_amax, float had_scale, int T, int heads, int d, int K, hipStream_t st);
+bool heads_hadamard_mix_merge_spread_supported(int T, int heads, int d, int K);
 int heads_hadamard_merge_spread(const float* ws, int max_tokens, int n_splits, f16* out_f16, float* part_amax, float had_scale,
                                 int T, int heads, int d, hipStream_t st);
 int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,

@@ -159,6 +159,11 @@ class QuarotLlamaForCausalLM:
 
     # M above which the fused GEMM epilogues (QKV+RoPE+KV write, gate_up+SiLU) give way to plain GEMM + separate kernels
     BIG_M = 64
+    # verify pass: the fused-epilogue W4A16 forms are the 16-row streaming kernels; from 17 rows on the M-tiled kernel
+    # (gemm_tiled.hip) + separate RoPE / SiLU launches is faster than the first-generation 2-D kernel that used to take
+    # 17..64 rows (Llama-3-70B, bs = 8, T = 32: 51.2 -> 47.9 ms per cycle; Llama-3-8B bs = 8: 9.81 -> 9.56).  The
+    # tensor-parallel shard views (K-sliced / channel-sharded streaming forms, T <= 32) keep the fused path.
+    VERIFY_FUSE_MAX_M = int(__import__("os").environ.get("QSPEC_VERIFY_FUSE_MAX_M", "16"))
     # draft pass: LN in the GEMM prologue up to this many tokens (0 = always a separate LN launch; bit-identical).
     # Measured in the engine (round 2): bs = 4 fused 8.39 vs separate 8.43 ms per cycle; bs = 16 fused (hand-off form)
     # 14.30 vs separate 13.38 ms -- the standalone norm launch (3.4 us) beats the hand-off from 8 tokens on.
@@ -191,11 +196,18 @@ class QuarotLlamaForCausalLM:
         B = md.ctx_lens.numel()
         merged = (self.MERGE_IN_HADAMARD and cfg.head_dim == 128 and nh in (32, 64) and md.n_splits <= 64
                   and self.head_had_K == 1)
+        # head count with a table factor (40 heads = had40): the split merge + transform spread over 8 workgroups per token
+        mix_merged = (self.MERGE_IN_HADAMARD and self.head_had_K > 1 and md.n_splits <= 64
+                      and ops.heads_hadamard_mix_merged_spread_supported(T, nh, cfg.head_dim, self.head_had_K))
         ops.paged_attention(qkv, row, kc, vc, md.block_tables, md.ctx_lens, md.q_start, T, md.max_q_len, nh,
-                            self.sm_scale, md.n_splits, s.attn_ws, None if merged else attn)
-        if self.head_had_K > 1:   # head count with a table factor (40 heads = had40): generic kernels, then the Quantizer
+                            self.sm_scale, md.n_splits, s.attn_ws, None if (merged or mix_merged) else attn)
+        if self.head_had_K > 1:
             buf = had if had is not None else s.act_buffer_had[:T]
-            ops.heads_hadamard_mix(attn.view(T, nh, cfg.head_dim), self.head_had, self.head_had_K, self.head_had_scale, buf)
+            if mix_merged:
+                ops.heads_hadamard_mix_merged_spread(s.attn_ws, B * md.max_q_len, md.n_splits, T, nh, cfg.head_dim, self.head_had,
+                                                     self.head_had_K, self.head_had_scale, buf)
+            else:   # generic kernels: one workgroup per token
+                ops.heads_hadamard_mix(attn.view(T, nh, cfg.head_dim), self.head_had, self.head_had_K, self.head_had_scale, buf)
             if q1 is not None:
                 ops.fuse_sym_quant(buf, sc, q1)
         elif merged:
@@ -224,10 +236,11 @@ class QuarotLlamaForCausalLM:
         q1, q3, sc = s.quantized_buffer_qkv[:T], s.quantized_buffer_mlp[:T], s.scale_buffer[:T]
         normed, had, had_mlp = s.normed[:T], s.act_buffer_had[:T], s.act_buffer_had_mlp[:T]
         row = cfg.q_size + 2 * cfg.kv_size
-        fuse = cfg.head_dim == 128 and (w4a4 or T <= self.BIG_M)   # fused GEMM epilogues (decode-sized M)
+        tp_sharded = self.tp is not None and self.tp.world > 1 and getattr(self.tp, "shard_layers", True) and not w4a4
+        # fused GEMM epilogues (decode-sized M)
+        fuse = cfg.head_dim == 128 and (w4a4 or T <= (min(self.BIG_M, 32) if tp_sharded else self.VERIFY_FUSE_MAX_M))
         # tensor parallelism only on the verify pass at decode-sized M; the draft pass and prefill run replicated
-        tp_on = (self.tp is not None and self.tp.world > 1 and getattr(self.tp, "shard_layers", True) and not w4a4
-                 and fuse and T <= 32)
+        tp_on = tp_sharded and fuse and T <= 32
         act = s.act_buffer_had_mlp[:T]                            # silu(gate)*up, [T, I]
         nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         # draft pass at decode-sized M: residual add + LN + int4 quant run in the prologue of the qkv / gate_up GEMM
@@ -237,8 +250,9 @@ class QuarotLlamaForCausalLM:
                     and ops.ln_linear_s4s4_supported(T, 2 * cfg.intermediate_size, cfg.hidden_size)
                     and ops.rowwise_scaled_linear_s4s4_residual_supported(T, cfg.hidden_size, cfg.hidden_size)
                     and ops.rowwise_scaled_linear_s4s4_residual_supported(T, cfg.hidden_size, cfg.intermediate_size))
-        hq = (ln_fused and self.HADAMARD_QUANT_IN_OPROJ and self.MERGE_IN_HADAMARD and self.head_had_K == 1
-              and md.n_splits <= 64 and ops.heads_hadamard_merged_spread_supported(T, nh, hd)
+        hq = (ln_fused and self.HADAMARD_QUANT_IN_OPROJ and self.MERGE_IN_HADAMARD and md.n_splits <= 64
+              and (ops.heads_hadamard_merged_spread_supported(T, nh, hd) if self.head_had_K == 1 else
+                   ops.heads_hadamard_mix_merged_spread_supported(T, nh, hd, self.head_had_K))
               and ops.rowwise_scaled_linear_s4s4_residual_hq_supported(T, cfg.hidden_size, cfg.q_size))
         had16 = s.act_buffer_had[:T]
         for li, layer in enumerate(self.layers):
@@ -255,8 +269,13 @@ class QuarotLlamaForCausalLM:
                     # of :235-238 in the o_proj launch's prologue: same bits as the two calls of the else branch
                     ops.paged_attention(qkv, row, kc, vc, md.block_tables, md.ctx_lens, md.q_start, T, md.max_q_len, nh,
                                         self.sm_scale, md.n_splits, s.attn_ws, None)
-                    ops.heads_hadamard_merged_spread(s.attn_ws, md.ctx_lens.numel() * md.max_q_len, md.n_splits, T, nh, hd,
-                                                     self.head_had_scale, had16, s.had_part_amax[:T])
+                    if self.head_had_K == 1:
+                        ops.heads_hadamard_merged_spread(s.attn_ws, md.ctx_lens.numel() * md.max_q_len, md.n_splits, T, nh, hd,
+                                                         self.head_had_scale, had16, s.had_part_amax[:T])
+                    else:   # table-factor head count (Llama-2-13B: had40)
+                        ops.heads_hadamard_mix_merged_spread(s.attn_ws, md.ctx_lens.numel() * md.max_q_len, md.n_splits, T, nh,
+                                                             hd, self.head_had, self.head_had_K, self.head_had_scale, had16,
+                                                             s.had_part_amax[:T])
                     ops.rowwise_scaled_linear_s4s4_residual_hq(had16, s.had_part_amax[:T], 1.0, layer.o_proj.weight,
                                                                layer.o_proj._scales(), hidden, hidden)
                 else:

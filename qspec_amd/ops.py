@@ -500,6 +500,19 @@ def heads_hadamard_merged_spread_supported(tokens: int, heads: int, head_dim: in
     return bool(_lib.load().qspec_heads_hadamard_merged_spread_supported(tokens, heads, head_dim))
 
 
+def heads_hadamard_mix_merged_spread(workspace, max_tokens, n_splits, tokens, heads, head_dim, hadK, K: int, had_scale: float,
+                                     out_f16, part_amax=None):
+    """The spread merge + head transform for head counts with a table factor (40 heads = had40): fp16 rows, and with
+    part_amax [tokens, 8] the partial row maxima for rowwise_scaled_linear_s4s4_residual_hq."""
+    _call("qspec_heads_hadamard_mix_merged_spread", workspace.data_ptr(), max_tokens, n_splits, _chk(hadK, "hadK", _F16), K,
+          _chk(out_f16, "out_f16", _F16), _opt(part_amax, "part_amax", _F32), float(had_scale), tokens, heads, head_dim,
+          _stream())
+
+
+def heads_hadamard_mix_merged_spread_supported(tokens: int, heads: int, head_dim: int, K: int) -> bool:
+    return bool(_lib.load().qspec_heads_hadamard_mix_merged_spread_supported(tokens, heads, head_dim, K))
+
+
 # ------------------------------------------------------------------ token side
 
 def embedding(ids, table, out):

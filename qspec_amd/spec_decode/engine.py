@@ -48,7 +48,13 @@ def n_splits_for(ctx: int, n_groups: int = 0) -> int:
         forced = int(os.environ.get("QSPEC_ATTN_SPLITS", "0"))   # dev knob for sweeps
         if forced > 0:
             return forced
-        return max(1, min(16, (256 + n_groups - 1) // n_groups))
+        n = max(1, min(16, (256 + n_groups - 1) // n_groups))
+        if n_groups > 64 and 256 % n_groups:
+            # group counts that do not divide the chip (Llama-2-13B at batch 4: 4 x 40 kv heads = 160): two workgroups are
+            # resident per CU, so fill the 512 slots -- 160 x 3 = 480 workgroups of 171 keys instead of 320 of 256, of which
+            # 64 CUs carried two (cycle 13.49 -> 12.99 ms; 4 splits = 640 workgroups: 13.28)
+            n = max(n, min(16, 512 // n_groups))
+        return n
     return 1
 
 

@@ -194,6 +194,31 @@ def test_mlp_hadamard_spread_70b_width_vs_oracle(ops, oracle, golden_dir):
     assert np.array_equal(host(q), q0) and np.array_equal(bits(host(s)), bits(s0))
 
 
+@pytest.mark.parametrize("M", [1, 4, 16])
+def test_mlp_hadamard_spread_13b_width_vs_oracle(ops, oracle, golden_dir, M):
+    """I = 13824 = had108 x H128 (Llama-2-13B): 8 workgroups per token, 16-byte lanes covering four rows of 128 per wave
+    trip; int4 + scale (draft) and fp16 (verify) against the oracle, repeated launches on the never-reset counters, and the
+    one-workgroup generic form for the same bytes."""
+    rng = np.random.default_rng(43 + M)
+    had = np.load(os.path.join(golden_dir, "hadamard.npz"))["had108"].astype(np.float16)
+    I2 = 13824
+    act = rand_hidden(rng, M, I2, 0.5)
+    sc = oracle.rsqrt_scale(I2)
+    z0 = oracle.mlp_hadamard(act, had, 108, sc)
+    q0, s0 = oracle.rowabsmax_quant_i4(z0, 1.0)
+    for ws in ("auto", None):
+        q = torch.empty(M, I2 // 2, dtype=torch.int8, device=DEV)
+        s = torch.empty(M, dtype=torch.float16, device=DEV)
+        for rep in range(3):
+            q.fill_(0); s.fill_(0)
+            ops.mlp_hadamard(dev(act), dev(had), 108, sc, q=q, scale=s, workspace=ws)
+            assert np.array_equal(host(q), q0) and np.array_equal(bits(host(s)), bits(s0)), (ws, rep)
+        z = torch.empty(M, I2, dtype=torch.float16, device=DEV)
+        ops.mlp_hadamard(dev(act), dev(had), 108, sc, out_f16=z, workspace=ws)
+        assert np.array_equal(bits(host(z)), bits(z0)), ws
+    assert int(ops.xwg_error_word(torch.device(DEV)).abs().max().item()) == 0
+
+
 def test_draft_mlp_block_chain_vs_oracle(ops, oracle, golden_dir):
     """The four MLP-side launches of a draft layer chained on the device exactly as model.py does (no host round trip
     in between), against the oracle chain: post-attention norm -> gate_up -> silu*up -> Hadamard -> quant -> down_proj

@@ -212,7 +212,8 @@ def rand_w4(rng, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 64, 128), (4, 6144, 4096), (4, 4096, 14336), (16, 4096, 4096), (32, 512, 4096),
-                                   (33, 256, 1408), (67, 64, 1408), (192, 128, 4096), (4, 28672, 4096)])
+                                   (33, 256, 1408), (67, 64, 1408), (192, 128, 4096), (4, 28672, 4096),
+                                   (4, 5120, 13824), (16, 512, 13824), (32, 640, 13824), (32, 5120, 13824), (3, 6144, 14336), (1, 2048, 5632), (4, 2048, 5632)])
 def test_w4a4_gemm_bit_exact(ops, oracle, M, N, K):
     rng = np.random.default_rng(M * 7 + N + K)
     xq = oracle.pack_i4(rand_w4(rng, M, K))
@@ -480,7 +481,8 @@ def test_ln_prologue_full_layer_shapes_with_lds_prefetch(ops, oracle, M, monkeyp
     assert torch.equal(act.view(torch.int16), act_ref.view(torch.int16))
 
 
-@pytest.mark.parametrize("M,N,K", [(4, 4096, 4096), (4, 4096, 14336), (16, 1024, 2048), (3, 512, 1024)])
+@pytest.mark.parametrize("M,N,K", [(4, 4096, 4096), (4, 4096, 14336), (16, 1024, 2048), (3, 512, 1024), (4, 5120, 13824),
+                                   (4, 5120, 5120), (1, 2048, 5632), (8, 8192, 28672), (3, 512, 28672)])
 def test_s4s4_residual_epilogue_equals_linear_then_add(ops, oracle, M, N, K):
     """hidden = residual + proj_out in the GEMM epilogue == the GEMM entry followed by an fp16 tensor add; also in
     place (resid_out aliasing resid_in), and the delta-less norm prologue == the plain LN kernel + GEMM."""
@@ -761,6 +763,103 @@ def test_spread_head_hadamard_and_quantiser_in_the_o_proj_prologue(ops, oracle, 
     assert np.array_equal(bits(host(h1)), bits(ref))
 
 
+def _attn_partials_ws(ops, T, heads, d, S, o, m, l):
+    """A paged_attention workspace holding the given per-split partials: [ticket counters | o [T, heads, S, d] | (m, l)
+    [T, heads, S, 2]] fp32 (attention.hip: paged_attention, out = NULL)."""
+    total = ops.paged_attention_workspace_bytes(T, heads, d, S) // 4
+    cnt = total - T * heads * S * (d + 2)
+    ws = torch.zeros(total, dtype=torch.float32, device=DEV)
+    ws[cnt:cnt + T * heads * S * d] = dev(np.ascontiguousarray(o, np.float32)).view(-1)
+    ml = np.stack([m, l], axis=-1).astype(np.float32)
+    ws[cnt + T * heads * S * d:] = dev(ml).view(-1)
+    return ws.view(torch.uint8)
+
+
+@pytest.mark.parametrize("T,heads", [(4, 40), (1, 40), (3, 24), (16, 40), (2, 48)])
+def test_spread_table_factor_head_transform_bit_exact_on_given_partials(ops, oracle, T, heads):
+    """Head counts with a table factor (Llama-2-13B: 40 heads = had40; 24 = had12 x 2; 48 = had12 x 4): the spread merge +
+    FWHT over 2^p + scale + table mix on GIVEN partials.  One split with (m, l) = (0, 1) makes the merge the identity on fp16
+    values, so the transform is compared bit for bit with heads_hadamard_mix and with the oracle's heads_hadamard; two splits
+    with different maxima are compared with the merge formula in fp64 (the hardware 2^x is ~1 ulp: 1e-3)."""
+    from qspec_amd import hadamard_tables
+    rng = np.random.default_rng(T * 100 + heads)
+    d = 128
+    hadK, K = hadamard_tables.get_hadK(heads)
+    assert K > 1 and ops.heads_hadamard_mix_merged_spread_supported(T, heads, d, K)
+    hk = hadK.to(torch.float16).to(DEV)
+    had_scale = oracle.rsqrt_scale(heads)
+    attn = (rng.standard_normal((T, heads, d)) * 0.5).astype(np.float16)
+    attn[0, :, 5] = 0
+    ws = _attn_partials_ws(ops, T, heads, d, 1, attn.astype(np.float32)[:, :, None, :], np.zeros((T, heads, 1)), np.ones((T, heads, 1)))
+    o0 = torch.empty(T, heads * d, dtype=torch.float16, device=DEV)
+    ops.heads_hadamard_mix(dev(attn), hk, K, had_scale, o0)
+    o1 = torch.empty_like(o0); o2 = torch.empty_like(o0)
+    pam = torch.full((T, 8), -1.0, dtype=torch.float32, device=DEV)
+    ops.heads_hadamard_mix_merged_spread(ws, T, 1, T, heads, d, hk, K, had_scale, o1)
+    ops.heads_hadamard_mix_merged_spread(ws, T, 1, T, heads, d, hk, K, had_scale, o2, pam)
+    torch.cuda.synchronize()
+    assert torch.equal(o0.view(torch.int16), o1.view(torch.int16)) and torch.equal(o0.view(torch.int16), o2.view(torch.int16))
+    assert np.array_equal(host(pam).max(axis=1), np.abs(host(o1).astype(np.float32)).max(axis=1))
+    ref = oracle.heads_hadamard(attn.reshape(T, heads * d), heads, had_scale, hadK.numpy().astype(np.float16), K)
+    assert np.array_equal(bits(host(o1)), bits(ref))
+    # two splits: out = sum_s e^(m_s - M) o_s / sum_s e^(m_s - M) l_s
+    o = rng.standard_normal((T, heads, 2, d)) * 2.0
+    m = rng.standard_normal((T, heads, 2)) * 3.0
+    l = rng.random((T, heads, 2)) * 5.0 + 0.5
+    m[0, 0, 1] = -np.inf                        # an empty split (a sequence shorter than the split's first key)
+    o[0, 0, 1], l[0, 0, 1] = 0.0, 0.0
+    ws2 = _attn_partials_ws(ops, T, heads, d, 2, o, m, l)
+    wgt = np.exp(m - m.max(axis=2, keepdims=True))
+    merged = ((wgt[..., None] * o).sum(axis=2) / (wgt * l).sum(axis=2)[..., None]).astype(np.float16)
+    ref2 = oracle.heads_hadamard(merged.reshape(T, heads * d), heads, had_scale, hadK.numpy().astype(np.float16), K)
+    ops.heads_hadamard_mix_merged_spread(ws2, T, 2, T, heads, d, hk, K, had_scale, o1)
+    assert np.abs(host(o1).astype(np.float64) - ref2.astype(np.float64)).max() <= 2e-3 * max(1.0, np.abs(ref2).max())
+    if T <= 4 and ops.rowwise_scaled_linear_s4s4_residual_hq_supported(T, 256, heads * d):   # K = 5120: PRO_RQ, two chunks per thread
+        Kd, N = heads * d, 1024
+        wq, wsc = rng.integers(-128, 128, (N, Kd // 2)).astype(np.int8), (rng.random(N) * 0.01 + 0.001).astype(np.float16)
+        resid = (rng.standard_normal((T, N))).astype(np.float16)
+        q0 = torch.empty(T, Kd // 2, dtype=torch.int8, device=DEV); s0 = torch.empty(T, dtype=torch.float16, device=DEV)
+        ops.fuse_sym_quant(o0, s0, q0)
+        h0 = dev(resid)
+        ops.rowwise_scaled_linear_s4s4_residual(q0, s0, dev(wq), dev(wsc), h0, h0)
+        h1 = dev(resid)
+        ops.rowwise_scaled_linear_s4s4_residual_hq(o2, pam, 1.0, dev(wq), dev(wsc), h1, h1)
+        torch.cuda.synchronize()
+        assert torch.equal(h0.view(torch.int16), h1.view(torch.int16))
+        qo, so = oracle.rowabsmax_quant_i4(host(o2), 1.0)
+        assert np.array_equal(bits(host(h1)), bits(oracle.add_f16(resid, oracle.gemm_w4a4(qo, so, wq, wsc))))
+
+
+@pytest.mark.parametrize("ctx_lens,q_len,n_splits,heads,nkv", [([37, 128, 129, 500], 1, 2, 40, 40), ([600, 5, 20], 1, 8, 40, 40),
+                                                                ([37, 130], 2, 2, 40, 40), ([300], 4, 8, 40, 40), ([90, 17], 1, 1, 24, 24)])
+def test_spread_table_factor_head_transform_behind_the_attention_launch(ops, oracle, ctx_lens, q_len, n_splits, heads, nkv):
+    """The same kernel behind a real attention launch that leaves its partials (out = NULL), against the oracle's head
+    transform of the in-kernel-merged attention output (out != NULL): 1e-3 -- the two attention launches may be different
+    kernels (per-wave form for partials: another summation order inside a split, include/qspec_hip.h)."""
+    from qspec_amd import hadamard_tables
+    rng = np.random.default_rng(sum(ctx_lens) * 3 + q_len + heads)
+    d, bs = 128, 16
+    n_seqs = len(ctx_lens)
+    bt, kc, vc = make_paged(rng, n_seqs, ctx_lens, nkv, d, bs)
+    T = n_seqs * q_len
+    row = (heads + 2 * nkv) * d
+    qkv = dev((rng.standard_normal((T, row)) * 0.5).astype(np.float16))
+    q_start = dev((np.arange(n_seqs + 1) * q_len).astype(np.int32))
+    ctx = dev(np.array(ctx_lens, np.int32))
+    hadK, K = hadamard_tables.get_hadK(heads)
+    hk = hadK.to(torch.float16).to(DEV)
+    had_scale = oracle.rsqrt_scale(heads)
+    ws = torch.zeros(ops.paged_attention_workspace_bytes(T, heads, d, n_splits), dtype=torch.uint8, device=DEV)
+    attn = torch.empty(T, heads * d, dtype=torch.float16, device=DEV)
+    ops.paged_attention(qkv, row, dev(kc), dev(vc), dev(bt), ctx, q_start, T, q_len, heads, d ** -0.5, n_splits, ws, attn)
+    ws.zero_()
+    ops.paged_attention(qkv, row, dev(kc), dev(vc), dev(bt), ctx, q_start, T, q_len, heads, d ** -0.5, n_splits, ws, None)
+    o1 = torch.empty(T, heads * d, dtype=torch.float16, device=DEV)
+    ops.heads_hadamard_mix_merged_spread(ws, T, n_splits, T, heads, d, hk, K, had_scale, o1)
+    ref = oracle.heads_hadamard(host(attn), heads, had_scale, hadK.numpy().astype(np.float16), K)
+    assert np.abs(host(o1).astype(np.float64) - ref.astype(np.float64)).max() <= 1e-3
+
+
 def test_embedding(ops):
     rng = np.random.default_rng(0)
     V, H = 1000, 4096
@@ -894,7 +993,7 @@ def test_advance_step(ops, oracle):
 
 # ------------------------------------------------------------------ tensor-parallel views
 
-@pytest.mark.parametrize("M,N,K", [(16, 4096, 14336), (5, 4096, 14336), (16, 1024, 14336)])
+@pytest.mark.parametrize("M,N,K", [(16, 4096, 14336), (5, 4096, 14336), (16, 1024, 14336), (16, 5120, 13824), (3, 1024, 13824)])
 def test_w4a16_long_k_slices_and_norm_finish(ops, oracle, M, N, K):
     """Long-K W4A16 (down_proj): K slices -> raw fp32 sums; w4a16_linear finishes them with a small launch, the verify
     pass inside the next norm.  Both against the oracle (1e-3) and against each other (bit for bit)."""
@@ -904,7 +1003,7 @@ def test_w4a16_long_k_slices_and_norm_finish(ops, oracle, M, N, K):
     wq = oracle.pack_i4(w)
     ws = (rng.random(N) * 0.002 + 0.0005).astype(np.float16)
     S = ops.w4a16_linear_partial_slices(M, N, K)
-    assert S == 4      # four slices first: a workgroup stages as many activation bytes as it streams weight bytes
+    assert S == (3 if K == 13824 else 4)   # four slices first: a workgroup stages as many activation bytes as it streams weight bytes
     out = torch.empty(M, N, dtype=torch.float16, device=DEV)
     ops.w4a16_linear(dev(x), dev(wq), dev(ws), out)
     assert_close_1e3(host(out), oracle.gemm_w4a16(x, wq, ws))
