@@ -11,7 +11,10 @@ configs[1]: Llama-3-8B QSpec, k=3, bs=4, synthetic weights and prompts (SURVEY.m
 the timed region (inputs resident in HBM when timing starts).
 
 One JSON line on rank 0.  The hardware quantity is `ms_per_step` (one cycle; identical with the synthetic knob on or
-off).  `value` = emitted tokens per second of the whole job at the SYNTHETIC draft/target agreement named in
+off): the --steps region is timed `--repeats` (3) times back to back and the MEDIAN region is reported, every region listed in
+`ms_per_step_repeats`.  With N = 1 and the default workload the line also carries `other_configs`: the other BASELINE.json
+configs' shapes (k=5 bs=32; Llama-2-13B; Llama-3-70B; TinyLlama) built, timed the same way and freed one after the other on
+this GPU, each with its own `ms_per_step`, `value` and dominant-kernel `roofline`.  `value` = emitted tokens per second of the whole job at the SYNTHETIC draft/target agreement named in
 `config.agreement` (random int4 weights agree ~1-4 %; the reference's trained checkpoint 0.96; SURVEY.md 8d
 sanctions the controlled-agreement mode) -- the same cycles at the weights' own agreement are under `natural_agreement`,
 and `e2e_incl_prefill` is the demo.py:139-160 figure (prompt pass + decode to max_tokens, tokens / wall time).  Plus
@@ -54,7 +57,22 @@ def parse():
     p.add_argument("--cpu-cycles", type=int, default=5, help="timed CPU cycles (median), after --cpu-warmup untimed ones")
     p.add_argument("--cpu-warmup", type=int, default=2)
     p.add_argument("--e2e-max-tokens", type=int, default=256, help="max_tokens of the end-to-end (prefill included) run; 0 = skip")
+    p.add_argument("--repeats", type=int, default=3, help="the --steps region is timed this many times back to back; "
+                   "ms_per_step / value are the MEDIAN repeat, every repeat is listed beside them")
+    p.add_argument("--other-configs", default="auto",
+                   help="'auto' (N = 1, default workload only): after the headline also time the other BASELINE.json configs' shapes "
+                        "on this GPU and report them under other_configs; 'none' = skip; or a list 'model:k:batch,...'")
+    p.add_argument("--other-steps", type=int, default=20)
     return p.parse_args()
+
+
+# BASELINE.json configs other than the headline, as (model, k, batch, label).  Configs 4 / 5 are quoted at TP = 2 / 8; the draft
+# pass (3 of the 4 forwards of a cycle) runs replicated under this design, so their shapes on ONE GPU are what every rank runs
+# for the draft pass and an upper bound for the verify pass.
+OTHER_CONFIGS = (("llama-3-8b", 5, 32, "config 3: Llama-3-8B k=5 bs=32 TP=1"),
+                 ("llama-2-13b", 3, 4, "config 4 shapes on one GPU: Llama-2-13B k=3 bs=4 (quoted at TP=2)"),
+                 ("llama-3-70b", 3, 8, "config 5 shapes on one GPU: Llama-3-70B k=3 bs=8 (quoted at TP=8)"),
+                 ("tinyllama-1.1b", 3, 1, "config 1 shapes on the HIP path: TinyLlama-1.1B k=3 bs=1 (quoted on the CPU executor)"))
 
 
 def make_bench_engine_class():
@@ -291,8 +309,10 @@ def measure_verify_plans(model, eng, world, reps=10):
     return res
 
 
-PMC_FILES = ("r03_pmc_fetch_size.json", "r03_pmc_fetch_size_llama-3-8b_bs32_k5.json", "r02_pmc_fetch_size.json")
-PMC_SOURCE = "profiles/r03_pmc_fetch_size*.json"
+PMC_FILES = ("r04_pmc_fetch_size.json", "r04_pmc_fetch_size_llama-3-8b_bs32_k5.json", "r04_pmc_fetch_size_llama-2-13b_bs4_k3.json",
+             "r04_pmc_fetch_size_llama-3-70b_bs8_k3.json", "r04_pmc_fetch_size_tinyllama-1.1b_bs1_k3.json",
+             "r03_pmc_fetch_size.json", "r03_pmc_fetch_size_llama-3-8b_bs32_k5.json", "r02_pmc_fetch_size.json")
+PMC_SOURCE = "profiles/r0*_pmc_fetch_size*.json"
 
 
 def pmc_traffic_per_launch(model_name, batch, k):
@@ -314,7 +334,7 @@ def pmc_traffic_per_launch(model_name, batch, k):
         return None
     tot = n = 0
     for name, v in d.get("kernels", {}).items():
-        if "gemm_w4a4_stream_kernel" in name:
+        if "gemm_w4a4_stream_kernel" in name or "gemm_w4a4_longk_kernel" in name:
             tot += v["hbm_read_bytes_per_launch_corrected"] * v["launches"]
             n += v["launches"]
     return int(tot / n) if n else None
@@ -376,6 +396,103 @@ def cpu_baseline(model, args, rho):
                       f"measured -> {full:.2f} s/cycle full depth), OpenMP {cores} threads"}
 
 
+def timed_run(QSpecEngine, model, k, batch, prompts, prompt_len, agreement, warmup, steps, repeats, seed, world, dev):
+    """W untimed cycles, then `repeats` timed regions of exactly `steps` cycles each, every region bracketed by a barrier +
+    torch.cuda.synchronize() on both sides, MAX over ranks per region.  Returns the engine and one record per region:
+    (seconds, accepted, emitted, draft tokens)."""
+    total = warmup + repeats * steps + 2
+    eng = QSpecEngine(model, k, batch, max_model_len=prompt_len + total * (k + 1) + 32, block_size=16,
+                      max_new_tokens=total * (k + 1) + 8, use_graph=True, seed=seed)
+    eng.set_agreement(agreement)
+    eng.add_sequences(prompts)               # prefill (W4A16), untimed: inputs are resident when timing starts
+    for _ in range(warmup):
+        eng.step()
+    regions = []
+    for _ in range(repeats):
+        barrier(world)
+        c0 = eng.sampler.counters.clone()
+        barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.step()
+        barrier(world)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        acc, emit, draft = (int(v) for v in (eng.sampler.counters - c0).tolist())
+        regions.append((dt, acc, emit, draft))
+    assert eng.error_flag() == 0, "a device-side hand-off timed out"
+    return eng, regions
+
+
+def median_region(regions):
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    return regions[order[len(order) // 2]]
+
+
+def roofline_block(model, eng, cfg, batch, k):
+    tot_b, tot_t, n, per_shape = measure_dominant_kernel(model, eng)
+    achieved = tot_b / tot_t / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic_per_launch(cfg.name, batch, k),
+            "traffic_source": PMC_SOURCE + " (builder's separate `rocprofv3 --pmc FETCH_SIZE` pass of the same "
+                              "workload, committed; not collected in this run)",
+            "kernel": "qspec::gemm_w4a4_stream_kernel (the four decoder GEMM launches of a draft forward, M = batch, in "
+                      "the forms the cycle launches for this shape: LN+int4-quant prologue -> qkv+RoPE+KV-write / "
+                      "gate_up+silu*up and o_proj / down_proj + residual add where built, the plain (xq, xs) forms otherwise)",
+            "launches": n, "avg_launch_us": round(tot_t / n * 1e6, 2),
+            "bytes_per_launch_avg": int(tot_b / n), "per_shape": per_shape}
+
+
+def cycle_numbers(cfg, k, batch, sec_per_step):
+    alg_bytes_cycle = (k + 1) * cfg.algorithmic_bytes_per_forward()
+    macs_per_token = 2 * cfg.packed_weight_bytes_per_layer() * cfg.num_hidden_layers + cfg.vocab_size * cfg.hidden_size
+    flops_cycle = 2.0 * macs_per_token * batch * (2 * k + 1)
+    return {"cycle_hbm_GBps_algorithmic": round(alg_bytes_cycle / sec_per_step / 1e9, 1),
+            "cycle_hbm_frac_of_8TBps": round(alg_bytes_cycle / sec_per_step / 8e12, 4),
+            # matrix-core work of a cycle: 2 flop per weight per token (layers + lm_head), k x B draft + (k+1) x B verify
+            # tokens, against the 2.5 PFLOP/s dense fp16 / int8-as-fp16-equivalent peak
+            "cycle_mfma_TFLOPs": round(flops_cycle / sec_per_step / 1e12, 2),
+            "cycle_mfma_frac_of_2.5PF": round(flops_cycle / sec_per_step / 2.5e15, 4)}
+
+
+def measure_other_config(QSpecEngine, name, k, batch, label, args, rho, dev):
+    """One of the other BASELINE.json configs on this GPU: same engine code, same synthetic-agreement knob, same timing
+    brackets as the headline (warm-up, `repeats` regions of `other_steps` cycles, median), plus the dominant kernel's
+    roofline for that shape.  The model is built, measured and freed inside."""
+    import gc
+    from qspec_amd.model import CONFIGS, QuarotLlamaForCausalLM
+    cfg = CONFIGS[name]
+    t_build = time.perf_counter()
+    model = QuarotLlamaForCausalLM(cfg, dev).init_synthetic(args.seed, args.lm_head_std)
+    g = torch.Generator().manual_seed(args.seed)
+    prompt_len = min(args.prompt_len, cfg.max_position_embeddings // 2)
+    prompts = [torch.randint(0, cfg.vocab_size, (prompt_len,), generator=g).tolist() for _ in range(batch)]
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    eng, regions = timed_run(QSpecEngine, model, k, batch, prompts, prompt_len, rho, min(args.warmup, 5), args.other_steps,
+                             args.repeats, args.seed, 1, dev)
+    dt, acc, emit, draft = median_region(regions)
+    sec = dt / args.other_steps
+    out = {"workload": f"{label}; prompt_len={prompt_len} greedy, synthetic int4 weights, synthetic agreement {rho}",
+           "model": name, "num_speculative_tokens": k, "batch": batch,
+           "value": round(emit / dt, 2), "unit": "tokens/s", "steps": args.other_steps, "ms_per_step": round(sec * 1e3, 4),
+           "ms_per_step_repeats": [round(r[0] / args.other_steps * 1e3, 4) for r in regions],
+           "draft_acceptance_rate": round(acc / draft, 4) if draft else None,
+           "system_efficiency": round(emit / ((draft // k) * (k + 1)), 4) if draft else None,
+           "capture": "graph" if eng._graph is not None else "eager", "build_s": round(t_build, 1)}
+    out.update(cycle_numbers(cfg, k, batch, sec))
+    if not args.no_roofline:
+        out["roofline"] = roofline_block(model, eng, cfg, batch, k)
+    del eng, model
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -397,30 +514,9 @@ def main():
     g = torch.Generator().manual_seed(args.seed)
     prompts = [torch.randint(0, cfg.vocab_size, (args.prompt_len,), generator=g).tolist() for _ in range(args.batch)]
 
-    def run(agreement, warmup, steps):
-        total = warmup + steps + 2
-        eng = QSpecEngine(model, args.k, args.batch, max_model_len=args.prompt_len + total * (args.k + 1) + 32,
-                          block_size=16, max_new_tokens=total * (args.k + 1) + 8, use_graph=True, seed=args.seed)
-        eng.set_agreement(agreement)
-        eng.add_sequences(prompts)               # prefill (W4A16), untimed: inputs are resident when timing starts
-        for _ in range(warmup):
-            eng.step()
-        barrier(world)
-        c0 = eng.sampler.counters.clone()
-        barrier(world)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            eng.step()
-        barrier(world)
-        dt = time.perf_counter() - t0
-        if world > 1:
-            import torch.distributed as dist
-            t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        acc, emit, draft = (int(v) for v in (eng.sampler.counters - c0).tolist())
-        assert eng.error_flag() == 0, "a device-side hand-off timed out"
-        return eng, dt, acc, emit, draft
+    def run(agreement, warmup, steps, repeats=1):
+        return timed_run(QSpecEngine, model, args.k, args.batch, prompts, args.prompt_len, agreement, warmup, steps, repeats,
+                         args.seed, world, dev)
 
     def run_e2e(agreement, max_tokens):
         """demo.py:139-160: prompt pass + decode until every request has max_tokens tokens; tokens / wall time.  The
@@ -454,12 +550,11 @@ def main():
         gc.collect()
         return total / dt, t_prefill, cycles, dt
 
-    eng, dt, acc, emit, draft = run(rho, args.warmup, args.steps)
+    eng, regions = run(rho, args.warmup, args.steps, max(1, args.repeats))
+    dt, acc, emit, draft = median_region(regions)     # ms_per_step / value: the MEDIAN of the timed regions
+    per_step = [r[0] / args.steps * 1e3 for r in regions]
     rate = acc / draft if draft else float("nan")
     eff = emit / ((draft // args.k) * (args.k + 1)) if draft else float("nan")
-    alg_bytes_cycle = (args.k + 1) * cfg.algorithmic_bytes_per_forward()
-    macs_per_token = 2 * cfg.packed_weight_bytes_per_layer() * cfg.num_hidden_layers + cfg.vocab_size * cfg.hidden_size
-    flops_cycle = 2.0 * macs_per_token * args.batch * (2 * args.k + 1)
     agree_txt = "weights' own agreement" if rho is None else f"synthetic draft/target agreement {rho}"
     out = {
         "metric": "accepted_tokens_per_s" if rho is None else f"accepted_tokens_per_s_at_synthetic_agreement_{rho:g}",
@@ -484,17 +579,18 @@ def main():
                    # per GPU: the only configuration in which an RCCL-in-graph claim means anything)
                    "capture": ("graph" if eng._graph is not None else
                                ("draft-graph+eager-verify" if eng._graph_draft is not None else "eager"))},
+        # the --steps region timed `repeats` times back to back (same engine, same graph): ms_per_step / value above are the
+        # median region's; spread = (max - min) / median
+        "repeats": len(regions), "ms_per_step_repeats": [round(v, 4) for v in per_step],
+        "ms_per_step_spread": round((max(per_step) - min(per_step)) / sorted(per_step)[len(per_step) // 2], 4),
         "draft_acceptance_rate": round(rate, 4), "system_efficiency": round(eff, 4),
         "accepted_tokens": acc, "emitted_tokens": emit, "draft_tokens": draft,
-        "cycle_hbm_GBps_algorithmic": round(alg_bytes_cycle / (dt / args.steps) / 1e9, 1),
-        # matrix-core work of a cycle: 2 flop per weight per token (layers + lm_head), k x B draft + (k+1) x B verify tokens,
-        # against the 2.5 PFLOP/s dense fp16 / int8-as-fp16-equivalent peak: decode is nowhere near MFMA-bound
-        "cycle_mfma_TFLOPs": round(flops_cycle / (dt / args.steps) / 1e12, 2),
-        "cycle_mfma_frac_of_2.5PF": round(flops_cycle / (dt / args.steps) / 2.5e15, 4),
     }
+    out.update(cycle_numbers(cfg, args.k, args.batch, dt / args.steps))
     if rho is not None and args.natural_steps > 0:
         # the same engine code with the random weights' own agreement (acceptance ~ a few %): reported beside the headline
-        _, dt2, acc2, emit2, draft2 = run(None, min(args.warmup, 5), args.natural_steps)
+        _, reg2 = run(None, min(args.warmup, 5), args.natural_steps)
+        dt2, acc2, emit2, draft2 = reg2[0]
         out["natural_agreement"] = {"value": round(emit2 / dt2, 2), "unit": "tokens/s", "steps": args.natural_steps,
                                     "ms_per_step": round(dt2 / args.natural_steps * 1e3, 4),
                                     "draft_acceptance_rate": round(acc2 / draft2, 4) if draft2 else None,
@@ -509,19 +605,30 @@ def main():
     if world > 1:
         out["config"]["tp_verify_forward"] = measure_verify_plans(model, eng, world)
     if rank == 0 and not args.no_roofline:   # the draft pass is replicated under TP: rank 0's launches are every rank's
-        tot_b, tot_t, n, per_shape = measure_dominant_kernel(model, eng)
-        achieved = tot_b / tot_t / 1e9
-        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                           "frac": round(achieved / 8000.0, 4), "traffic": pmc_traffic_per_launch(cfg.name, args.batch, args.k),
-                           "traffic_source": PMC_SOURCE + " (builder's separate `rocprofv3 --pmc FETCH_SIZE` pass of the same "
-                                             "workload, committed; not collected in this run)",
-                           "kernel": "qspec::gemm_w4a4_stream_kernel (the four decoder GEMM launches of a draft forward, M = batch, in "
-                                     "the forms the cycle launches for this shape: LN+int4-quant prologue -> qkv+RoPE+KV-write / "
-                                     "gate_up+silu*up and o_proj / down_proj + residual add where built, the plain (xq, xs) forms otherwise)",
-                           "launches": n, "avg_launch_us": round(tot_t / n * 1e6, 2),
-                           "bytes_per_launch_avg": int(tot_b / n), "per_shape": per_shape}
+        out["roofline"] = roofline_block(model, eng, cfg, args.batch, args.k)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, args, rho)
+    # ---- the other BASELINE.json configs on this GPU (N = 1, default workload only: the driver's run)
+    others = []
+    if args.other_configs == "auto":
+        if world == 1 and (args.model, args.k, args.batch) == ("llama-3-8b", 3, 4):
+            others = list(OTHER_CONFIGS)
+    elif args.other_configs not in ("none", ""):
+        for item in args.other_configs.split(","):
+            nm, kk, bb = item.split(":")
+            others.append((nm, int(kk), int(bb), f"{nm} k={kk} bs={bb}"))
+    if others and world == 1:
+        import gc
+        del eng, model
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["other_configs"] = {}
+        for nm, kk, bb, label in others:
+            try:
+                out["other_configs"][f"{nm}_k{kk}_bs{bb}"] = measure_other_config(QSpecEngine, nm, kk, bb, label, args, rho, dev)
+            except Exception as exc:   # the headline line must survive a failure here: reported, not hidden
+                out["other_configs"][f"{nm}_k{kk}_bs{bb}"] = {"error": repr(exc)[:300]}
+                torch.cuda.synchronize()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
