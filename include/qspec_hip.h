@@ -339,6 +339,23 @@ int qspec_heads_hadamard_mix_merged_spread(const void* attn_workspace, int max_t
                                            int heads, int head_dim, void* stream);
 int qspec_heads_hadamard_mix_merged_spread_supported(int tokens, int heads, int head_dim, int K);
 
+/* The s4s4 linear (rowwise_scaled_linear_cutlass_s4s4_unified, quarot_nn/linear.py:67-84) at 17..32 tokens as K SLICES whose raw
+ * int32 sums are finished by the consumer: ipart [slices, M, N] int32, slice s = sum over k in [s K / slices, (s + 1) K / slices)
+ * of xq[m, k] wq[n, k].  Integer sums are exact in any order, so qspec_add_rms_norm_ipartial below -- which adds the slices,
+ * applies the reference epilogue h((f(acc) f(xs[m])) f(ws[n])) (rowwise_scaled_linear_cutlass_unified.cuh:342-377), the fp16
+ * residual add (quarot_llama.py:380,390) and the following norm (layernorm_kernels.cu:569-716) -- gives the bits of
+ * qspec_rowwise_scaled_linear_s4s4 followed by qspec_add_rms_norm_i4 / _fp16.  Why: with one 16-row weight tile per workgroup
+ * a workgroup reads twice as many activation bytes as weight bytes at 32 tokens; with two K slices it owns two tiles of half
+ * the K and reads its activation fragments once for both.  _slices: the slice count built for (M, N, K), 0 = use the plain entry. */
+int qspec_rowwise_scaled_linear_s4s4_partial_slices(int M, int N, int K);
+int qspec_rowwise_scaled_linear_s4s4_partial(const int8_t* xq, const int8_t* wq, int32_t* ipart, int M, int N, int K, int slices,
+                                             void* stream);
+/* hidden_out = h(f(x) + f(delta)), delta as above from ipart / xs [tokens] / ws [hidden]; then the norm of hidden_out:
+ * q != NULL: int4 rows + scale (generalLayerNorm_fuse_sum_i4), else fp16 rows out_f16.  hidden_out may alias x. */
+int qspec_add_rms_norm_ipartial(int8_t* q, qspec_half* scale, qspec_half* out_f16, qspec_half* hidden_out, const qspec_half* x,
+                                const int32_t* ipart, const qspec_half* xs, const qspec_half* ws, int slices, float eps,
+                                int tokens, int hidden, void* stream);
+
 /* ---- token side ------------------------------------------------------------------------------- */
 
 /* nn.Embedding lookup (quarot_llama.py:497). */

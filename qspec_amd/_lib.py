@@ -54,6 +54,9 @@ SIGNATURES = {
     "qspec_heads_hadamard_merged_spread_supported": (_i, [_i, _i, _i]),
     "qspec_heads_hadamard_mix_merged_spread": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _f, _i, _i, _i, _vp]),
     "qspec_heads_hadamard_mix_merged_spread_supported": (_i, [_i, _i, _i, _i]),
+    "qspec_rowwise_scaled_linear_s4s4_partial_slices": (_i, [_i, _i, _i]),
+    "qspec_rowwise_scaled_linear_s4s4_partial": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "qspec_add_rms_norm_ipartial": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i, _vp]),
     "qspec_rowwise_scaled_linear_s4s4": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_w4a16_workspace_bytes": (_sz, []),
     "qspec_w4a16_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

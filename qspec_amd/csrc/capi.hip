@@ -611,6 +611,29 @@ int qspec_add_rms_norm_fp16_partial(qspec_half* out, qspec_half* hidden_out, con
     if (hidden % 1024 || hidden > 8192 || hidden <= 0) return fail("%s: hidden=%d must be a multiple of 1024, <= 8192", op, hidden);
     return finish(op, qspec::ln_fp16_partial(CH(x), part, CH(ws), slices, H(hidden_out), H(out), eps, tokens, hidden, ST));
 }
+int qspec_rowwise_scaled_linear_s4s4_partial_slices(int M, int N, int K) { return qspec::gemm_w4a4_stream_partial_slices(M, N, K); }
+int qspec_rowwise_scaled_linear_s4s4_partial(const int8_t* xq, const int8_t* wq, int32_t* ipart, int M, int N, int K, int slices,
+                                             void* stream) {
+    const char* op = "qspec_rowwise_scaled_linear_s4s4_partial";
+    if (M <= 0 || N <= 0) return fail("%s: empty problem", op);
+    NONNULL(op, xq); NONNULL(op, wq); NONNULL(op, ipart);
+    if (slices < 2 || slices != qspec::gemm_w4a4_stream_partial_slices(M, N, K))
+        return fail("%s: (M=%d N=%d K=%d) is not built for %d K slices (ask qspec_rowwise_scaled_linear_s4s4_partial_slices)", op, M, N, K, slices);
+    return finish(op, qspec::gemm_w4a4_stream_partial(xq, wq, ipart, M, N, K, slices, ST));
+}
+int qspec_add_rms_norm_ipartial(int8_t* q, qspec_half* scale, qspec_half* out_f16, qspec_half* hidden_out, const qspec_half* x,
+                                const int32_t* ipart, const qspec_half* xs, const qspec_half* ws, int slices, float eps,
+                                int tokens, int hidden, void* stream) {
+    const char* op = "qspec_add_rms_norm_ipartial";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, x); NONNULL(op, ipart); NONNULL(op, xs); NONNULL(op, ws); NONNULL(op, hidden_out);
+    if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
+    if (slices < 1) return fail("%s: slices < 1", op);
+    if (hidden % 1024 || hidden > 8192 || hidden <= 0) return fail("%s: hidden=%d must be a multiple of 1024, <= 8192", op, hidden);
+    return finish(op, qspec::ln_ipartial(CH(x), ipart, CH(xs), CH(ws), slices, H(hidden_out), H(out_f16), q, H(scale), eps, tokens,
+                                         hidden, ST));
+}
 int qspec_prefetch(const void* p, size_t bytes, int workgroups, void* stream) {
     const char* op = "qspec_prefetch";
     if (bytes == 0) return 0;

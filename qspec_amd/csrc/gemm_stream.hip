@@ -51,7 +51,12 @@ __device__ __forceinline__ T wload(const void* p) {
 #endif
 }
 
-enum { SEPI_PLAIN = 0, SEPI_QKV = 1, SEPI_GATEUP = 2, SEPI_RESID = 3, SEPI_PARTIAL = 4 };   // RESID: plain + fp16 residual add
+enum { SEPI_PLAIN = 0, SEPI_QKV = 1, SEPI_GATEUP = 2, SEPI_RESID = 3, SEPI_PARTIAL = 4, SEPI_IPART = 5 };   // RESID: plain + fp16 residual add
+// SEPI_IPART (W4A4, (xq, xs) input): blockIdx.y picks one of gridDim.y K slices of length K; the raw int32 sums of the slice
+// go to ipart[blockIdx.y][M][N] and whoever consumes them (norm_quant.hip: ln_kernel with ipart) adds the slices -- exact in
+// any order -- and applies the epilogue expression.  What it is for: at 17..32 tokens a workgroup with ONE 16-row tile reads
+// 2 x as many activation bytes as weight bytes (config 3's down_proj: 229 KB for 115 KB); with two K slices it takes TWO
+// tiles of half the K and reads its activation fragments once for both.
 enum { PRO_Q = 0, PRO_LN = 1, PRO_LNH = 2, PRO_LN1 = 3, PRO_LNS = 4, PRO_LN1S = 5, PRO_RQ = 6 };   // (see the header)
 
 struct StreamArgs {
@@ -71,6 +76,7 @@ struct StreamArgs {
     int64_t ldx, ldw;       // W4A16: activation row stride (halves) / packed weight row stride (bytes); 0 = dense
     int tile0;              // W4A16: first tile of the launch (column-parallel shards)
     float* part;            // W4A16 SEPI_PARTIAL: [gridDim.y][M][N] raw fp32 sums of K slice blockIdx.y (K = slice length)
+    int* ipart;             // W4A4 SEPI_IPART: [gridDim.y][M][N] raw int32 sums of K slice blockIdx.y (ldx / ldw = row strides in BYTES)
     const uint8_t* wq;      // [N, K/2]
     const f16* ws;          // [N]
     f16* out;
@@ -944,6 +950,7 @@ __device__ __forceinline__ void vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" 
 template <int EPI, int PRO, int NW, int UB, int NI, int MT = 1, int DMA = 0>
 __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ? 256 : 0)) void gemm_w4a4_stream_kernel(StreamArgs a) {
     static_assert(MT == 1 || (PRO == PRO_Q && NW >= 8), "two token tiles: (xq, xs) input, >= 512 threads for the epilogue");
+    static_assert(EPI != SEPI_IPART || PRO == PRO_Q, "K-slice partials: (xq, xs) input");
     static_assert(DMA == 0 || (pro_split<PRO>() && MT == 1 && NW * UB == 32 && DMA <= 3), "LDS-DMA tiles: split forms, 32 KiB tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef QS_STREAM_STAMPS
@@ -961,6 +968,9 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int Kb = a.K >> 1, RS = Kb + 32;
+    // SEPI_IPART: this workgroup's K slice starts kofs bytes into every row; rows are ldw / ldx bytes apart
+    const size_t kofs = EPI == SEPI_IPART ? (size_t)blockIdx.y * Kb : 0;
+    const size_t ldwb = EPI == SEPI_IPART ? (size_t)a.ldw : (size_t)Kb, ldxb = EPI == SEPI_IPART ? (size_t)a.ldx : (size_t)Kb;
     const int MP = a.M <= 4 ? 4 : (a.M <= 8 ? 8 : 16);
     unsigned char* xq_lds = smem;
     float* xs_lds = reinterpret_cast<float*>(smem + (PRO == PRO_Q ? (size_t)0 : (size_t)MP * RS));   // (xq, xs) input: no staged rows
@@ -1019,7 +1029,7 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
         f16 swn, cf, sf;
     };
     auto load_pre = [&](Pre& pre, int tile) {  // epilogue operands of (token m, column c) of `tile`
-        pre.swn = a.ws[stile_row<EPI>(tile, c, a.I)];
+        if (EPI != SEPI_IPART) pre.swn = a.ws[stile_row<EPI>(tile, c, a.I)];
         if (EPI == SEPI_RESID) pre.cf = a.resid_in[(size_t)mc * a.N + tile * 16 + c];   // the residual element
         if (EPI == SEPI_QKV) {
             const int o = qkv_pair(tile, c & 7, a.I).i;
@@ -1029,7 +1039,7 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
         }
     };
     auto wptr = [&](int tile, int b) -> const uint8_t* {
-        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I) * Kb + (size_t)(b * UB * NW) * 64 + g * 16;
+        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I) * ldwb + kofs + (size_t)(b * UB * NW) * 64 + g * 16;
     };
     // A wave owns the same K steps of every tile (one batch per tile: NB == 1, checked on the host), so its
     // activation fragments are widened ONCE and stay in registers: no per-step LDS read, and with (xq, xs) given
@@ -1051,8 +1061,10 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
             for (int mt = 0; mt < MT; mt++) {
                 // the widening is loop invariant (a wave meets the same K steps in every tile): left visible, hipcc
                 // hoists it and keeps 8 VGPRs per step and tile live -- spills at 1024 threads.  Opaque copies keep it here.
+                // (Up to 512 threads the budget is 256 VGPRs: there the hoist is what we want -- the fragments are widened
+                // once and config 3's gate_up no longer spends a third of its issue cycles re-widening them.)
                 u32 p0 = apk[mt][u][0], p1 = apk[mt][u][1], p2 = apk[mt][u][2], p3 = apk[mt][u][3];
-                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+                if constexpr (NW > 8 || UB > 7) asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));   // (8 x 8 steps: 1-4 spills)
                 acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(widen16(p0, p1), b0, acc[mt], 0, 0, 0);
                 acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(widen16(p2, p3), b1, acc[mt], 0, 0, 0);
             }
@@ -1072,9 +1084,14 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
             int sum = 0;
 #pragma unroll
             for (int w2 = 0; w2 < NW; w2++) sum += rb[w2 * MT * 256 + ridx];
+            if (EPI == SEPI_IPART) {   // the slice's raw sum (both operands carried a factor 16: an exact multiple of 256)
+                a.ipart[((size_t)blockIdx.y * a.M + m) * a.N + tile * 16 + c] = sum >> 8;
+                return;
+            }
             const float v = ((float)(sum >> 8) * xs_m) * h2f(pre.swn);  // both operands carried a factor 16
             hv = f2h(v);
         }
+        if (EPI == SEPI_IPART) return;
         if (EPI == SEPI_PLAIN) {
             if (ethread) a.out[(size_t)m * a.N + tile * 16 + c] = hv;
             return;
@@ -1335,19 +1352,20 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
         }
     } else {
         u32x4 araw[UB];
-        const unsigned char* xrow = reinterpret_cast<const unsigned char*>(a.xq) + (size_t)(r < a.M ? r : 0) * Kb + g * 16;
+        const unsigned char* xrow = reinterpret_cast<const unsigned char*>(a.xq) + (size_t)(r < a.M ? r : 0) * ldxb + kofs + g * 16;
 #pragma unroll
         for (int u = 0; u < UB; u++) araw[u] = *reinterpret_cast<const u32x4*>(xrow + step_off<NW, UB>(wave, u));
         if constexpr (MT > 1) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 const int row = mt * 16 + r;
-                const unsigned char* xr = reinterpret_cast<const unsigned char*>(a.xq) + (size_t)(row < a.M ? row : 0) * Kb + g * 16;
+                const unsigned char* xr = reinterpret_cast<const unsigned char*>(a.xq) + (size_t)(row < a.M ? row : 0) * ldxb + kofs + g * 16;
 #pragma unroll
                 for (int u = 0; u < UB; u++) apk[mt][u] = *reinterpret_cast<const u32x4*>(xr + step_off<NW, UB>(wave, u));
             }
         }
-        const f16 xsh = a.xs[mc];
+        f16 xsh = (f16)0.0f;
+        if (EPI != SEPI_IPART) xsh = a.xs[mc];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < UB; u++) w[u] = wload<u32x4>(wp0 + step_off<NW, UB>(wave, u));
@@ -2444,12 +2462,14 @@ static int launch_stream_inst(const StreamArgs& a, hipStream_t st) {
     }
     int cap = stream_cap();
     if (PRO == PRO_LNH && cap > 256) cap = 256;   // the fence-free hand-off is calibrated for one workgroup per CU
+    const int slices = EPI == SEPI_IPART ? a.nq : 1;   // (nq carries the slice count for SEPI_IPART)
+    if (slices > 1) cap = cap / slices > 0 ? cap / slices : 1;   // one workgroup per CU in total
     int grid = a.ntiles;
     if (grid > cap) {
         const int per = (a.ntiles + cap - 1) / cap;
         grid = (a.ntiles + per - 1) / per;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ? 256 : 0)), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid, slices), dim3(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ? 256 : 0)), lds, st, a);
     return 0;
 }
 
@@ -2731,6 +2751,23 @@ int gemm_w4a4_stream_residual(const StreamActs& x, const int8_t* wq, const f16* 
     a.resid_in = resid_in; a.resid_out = resid_out;
     if (longk_shape(K)) return launch_longk<SEPI_RESID>(a, st);
     return launch_stream<SEPI_RESID>(a, x.hidden_in != nullptr, st);
+}
+
+// K-sliced W4A4 at 17..32 tokens: slice count for (M, N, K), 0 = not built / does not pay.  Two slices where a workgroup
+// would otherwise hold ONE 16-row tile (N / 16 <= the chip's 256 workgroups): K = 14336 -> 2 x 7168 (Llama-3-8B down_proj).
+int gemm_w4a4_stream_partial_slices(int M, int N, int K) {
+    if (M < 17 || M > 32 || N % 32 || N / 16 > stream_cap()) return 0;
+    if (K == 14336) return 2;
+    return 0;
+}
+int gemm_w4a4_stream_partial(const int8_t* xq, const int8_t* wq, int* ipart, int M, int N, int K, int S, hipStream_t st) {
+    if (S != gemm_w4a4_stream_partial_slices(M, N, K) || S < 2 || !ipart) return -1;
+    StreamArgs a{};
+    a.xq = xq; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ipart = ipart; a.M = M; a.N = N; a.K = K / S; a.ntiles = N / 16;
+    a.ldx = K / 2; a.ldw = K / 2; a.nq = S;
+    // K slices of 7168 (14336 / 2), two token tiles: 8 waves x 7 steps
+    if (a.K == 7168) return launch_stream_inst<SEPI_IPART, PRO_Q, 8, 7, 0, 2>(a, st);
+    return -1;
 }
 
 bool gemm_w4a4_stream_residual_hq_supported(int M, int N, int K, int nparts) {

@@ -13,6 +13,8 @@ int ln_quant_i4(const f16* x, const f16* delta, f16* hidden_out, int8_t* q, f16*
                 int H, hipStream_t st);
 int ln_fp16(const f16* x, const f16* delta, f16* hidden_out, f16* out, float eps, int T, int H, hipStream_t st);
 // delta = h((part[0] + ... + part[S-1])[t, :] * f(ws[:])): the K-sliced W4A16 projection finished inside the norm
+int ln_ipartial(const f16* x, const int* ipart, const f16* xs, const f16* ws, int S, f16* hidden_out, f16* out, int8_t* q,
+                f16* scale, float eps, int T, int H, hipStream_t st);
 int ln_fp16_partial(const f16* x, const float* part, const f16* ws, int S, f16* hidden_out, f16* out, float eps, int T,
                     int H, hipStream_t st);
 int rowabsmax_quant(const f16* x, f16* scale, int8_t* q, float clip, int T, int K, hipStream_t st);
@@ -77,6 +79,8 @@ int gemm_w4a4_stream_residual(const StreamActs& x, const int8_t* wq, const f16* 
 int gemm_w4a4_stream_residual_hq(const f16* x16, const float* part_amax, int nparts, float clip, const int8_t* wq, const f16* ws,
                                  const f16* resid_in, f16* resid_out, int M, int N, int K, hipStream_t st);
 bool gemm_w4a4_stream_residual_hq_supported(int M, int N, int K, int nparts);
+int gemm_w4a4_stream_partial_slices(int M, int N, int K);
+int gemm_w4a4_stream_partial(const int8_t* xq, const int8_t* wq, int* ipart, int M, int N, int K, int S, hipStream_t st);
 int heads_hadamard_mix_merge_spread(const float* ws, int max_tokens, int n_splits, const f16* hadK, f16* out_f16,
                                     float* part_amax, float had_scale, int T, int heads, int d, int K, hipStream_t st);
 bool heads_hadamard_mix_merge_spread_supported(int T, int heads, int d, int K);

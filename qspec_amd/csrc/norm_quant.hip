@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
                                                  int8_t* __restrict__ q, f16* __restrict__ scale,
                                                  f16* __restrict__ input_sum, float eps, int H,
                                                  const float* __restrict__ part = nullptr,
-                                                 const f16* __restrict__ pws = nullptr, int S = 0, size_t pstride = 0) {
+                                                 const f16* __restrict__ pws = nullptr, int S = 0, size_t pstride = 0,
+                                                 const int* __restrict__ ipart = nullptr, const f16* __restrict__ pxs = nullptr) {
     __shared__ __attribute__((aligned(16))) float red_all[4][32];   // one region per reduction: no barrier in front
     float* red = red_all[0];
     const int row = blockIdx.x, j = threadIdx.x;
@@ -100,7 +101,33 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
 #pragma unroll
             for (int c = 0; c < 4; c++) da[it][c] = f2h(sum[it][c] * h2f(w4[it][c]));
     }
-    const bool has_delta = part != nullptr || delta != nullptr;
+    if (ipart) {
+        // delta arrives as S raw int32 K-slice sums of a W4A4 projection (gemm_stream.hip, SEPI_IPART): the slices add up
+        // exactly, then the GEMM's own epilogue expression: delta = h((f(i_0 + i_1 + ...) * f(xs[row])) * f(sw[col]))
+        typedef int i32x4v __attribute__((ext_vector_type(4)));
+        i32x4v isum[NI];
+        f16x4 w4[NI];
+        const float xsr = h2f(pxs[row]);
+#pragma unroll
+        for (int it = 0; it < NI; it++) {
+            const size_t col = (size_t)it * 1024 + 4 * j;
+            isum[it] = *reinterpret_cast<const i32x4v*>(ipart + (size_t)row * H + col);
+            w4[it] = *reinterpret_cast<const f16x4*>(pws + col);
+        }
+        for (int s2 = 1; s2 < S; s2++) {
+            i32x4v t[NI];
+#pragma unroll
+            for (int it = 0; it < NI; it++)
+                t[it] = *reinterpret_cast<const i32x4v*>(ipart + (size_t)s2 * pstride + (size_t)row * H + (size_t)it * 1024 + 4 * j);
+#pragma unroll
+            for (int it = 0; it < NI; it++) isum[it] = isum[it] + t[it];
+        }
+#pragma unroll
+        for (int it = 0; it < NI; it++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) da[it][c] = f2h(((float)isum[it][c] * xsr) * h2f(w4[it][c]));
+    }
+    const bool has_delta = part != nullptr || ipart != nullptr || delta != nullptr;
 #pragma unroll
     for (int it = 0; it < NI; it++) {
         f16x4 a = xa[it];
@@ -221,6 +248,30 @@ int ln_quant_i4(const f16* x, const f16* delta, f16* hidden_out, int8_t* q, f16*
 }
 int ln_fp16(const f16* x, const f16* delta, f16* hidden_out, f16* out, float eps, int T, int H, hipStream_t st) {
     return launch_ln<1>(x, delta, hidden_out, out, nullptr, nullptr, nullptr, eps, T, H, st);
+}
+// delta = the W4A4 projection whose S int32 K-slice sums are ipart [S][T][H] (activation scales xs [T], channel scales ws [H]);
+// q != nullptr: int4 output (the draft pass's next norm), else fp16 `out` (the final norm)
+int ln_ipartial(const f16* x, const int* ipart, const f16* xs, const f16* ws, int S, f16* hidden_out, f16* out, int8_t* q,
+                f16* scale, float eps, int T, int H, hipStream_t st) {
+    if (T == 0) return 0;
+    if (S < 1 || !ipart || !xs || !ws) return -1;
+#define QS_LNI_CASE(NI)                                                                                              \
+    case NI:                                                                                                         \
+        if (q)                                                                                                       \
+            hipLaunchKernelGGL((ln_kernel<NI, 0>), dim3(T), dim3(256), 0, st, x, (const f16*)nullptr, hidden_out,     \
+                               (f16*)nullptr, q, scale, (f16*)nullptr, eps, H, (const float*)nullptr, ws, S,          \
+                               (size_t)T * H, ipart, xs);                                                            \
+        else                                                                                                         \
+            hipLaunchKernelGGL((ln_kernel<NI, 1>), dim3(T), dim3(256), 0, st, x, (const f16*)nullptr, hidden_out, out, \
+                               (int8_t*)nullptr, (f16*)nullptr, (f16*)nullptr, eps, H, (const float*)nullptr, ws, S,  \
+                               (size_t)T * H, ipart, xs);                                                            \
+        break;
+    switch (H / 1024) {
+        QS_LNI_CASE(1) QS_LNI_CASE(2) QS_LNI_CASE(3) QS_LNI_CASE(4) QS_LNI_CASE(5) QS_LNI_CASE(6) QS_LNI_CASE(7) QS_LNI_CASE(8)
+        default: return -1;
+    }
+#undef QS_LNI_CASE
+    return 0;
 }
 int ln_fp16_partial(const f16* x, const float* part, const f16* ws, int S, f16* hidden_out, f16* out, float eps, int T,
                     int H, hipStream_t st) {

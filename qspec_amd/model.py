@@ -102,6 +102,9 @@ class Scratch:
         self.down_part = e(4, T, H, dtype=torch.float32) if T <= 16 else None
         self.tp_part = e(1, min(T, 32), H, dtype=torch.float32)   # TP verify pass (T <= 32): fp32 row-parallel partials
         self.had_part_amax = e(min(T, 16), 8, dtype=torch.float32)  # draft pass (T <= 4): partial row maxima of the spread head Hadamard
+        # draft pass at 17..32 tokens: int32 K-slice sums of down_proj + the activation scales they were computed with
+        self.down_ipart = e(2, T, H, dtype=torch.int32) if 16 < T <= 32 else None
+        self.down_xs = e(T) if 16 < T <= 32 else None
         ws = ops.paged_attention_workspace_bytes(n_seqs * max_q_len, cfg.num_attention_heads, cfg.head_dim, n_splits)
         self.attn_ws = torch.zeros(ws, dtype=torch.uint8, device=device)   # ticket counters start at zero
 
@@ -180,13 +183,17 @@ class QuarotLlamaForCausalLM:
     def _add_norm_fp16(self, normed, hidden, delta, eps):
         """hidden += delta; normed = LN(hidden).  delta: fp16 tensor, None, or ("partial", part, w_scale, S) = the raw
         K-slice sums of a long-K W4A16 down_proj, finished inside the norm kernel."""
-        if isinstance(delta, tuple):
+        if isinstance(delta, tuple) and delta[0] == "ipartial":
+            _, ipart, xs, w_scale, S = delta
+            ops.add_rms_norm_ipartial(hidden, hidden, ipart, xs, w_scale, S, eps, out_f16=normed)
+        elif isinstance(delta, tuple):
             _, part, w_scale, S = delta
             ops.add_rms_norm_fp16_partial(normed, hidden, hidden, part, w_scale, S, eps)
         else:
             ops.add_rms_norm_fp16(normed, hidden, hidden, delta, eps)
 
     MERGE_IN_HADAMARD = True   # False: the attention kernel merges its context splits itself (ticket + fences)
+    DOWN_K_SLICES = __import__("os").environ.get("QSPEC_DOWN_K_SLICES", "1") != "0"   # draft down_proj at 17..32 tokens as K slices
 
     def _attention_hadamard(self, qkv, row, kc, vc, md, T, s, attn, q1, sc, had):
         """Attention + head Hadamard (+ quant when q1 is given, else fp16 into `had`) (quarot_llama.py:213-238).
@@ -255,6 +262,9 @@ class QuarotLlamaForCausalLM:
                    ops.heads_hadamard_mix_merged_spread_supported(T, nh, hd, self.head_had_K))
               and ops.rowwise_scaled_linear_s4s4_residual_hq_supported(T, cfg.hidden_size, cfg.q_size))
         had16 = s.act_buffer_had[:T]
+        # draft pass at 17..32 tokens: down_proj as K slices (0 / 1 = the plain launch)
+        S_down = (ops.rowwise_scaled_linear_s4s4_partial_slices(T, cfg.hidden_size, cfg.intermediate_size)
+                  if (w4a4 and fuse and not ln_fused and s.down_ipart is not None and self.DOWN_K_SLICES) else 0)
         for li, layer in enumerate(self.layers):
             kc, vc = kv_caches[li]
             qkv_w, qkv_s = layer.qkv_proj.weight, layer.qkv_proj._scales()
@@ -288,7 +298,11 @@ class QuarotLlamaForCausalLM:
                 continue
             # input_layernorm (+ residual add of the previous MLP) -> qkv_proj -> rope -> kv write    :373-374,183-226
             if w4a4:
-                ops.add_rms_norm_i4(q1, sc, hidden, hidden, delta, eps)
+                if isinstance(delta, tuple):   # ("ipartial", ...): the previous down_proj's int32 K-slice sums
+                    _, ipart, pxs, pws, S = delta
+                    ops.add_rms_norm_ipartial(hidden, hidden, ipart, pxs, pws, S, eps, q=q1, scale=sc)
+                else:
+                    ops.add_rms_norm_i4(q1, sc, hidden, hidden, delta, eps)
                 x, xs = q1, sc
             else:
                 self._add_norm_fp16(normed, hidden, delta, eps)
@@ -337,8 +351,9 @@ class QuarotLlamaForCausalLM:
                     self.tp.all_gather_channels(act, cfg.intermediate_size)
                 else:
                     ops.gate_up_silu_linear(x, xs, gu_w, gu_s, act)
-                if w4a4:
-                    ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, q=q3, scale=sc)
+                if w4a4:   # (K-sliced down_proj: its activation scales outlive the next norm's, so they get their own buffer)
+                    ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, q=q3,
+                                     scale=s.down_xs[:T] if S_down > 1 else sc)
                 else:
                     had_mlp_in = s.act_buffer_gate_up.view(-1)[:T * cfg.intermediate_size].view(T, cfg.intermediate_size)
                     ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, out_f16=had_mlp_in)
@@ -351,6 +366,11 @@ class QuarotLlamaForCausalLM:
                     ops.silu_mul_hadamard(gu, self.had_rem_dim, self.had_K, self.mlp_had_scale, out_f16=had_mlp)
                     had_mlp_in = had_mlp
             if w4a4:
+                if S_down > 1:   # 17..32 tokens: K slices, int32 sums finished inside the next norm (ops.add_rms_norm_ipartial)
+                    ipart = s.down_ipart.view(-1)[:S_down * T * cfg.hidden_size].view(S_down, T, cfg.hidden_size)
+                    ops.rowwise_scaled_linear_s4s4_partial(q3, layer.down_proj.weight, ipart, S_down)
+                    delta = ("ipartial", ipart, s.down_xs[:T], layer.down_proj._scales(), S_down)
+                    continue
                 ops.rowwise_scaled_linear_cutlass_s4s4_unified(q3, sc, layer.down_proj.weight, layer.down_proj._scales(), None, o)
             elif tp_on:     # row-parallel down_proj: raw fp32 sums, finished by the next norm
                 k0, k1 = self.tp.k_range(cfg.intermediate_size)

@@ -385,6 +385,29 @@ def add_rms_norm_fp16_partial(out, hidden_out, x, part, w_scale, slices: int, ep
           _chk(x, "x", _F16), _chk(part, "part", _F32), _chk(w_scale, "w_scale", _F16), slices, float(eps), T, H, _stream())
 
 
+def rowwise_scaled_linear_s4s4_partial_slices(M: int, N: int, K: int) -> int:
+    """K slices the s4s4 linear is cut into at this shape (17..32 tokens, one weight tile per workgroup); 0: use the plain entry."""
+    return int(_lib.load().qspec_rowwise_scaled_linear_s4s4_partial_slices(M, N, K))
+
+
+def rowwise_scaled_linear_s4s4_partial(xq, wq, ipart, slices: int):
+    """Raw int32 K-slice sums of xq @ wq^T into ipart [slices, M, N] (finished by add_rms_norm_ipartial)."""
+    M, N, K = xq.shape[0], wq.shape[0], 2 * xq.shape[1]
+    _call("qspec_rowwise_scaled_linear_s4s4_partial", _chk(xq, "xq", (_I8, _U8)), _chk(wq, "wq", (_I8, _U8)),
+          _chk(ipart, "ipart", _I32), M, N, K, slices, _stream())
+    return ipart
+
+
+def add_rms_norm_ipartial(hidden_out, x, ipart, x_scale, w_scale, slices: int, eps: float, q=None, scale=None, out_f16=None):
+    """hidden_out = x + h((sum_s ipart[s]) * x_scale[row] * w_scale[col]) (the s4s4 epilogue + residual add); then the norm of
+    hidden_out: int4 rows q + scale, or fp16 rows out_f16."""
+    H = x.shape[-1]
+    T = x.numel() // H
+    _call("qspec_add_rms_norm_ipartial", _opt(q, "q", _I8), _opt(scale, "scale", _F16), _opt(out_f16, "out_f16", _F16),
+          _chk(hidden_out, "hidden_out", _F16), _chk(x, "x", _F16), _chk(ipart, "ipart", _I32), _chk(x_scale, "x_scale", _F16),
+          _chk(w_scale, "w_scale", _F16), slices, float(eps), T, H, _stream())
+
+
 def w4a16_linear_ksliced(x, wq, w_scale, out, k0: int, k1: int):
     """Row-parallel shard: out = x[:, k0:k1] @ dequant(wq)[:, k0:k1]^T * w_scale (partial sum; caller all-reduces).
     x [M,K] and wq [N,K/2] are the FULL tensors; only the K range is read."""

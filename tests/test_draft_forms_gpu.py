@@ -247,6 +247,42 @@ def test_draft_mlp_block_chain_vs_oracle(ops, oracle, golden_dir):
 
 # ------------------------------------------------------------------ batch 32 (config 3): separate norm + two token tiles
 
+@pytest.mark.parametrize("M", [32, 17, 24])
+def test_down_proj_k_slices_finished_in_the_next_norm(ops, oracle, M):
+    """Draft pass at 17..32 tokens: down_proj as two K slices whose raw int32 sums the NEXT norm adds and finishes (s4s4
+    epilogue + fp16 residual add + LN + int4 quant, or the final fp16 norm) == the plain GEMM followed by add_rms_norm_i4 /
+    _fp16, bit for bit, and == the oracle chain gemm_w4a4 -> add_f16 -> ln_quant_i4."""
+    rng = np.random.default_rng(900 + M)
+    xq, xs = rand_packed(rng, M, I), (rng.random(M) * 0.05 + 0.01).astype(np.float16)
+    wd, wds = rand_packed(rng, H, I), rand_scales(rng, H)
+    hid = rand_hidden(rng, M, H)
+    S = ops.rowwise_scaled_linear_s4s4_partial_slices(M, H, I)
+    assert S == 2 and ops.rowwise_scaled_linear_s4s4_partial_slices(16, H, I) == 0
+    o = torch.empty(M, H, dtype=torch.float16, device=DEV)
+    ops.rowwise_scaled_linear_cutlass_s4s4_unified(dev(xq), dev(xs), dev(wd), dev(wds), None, o)
+    q0 = torch.empty(M, H // 2, dtype=torch.int8, device=DEV); s0 = torch.empty(M, dtype=torch.float16, device=DEV)
+    h0 = dev(hid)
+    ops.add_rms_norm_i4(q0, s0, h0, h0, o, EPS)
+    n0 = torch.empty(M, H, dtype=torch.float16, device=DEV); h0b = dev(hid)
+    ops.add_rms_norm_fp16(n0, h0b, h0b, o, EPS)
+    ipart = torch.empty(S, M, H, dtype=torch.int32, device=DEV)
+    ops.rowwise_scaled_linear_s4s4_partial(dev(xq), dev(wd), ipart, S)
+    q1 = torch.empty_like(q0); s1 = torch.empty_like(s0); h1 = dev(hid)
+    ops.add_rms_norm_ipartial(h1, h1, ipart, dev(xs), dev(wds), S, EPS, q=q1, scale=s1)
+    n1 = torch.empty_like(n0); h1b = dev(hid)
+    ops.add_rms_norm_ipartial(h1b, h1b, ipart, dev(xs), dev(wds), S, EPS, out_f16=n1)
+    torch.cuda.synchronize()
+    # the slices add up to the exact integer product
+    acc = oracle.unpack_i4(xq).astype(np.int64) @ oracle.unpack_i4(wd).astype(np.int64).T
+    assert np.array_equal(host(ipart).astype(np.int64).sum(axis=0), acc)
+    assert torch.equal(h0.view(torch.int16), h1.view(torch.int16)) and torch.equal(h0b.view(torch.int16), h1b.view(torch.int16))
+    assert torch.equal(q0, q1) and torch.equal(s0.view(torch.int16), s1.view(torch.int16))
+    assert torch.equal(n0.view(torch.int16), n1.view(torch.int16))
+    ref_h = oracle.add_f16(hid, oracle.gemm_w4a4(xq, xs, wd, wds))
+    qr, sr, _ = oracle.ln_quant_i4(ref_h, EPS)
+    assert np.array_equal(bits(host(h1)), bits(ref_h)) and np.array_equal(host(q1), qr) and np.array_equal(bits(host(s1)), bits(sr))
+
+
 @pytest.mark.parametrize("M", [32])
 def test_batch32_draft_forms_vs_oracle(ops, oracle, M):
     """Config 3 (k = 5, bs = 32) takes the non-fused branch of model.forward: add_rms_norm_i4 -> qkv_rope_linear ->

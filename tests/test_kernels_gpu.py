@@ -329,6 +329,13 @@ def test_qkv_rope_linear_equals_gemm_then_rope_then_cache(ops, oracle, M, w4a4):
     kc1 = torch.zeros_like(kc0); vc1 = torch.zeros_like(kc0)
     ops.qkv_rope_linear(x, xs, wq, ws, out, pos, cs, kc1, vc1, slots, nq, nkv, d)
     torch.cuda.synchronize()
+    if not w4a4 and M > 16:
+        # W4A16 above 16 rows: w4a16_linear is the M-tiled kernel since round 4, the fused-epilogue entry the 2-D kernel of
+        # gemm.hip (the engine no longer calls it there): two fp32 summation orders, each within 1e-3 of the oracle
+        assert_close_1e3(host(out), host(ref))
+        assert_close_1e3(host(kc1), host(kc0))
+        assert_close_1e3(host(vc1), host(vc0))
+        return
     assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
     assert torch.equal(kc1, kc0) and torch.equal(vc1, vc0)
 
