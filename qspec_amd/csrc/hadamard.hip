@@ -834,6 +834,8 @@ __device__ __forceinline__ float xwg_row_amax(const float* wave_max, int nwaves,
 // PW < EPL * 64 (P = 128 with 16-byte lanes: Llama-2-13B's 13824 = had108 x H128): a wave trip of the FWHT phase covers
 // EPL * 64 / PW rows of P at once -- the lane stages stop below P -- so that the token's row still travels in 1 KiB wave loads,
 // all of them in flight before the first transform (with EPL = P / 64 = 2 a wave took 4-byte lanes and seven dependent trips).
+// (Round 4, measured and rejected: 14 waves = 896 threads for the spread had28 x H512 form -- two rows of the transform per wave
+// instead of 12 waves with two and 4 with one, and exactly 28 x 32 mix items: cycle 7.48 -> 7.565 ms in two alternating runs.)
 template <int EPL, int KH, bool PREACT, int NB = 1, int PW = EPL * 64>  // EPL = elements per lane in the FWHT phase; P = PW; KH = K if specialised, else 0
 __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const f16* __restrict__ gate_up,
                                                                             const f16* __restrict__ hadK,

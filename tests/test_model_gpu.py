@@ -332,6 +332,129 @@ def test_full_depth_llama3_8b_verify_forward_and_cycle(oracle):
     # the noise floor above): median bar as everywhere, no quantile bar, target bars 8e-3 / 2e-2
     _engine_cycle_check(model, oracle, 3, 4, (9, 12, 6, 5), 1, 40, (1e-4, 0.6, 8e-3, 2e-2), sync_kv=True)
 
+def _true_math_verify_forward(model, inp):
+    """The verify forward in UN-ROUNDED math: fp64 throughout (torch on the GPU, test infrastructure), the same weights
+    (int4 x fp16 scale, fp16 embedding / lm_head / cos-sin table taken as the model's parameters), the same op order
+    (quarot_llama.py:363-392), and NO fp16 rounding between stages -- what every fp16 implementation approximates.
+    Returns (normed hidden [T, H], logits [T, V]) as fp64 numpy."""
+    import math
+    cfg = model.config
+    f64 = torch.float64
+    H, I, nq, nkv, d = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    T, eps = inp["T"], cfg.rms_norm_eps
+
+    def unpack(w):       # [N, K/2] int8 -> [N, K] fp64 (low nibble = even k, two's complement)
+        u = w.view(torch.uint8).to(torch.int16)
+        lo, hi = u & 0xF, u >> 4
+        q = torch.stack((lo, hi), dim=-1).reshape(w.shape[0], -1)
+        return torch.where(q >= 8, q - 16, q).to(f64)
+
+    def linear(x, lin):  # x @ (w * s)^T, row blocks to bound the fp64 weight copy
+        out = torch.empty(x.shape[0], lin.weight.shape[0], dtype=f64, device=DEV)
+        sc = lin._scales().to(f64)
+        for n0 in range(0, lin.weight.shape[0], 4096):
+            w = unpack(lin.weight[n0:n0 + 4096])
+            out[:, n0:n0 + 4096] = (x @ w.t()) * sc[n0:n0 + 4096]
+        return out
+
+    def ln(h):
+        mean = h.mean(-1, keepdim=True)
+        var = ((h - mean) ** 2).mean(-1, keepdim=True)
+        return (h - mean) / torch.sqrt(var + eps)
+
+    def sylvester(n):
+        Hm = torch.ones(1, 1, dtype=f64, device=DEV)
+        while Hm.shape[0] < n:
+            Hm = torch.cat((torch.cat((Hm, Hm), 1), torch.cat((Hm, -Hm), 1)), 0)
+        return Hm
+    assert model.head_had_K == 1
+    Hh = sylvester(nq) / math.sqrt(nq)
+    P = I // model.had_K
+    Hp = sylvester(P)
+    hadK = model.had_rem_dim.to(f64) if model.had_rem_dim is not None else None
+    cs = model.cos_sin_cache.to(f64)
+    pos = inp["pos_t"]
+    cos, sin = cs[pos, :d // 2], cs[pos, d // 2:]
+    hidden = model.embed_tokens[inp["ids_t"]].to(f64)
+    bs = inp["kv_np"][0][0].shape[1]
+    q_len = T // len(inp["ctx"])
+    for li, layer in enumerate(model.layers):
+        qkv = linear(ln(hidden), layer.qkv_proj)
+        q = qkv[:, :nq * d].reshape(T, nq, d)
+        k = qkv[:, nq * d:(nq + nkv) * d].reshape(T, nkv, d)
+        v = qkv[:, (nq + nkv) * d:].reshape(T, nkv, d)
+
+        def rope(x):     # neox style: pairs (i, i + d/2)
+            x1, x2 = x[..., :d // 2], x[..., d // 2:]
+            c, s_ = cos[:, None, :], sin[:, None, :]
+            return torch.cat((x1 * c - x2 * s_, x2 * c + x1 * s_), -1)
+        q, k = rope(q), rope(k)
+        kc = torch.from_numpy(inp["kv_np"][li][0]).to(DEV).to(f64).reshape(-1, nkv, d)     # the fp16 HISTORY is given data
+        vc = torch.from_numpy(inp["kv_np"][li][1]).to(DEV).to(f64).reshape(-1, nkv, d)
+        slots = torch.from_numpy(inp["slots"]).to(DEV)
+        kc[slots], vc[slots] = k, v                                                          # this pass's rows: un-rounded
+        attn = torch.empty(T, nq, d, dtype=f64, device=DEV)
+        for b, c in enumerate(inp["ctx"].tolist()):
+            positions = np.arange(c)
+            sl = torch.from_numpy(inp["bt"][b, positions // bs].astype(np.int64) * bs + positions % bs).to(DEV)
+            kb = kc[sl].repeat_interleave(nq // nkv, dim=1)        # [c, nq, d]
+            vb = vc[sl].repeat_interleave(nq // nkv, dim=1)
+            for i in range(q_len):
+                t = b * q_len + i
+                n = c - q_len + i + 1
+                sc_ = torch.einsum("hd,nhd->hn", q[t], kb[:n]) * model.sm_scale
+                attn[t] = torch.einsum("hn,nhd->hd", torch.softmax(sc_, -1), vb[:n])
+        a = torch.einsum("gh,thd->tgd", Hh, attn).reshape(T, nq * d)
+        hidden = hidden + linear(a, layer.o_proj)
+        gu = linear(ln(hidden), layer.gate_up)
+        up, gate = gu[:, :I], gu[:, I:]
+        act = (gate / (1.0 + torch.exp(-gate))) * up
+        y = act.reshape(T, model.had_K, P) @ Hp.t()
+        if hadK is not None:
+            y = torch.einsum("ik,tkj->tij", hadK, y)
+        g = y.reshape(T, I) / math.sqrt(I)
+        hidden = hidden + linear(g, layer.down_proj)
+    normed = ln(hidden)
+    logits = normed @ model.lm_head.to(f64).t()
+    return normed.cpu().numpy(), logits.cpu().numpy()
+
+
+def test_full_depth_distance_to_true_math(oracle):
+    """North_star's "logits within 1e-3" end to end, stated against the TRUTH instead of against an oracle-vs-oracle floor
+    (VERDICT r3): the full-depth verify forward (32 layers, V = 128256, T = 16) in un-rounded fp64 math, and
+    |HIP - true| <= 1.1 x |oracle - true| at the median and the 99 % quantile, for the normed hidden state and the logits.
+    Both fp16 pipelines sit a few 1e-3 from the truth (32 layers of fp16 roundings on the residual stream); the claim is
+    that the HIP path is not further from it than the reference arithmetic's restatement is."""
+    from oracle.model import OracleModel
+    from qspec_amd.model import CONFIGS, QuarotLlamaForCausalLM, Scratch
+    cfg = CONFIGS["llama-3-8b"]
+    model = QuarotLlamaForCausalLM(cfg, DEV).init_synthetic(seed=0)
+    rng = np.random.default_rng(8)
+    ctx_lens, q_len = [40, 130, 9, 260], 4
+    inp = make_inputs(model, rng, ctx_lens, q_len)
+    true_h, true_l = _true_math_verify_forward(model, inp)
+    om = OracleModel.from_torch_model(model, 16)
+    kv_np = [(k.copy(), v.copy()) for k, v in inp["kv_np"]]
+    ref = om.forward(inp["ids"], inp["pos"], kv_np, inp["slots"], inp["bt"], inp["ctx"], inp["q_start"], False)
+    ref_l = om.logits(ref)
+    s = Scratch(cfg, inp["T"], len(ctx_lens), q_len, inp["n_splits"], DEV)
+    out = model.forward(inp["ids_t"], inp["pos_t"], inp["kv_t"], inp["md"], s, w4a4=False)
+    logits = model.compute_logits(out, s)
+    torch.cuda.synchronize()
+    for what, hip, orc, tru in (("normed hidden", out.cpu().numpy(), ref, true_h), ("logits", logits.cpu().numpy(), ref_l, true_l)):
+        e_hip, e_or = _rel3(hip, tru), _rel3(orc, tru)
+        qh, qo = np.quantile(e_hip, [0.5, 0.99]), np.quantile(e_or, [0.5, 0.99])
+        print(f"full depth, verify T=16, {what}: |HIP - true| / 1e-3 median {qh[0]:.2f} q99 {qh[1]:.2f} max {e_hip.max():.1f};  "
+              f"|oracle - true| median {qo[0]:.2f} q99 {qo[1]:.2f} max {e_or.max():.1f};  |HIP - oracle| median "
+              f"{np.median(_rel3(hip, orc)):.2f}")
+        assert qh[0] <= 1.1 * qo[0] and qh[1] <= 1.1 * qo[1], (what, qh, qo)
+    # the greedy token of both pipelines agrees with the truth's wherever the truth's two best logits are not a near tie
+    top2 = np.sort(true_l, -1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 0.05
+    assert np.array_equal(logits.float().argmax(-1).cpu().numpy()[clear], true_l.argmax(-1)[clear])
+    assert np.array_equal(ref_l.astype(np.float32).argmax(-1)[clear], true_l.argmax(-1)[clear])
+
+
 def test_graph_replay_equals_eager(tiny):
     """The captured hipGraph of the cycle produces the same tokens as the eager cycle (same Philox stream)."""
     from qspec_amd.spec_decode import QSpecEngine
