@@ -211,14 +211,6 @@ int qspec_ln_gate_up_silu_linear_s4s4(const qspec_half* hidden_in, const qspec_h
                                       int intermediate, int K, void* sync_workspace, void* stream);
 int qspec_ln_linear_s4s4_supported(int M, int N, int K);   /* 1 if the two entries above accept the shape */
 
-/* Cache hint: read `bytes` at p (16-byte aligned) with `workgroups` x 256 threads and discard them, which leaves
- * the lines in the 256 MiB Infinity Cache.  Meant for a side stream, concurrently with the latency-bound kernels
- * between two GEMMs, so the next GEMM finds its weights on-die.  No reference counterpart; no effect on results. */
-int qspec_prefetch(const void* p, size_t bytes, int workgroups, void* stream);
-/* Tile-aligned form: workgroup b touches tiles b, b + workgroups, ... (tile_bytes each, from first_tile, ntiles of them)
- * -- the ranges the streaming GEMM's workgroup b reads -- so the lines wait in that workgroup's own XCD's L2. */
-int qspec_prefetch_tiles(const void* p, size_t tile_bytes, int first_tile, int ntiles, int workgroups, void* stream);
-
 /* Tensor-parallel views of the SAME buffers (no reference counterpart: the reference QSpec model has no TP).
  * _ksliced: row-parallel shard = a K range of x [M, *] (row stride ldx halves) and of wq [N, *] (row stride ldw_bytes);
  *           the caller all-reduces the partial outputs.

@@ -43,8 +43,6 @@ SIGNATURES = {
                                            _i, _i, _vp, _vp]),
     "qspec_ln_gate_up_silu_linear_s4s4": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "qspec_ln_linear_workspace_bytes": (_sz, []),
-    "qspec_prefetch": (_i, [_vp, _sz, _i, _vp]),
-    "qspec_prefetch_tiles": (_i, [_vp, _sz, _i, _i, _i, _vp]),
     "qspec_ln_linear_s4s4_supported": (_i, [_i, _i, _i]),
     "qspec_rowwise_scaled_linear_s4s4_residual": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_rowwise_scaled_linear_s4s4_residual_supported": (_i, [_i, _i, _i]),
@@ -101,6 +99,14 @@ SIGNATURES = {
 }
 
 
+# entry points only the experimental build exports (csrc/experimental/qspec_hip_experimental.h): bound when present
+EXPERIMENTAL_SIGNATURES = {
+    "qspec_prefetch": (_i, [_vp, _sz, _i, _vp]),
+    "qspec_prefetch_tiles": (_i, [_vp, _sz, _i, _i, _i, _vp]),
+}
+EXPERIMENTAL_LIB_PATH = os.path.join(_HERE, "csrc", "libqspec_hip_experimental.so")
+
+
 def header_symbols(path: str = HEADER_PATH):
     """Every function name declared in include/qspec_hip.h."""
     text = open(path).read()
@@ -133,6 +139,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in EXPERIMENTAL_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 

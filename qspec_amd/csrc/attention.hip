@@ -1291,7 +1291,7 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
     if (n_splits < 1 || n_splits > QS_ATT_MAXSPLIT) return -3;
     const int bs_log2 = ilog2_exact(block_size), group_log2 = ilog2_exact(nq / nkv);
     if (bs_log2 < 0 || group_log2 < 0) return -5;  // block size and GQA group must be powers of two
-    static const int fa_env = getenv("QSPEC_ATTN_PREFILL") ? atoi(getenv("QSPEC_ATTN_PREFILL")) : 1;   // dev knob
+    static const int fa_env = QS_DEV_KNOB("QSPEC_ATTN_PREFILL", 1);
     if (fa_env && n_splits == 1 && (max_q_len << group_log2) >= 2 * QS_FA_ROWS) {   // prompt-sized queries
         const int n_rb64 = ((max_q_len << group_log2) + QS_FA_ROWS - 1) / QS_FA_ROWS;
         const size_t Tm = (size_t)n_seqs * max_q_len;
@@ -1316,12 +1316,12 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
     // Partials only, and a split may be longer than one 128-key chunk (large batch: one split; long contexts): the keys
     // go over the waves of a workgroup instead of through barrier-separated chunk phases (bs=32: 21.1 -> 20.3 us, 4 K
     // context: 20.8 -> 19.1 us per launch; equal at 64 keys per split).  QSPEC_ATTN_WAVES=0/1 forces either kernel.
-    static const int aw_env = getenv("QSPEC_ATTN_WAVES") ? atoi(getenv("QSPEC_ATTN_WAVES")) : -1;
+    static const int aw_env = QS_DEV_KNOB("QSPEC_ATTN_WAVES", -1);
     const bool long_splits = ((int64_t)max_blocks << bs_log2) > (int64_t)QS_ATT_CHUNK * n_splits;
     if (!out && (aw_env >= 0 ? aw_env != 0 : long_splits)) {
         // QSPEC_ATTN_NW=8 (dev knob): eight waves, two per SIMD -- measured SLOWER (config 3: 21.6 against 19.1 us back to
         // back): the kernel is not short of bytes in flight
-        static const int nw_env = getenv("QSPEC_ATTN_NW") ? atoi(getenv("QSPEC_ATTN_NW")) : 0;
+        static const int nw_env = QS_DEV_KNOB("QSPEC_ATTN_NW", 0);
         const int nw = nw_env == 8 ? 8 : 4;
         const size_t wave_lds = QS_AW_KEYS * QS_ATT_VSTRIDE * 2 + 2 * 16 * 40 * 2;
         const size_t wlds = std::max((size_t)nw * wave_lds, (size_t)nw * 16 * (128 + 2) * 4);
@@ -1338,22 +1338,31 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
                            wlds, st, q, q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, nq, \
                            nkv, bs_log2, group_log2, sm_scale, n_splits, n_rb, ws_o, ws_ml);                               \
     } while (0)
-        static const int fast_env = getenv("QSPEC_ATTN_FAST") ? atoi(getenv("QSPEC_ATTN_FAST")) : 1;   // dev knob
+        static const int fast_env = QS_DEV_KNOB("QSPEC_ATTN_FAST", 1);
         if (max_blocks <= 128 && bs_log2 >= 4 && fast_env) {   // two uniform table entries per 32-key slice
+#ifdef QS_EXPERIMENTAL
             if (nw == 8) QS_AW_LAUNCH(true, 8, true);
-            else QS_AW_LAUNCH(true, 4, true);
+            else
+#endif
+            QS_AW_LAUNCH(true, 4, true);
         } else if (max_blocks <= 128) {
+#ifdef QS_EXPERIMENTAL
             if (nw == 8) QS_AW_LAUNCH(true, 8, false);
-            else QS_AW_LAUNCH(true, 4, false);
+            else
+#endif
+            QS_AW_LAUNCH(true, 4, false);
         } else {
+#ifdef QS_EXPERIMENTAL
             if (nw == 8) QS_AW_LAUNCH(false, 8, false);
-            else QS_AW_LAUNCH(false, 4, false);
+            else
+#endif
+            QS_AW_LAUNCH(false, 4, false);
         }
 #undef QS_AW_LAUNCH
         return 0;
     }
     // more workgroups than CUs: occupancy (two per CU) instead of the in-workgroup prefetch
-    static const int pf_env = getenv("QSPEC_ATTN_PF") ? atoi(getenv("QSPEC_ATTN_PF")) : -1;   // dev knob
+    static const int pf_env = QS_DEV_KNOB("QSPEC_ATTN_PF", -1);
     const bool pf = pf_env >= 0 ? pf_env != 0 : (size_t)n_seqs * nkv * n_rb * n_splits <= 256;
     const bool btreg = max_blocks <= 128;
 #define QS_ATT_LAUNCH(PFV, BTV)                                                                                        \

@@ -32,22 +32,14 @@ static int finish(const char* op, int rc) {
 
 // QSPEC_OLD_GEMM=1 keeps the first-generation one-tile-per-workgroup W4A4 kernel (A/B measurements)
 static bool use_stream() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("QSPEC_OLD_GEMM");
-        v = (e && e[0] == '1') ? 0 : 1;
-    }
-    return v == 1;
+    static const int old = QS_DEV_KNOB("QSPEC_OLD_GEMM", 0);
+    return old != 1;
 }
 // smallest M routed to the M-tiled W4A16 kernel (gemm_tiled.hip); QSPEC_TILED_MIN_M overrides (0 disables)
 static int tiled_min_m() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("QSPEC_TILED_MIN_M");
-        v = e ? atoi(e) : 17;   // (33 until round 4: 17..32 rows ran the 2-D kernel of gemm.hip -- 70B gate_up at 32 rows 83.8 us)
-        if (v <= 0) v = 1 << 30;
-    }
-    return v;
+    // (33 until round 4: 17..32 rows ran the 2-D kernel of gemm.hip -- 70B gate_up at 32 rows 83.8 us)
+    static const int v = QS_DEV_KNOB("QSPEC_TILED_MIN_M", 17);
+    return v <= 0 ? (1 << 30) : v;
 }
 
 extern "C" {
@@ -634,6 +626,7 @@ int qspec_add_rms_norm_ipartial(int8_t* q, qspec_half* scale, qspec_half* out_f1
     return finish(op, qspec::ln_ipartial(CH(x), ipart, CH(xs), CH(ws), slices, H(hidden_out), H(out_f16), q, H(scale), eps, tokens,
                                          hidden, ST));
 }
+#ifdef QS_EXPERIMENTAL   // (csrc/experimental/qspec_hip_experimental.h)
 int qspec_prefetch(const void* p, size_t bytes, int workgroups, void* stream) {
     const char* op = "qspec_prefetch";
     if (bytes == 0) return 0;
@@ -648,6 +641,7 @@ int qspec_prefetch_tiles(const void* p, size_t tile_bytes, int first_tile, int n
     if (((uintptr_t)p) % 16 || tile_bytes % 16) return fail("%s: pointer and tile_bytes must be multiples of 16", op);
     return finish(op, qspec::prefetch_tiles(p, tile_bytes, first_tile, ntiles, workgroups, ST));
 }
+#endif
 int qspec_ln_linear_s4s4_supported(int M, int N, int K) { return qspec::gemm_w4a4_stream_supported(M, N, K, true) ? 1 : 0; }
 
 }  // extern "C"

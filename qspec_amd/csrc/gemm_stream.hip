@@ -494,24 +494,7 @@ __device__ __forceinline__ void lnw_compute(const StreamArgs& a, int row, LnwReg
 #endif
 }
 
-// ------------------------------------------------------------------ loader / consumer form ("engine"), M <= 4
-// The same GEMM with the weights brought in by LDS-DMA (global_load_lds_dwordx4 nt) instead of register loads:
-//   * waves 4..7 = LOADERS, one per SIMD.  They do nothing but issue 1-KiB LDS-DMA loads of the workgroup's weight tiles
-//     into a ring of 16-KiB fills in LDS (fill = the f-th KiB of each of a tile's 16 rows; loader lw moves rows lw, lw+4,
-//     lw+8, lw+12), run ahead of the consumers by up to the ring, and publish per-loader `landed` counters behind counted
-//     `s_waitcnt vmcnt`.  A loader that blocks at the issue (a CU holds ~32 KB of loads in flight) blocks nobody else.
-//     Measured floor (scripts/micro/ldsdma.hip, nobody consuming, launch boundary included): gate_up 9.65 us, qkv 3.6,
-//     o 2.75, down 5.6 -- against 10.5 / 3.9 / 3.0 / 6.7 for the register path's PURE read of the same bytes and
-//     13.3 / 6.7 / 4.85 / 8.4 for the register kernels as the cycle runs them.  ONE loader wave per CU reaches only 2.5 TB/s.
-//   * waves 0..3 = CONSUMERS: first the prologue (norm + int4 quant of row `wave`, one wave per row, no barrier inside:
-//     lnw_*), then per fill: wait for the four `landed` counters, four ds_read_b128 fragments (conflict-free: the row
-//     XOR swizzle sits on the loaders' SOURCE addresses, the LDS image stays lane-linear), publish `consumed`, 8 MFMAs.
-//     Consumer cw owns K steps cw, cw+4, cw+8, cw+12 of every fill; its activation fragments stay in registers.
-//   * no s_barrier after the first one (row requests before weight requests): everything else is LDS counters, so a
-//     loader never waits for a consumer except for ring space and a consumer never waits for a loader except for data.
-//   * wave 0 is also the epilogue wave (M <= 4: 64 (token, column) pairs): it sums the four int32 partials (exact: same
-//     bits as any other partition of K) once waves 1..3 have posted theirs and applies the same epilogue expressions.
-// Every spin is bounded (a lost partner ends in wrong results and a failed test, not in a hung GPU).
+// global_load_lds_dwordx4: 16 bytes per lane from memory straight into LDS (lane-linear image at lds_dst); nt = non-temporal.
 template <int NT>
 __device__ __forceinline__ void glds16(const void* gsrc, u32 lds_dst) {
     u32 keep;
@@ -522,391 +505,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, u32 lds_dst) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-// Flag words live in LDS and are accessed through address-space-3 pointers: a VOLATILE access through a generic pointer
-// is not rewritten by hipcc's address-space inference and becomes flat_load / flat_store (sc0 sc1) + s_waitcnt vmcnt(0) --
-// on a loader that drains every LDS-DMA load in flight at each publish (first version of this kernel: 15.9 us).
-typedef __attribute__((address_space(3))) int lds_int_t;
-typedef __attribute__((address_space(3))) i32x4 lds_i32x4_t;
-__device__ __forceinline__ int lds_min4(const int* p) {   // four counters, one broadcast ds_read_b128
-    const i32x4 v = *reinterpret_cast<const volatile lds_i32x4_t*>((const lds_int_t*)p);
-    return min(min(v[0], v[1]), min(v[2], v[3]));
-}
-__device__ __forceinline__ int lds_flag_load(const int* p) { return *reinterpret_cast<const volatile lds_int_t*>((const lds_int_t*)p); }
-__device__ __forceinline__ void lds_flag_store(int* p, int v) { *reinterpret_cast<volatile lds_int_t*>((lds_int_t*)p) = v; }
-#define QS_ENG_SPIN_GUARD (1 << 20)
-#ifndef QS_ENG_RING
-#define QS_ENG_RING 8    // fills of 16 KiB
+#ifdef QS_EXPERIMENTAL
+#include "experimental/w4a4_engine.inc"   // loader / consumer ("engine") form of the draft GEMMs: QSPEC_ENGINE=1
 #endif
-#ifndef QS_ENG_DEPTH
-#define QS_ENG_DEPTH 5   // fills a loader keeps in flight behind the one it publishes (4 KiB each): throughput = bytes in
-                         // flight / latency (~3 us under load), and what LDS-DMA can keep in flight is bounded by ring space
-                         // only -- 64 KB per CU in flight gave 20 GB/s per CU, the floor needs >= 90 KB
-#endif
-#ifndef QS_ENG_NT
-#define QS_ENG_NT 1
-#endif
-#ifndef QS_ENG_EARLY
-#define QS_ENG_EARLY 1   // 1: the loaders start at once (one barrier, right at the start, publishes the zeroed flags);
-#endif                   // 0: they wait until the consumers' row requests are out
-#define QS_ENG_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
-enum { ENG_FLAGS = 0, ENG_XS = 256, ENG_XQ = 512 };
-__host__ __device__ inline size_t eng_red_off(int K) { return ENG_XQ + (size_t)4 * (K / 2 + 32); }
-__host__ __device__ inline size_t eng_ring_off(int K) { return (eng_red_off(K) + 4 * 4 * 256 + 1023) & ~(size_t)1023; }
-#ifdef QS_ENG_STAMPS
-__host__ __device__ inline size_t eng_lds_bytes(int K, int R) { return eng_ring_off(K) + (size_t)R * 16384 + 6 * 64 * 8; }
-#else
-__host__ __device__ inline size_t eng_lds_bytes(int K, int R) { return eng_ring_off(K) + (size_t)R * 16384; }
-#endif
-
-#ifdef QS_ENG_STAMPS
-__device__ long long g_engst[6][64];   // [consumer wave 0 | loaders 0..3 | epilogue wave] of workgroup 100, s_memrealtime (100 MHz)
-// stamps go to LDS (no vector-memory traffic of their own: a global store would count in the loaders' vmcnt) and are
-// copied out at the end
-#define QS_ESTAMP(who, i) do { long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-                               if (lane == 0 && (i) < 64) est[(who) * 64 + (i)] = t_; } while (0)
-#define QS_ESTAMP_DUMP(who) do { if (blockIdx.x == 100) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_engst[who][lane] = est[(who) * 64 + lane]; } } while (0)
-#else
-#define QS_ESTAMP(who, i)
-#define QS_ESTAMP_DUMP(who)
-#endif
-#ifndef QS_ENG_NC
-#define QS_ENG_NC 4      // consumer waves
-#endif
-#ifndef QS_ENG_NE
-#define QS_ENG_NE 2      // epilogue waves, tile ti -> wave ti % NE (an epilogue is a ~0.4 us dependent chain per tile)
-#endif
-template <int EPI, int PRO, int NI, int FPT /* fills per tile = K / 2048 */, int R /* ring, in fills */>
-__global__ __launch_bounds__((QS_ENG_NC + 4 + QS_ENG_NE) * 64) void gemm_w4a4_engine_kernel(StreamArgs a) {
-    static_assert(PRO == PRO_LN1S || PRO == PRO_LNS || PRO == PRO_Q, "prologues built so far");
-    static_assert(EPI == SEPI_GATEUP || EPI == SEPI_RESID, "epilogues built so far");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NC = QS_ENG_NC, NE = QS_ENG_NE;
-    constexpr bool AF_REGS = FPT * 4 <= 8;   // the wave's activation fragments live in registers (else: read per step from LDS)
-    constexpr int SPF = 16 / NC;   // K steps of a fill per consumer wave
-    static_assert(R >= 7 && R <= 9, "ring: two fills per loader in flight");
-    static_assert(NC == 4, "consumer cw takes unit cw (K steps 4 cw .. 4 cw + 3) of every fill");
-    static_assert(NE == 1 || NE == 2 || NE == 4, "epilogue waves (4 slots of partial sums)");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Kb = a.K >> 1, RS = Kb + 32;
-    int* flags = reinterpret_cast<int*>(smem + ENG_FLAGS);
-    int* landed = flags;          // [4] fills of loader lw that have landed
-    int* consumed = flags + 4;    // [8] fills whose fragments consumer cw holds in registers
-    int* done = flags + 12;       // [8] tiles whose partial sums consumer cw has posted
-    int* rows_done = flags + 20;  // [4] row r is quantised
-    int* epi_done = flags + 24;   // [4] per slot of `red`: tiles of that slot the epilogue has taken out
-    float* xs_lds = reinterpret_cast<float*>(smem + ENG_XS);
-    unsigned char* xq_lds = smem + ENG_XQ;
-    int* red = reinterpret_cast<int*>(smem + eng_red_off(a.K));   // [4 tile slots][NC waves][64]: (token m < 4, column c) at m * 16 + c
-    unsigned char* ring = smem + eng_ring_off(a.K);
-#ifdef QS_ENG_STAMPS
-    long long* est = reinterpret_cast<long long*>(ring + (size_t)R * 16384);
-#endif
-    static_assert(FPT <= R, "");
-    const int my_tiles = (a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1
-    const int n_fills = my_tiles * FPT;
-    auto min_consumed = [&]() { return NC == 8 ? min(lds_min4(consumed), lds_min4(consumed + 4)) : lds_min4(consumed); };
-    auto min_done = [&]() { return NC == 8 ? min(lds_min4(done), lds_min4(done + 4)) : lds_min4(done); };
-    if (tid < 32) flags[tid] = 0;
-    QS_ENG_BARRIER();   // the zeroed flags are visible to every wave
-
-    if (wave >= NC && wave < NC + 4) {   // ---------------------------------------------------------------- loaders
-        const int lw = wave - NC;
-        const u32 ring0 = (u32)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)ring;
-#ifdef QS_ENG_LOADER_PRIO
-        __builtin_amdgcn_s_setprio(QS_ENG_LOADER_PRIO);   // (measured: prio 3 starves the norm wave on the same SIMD)
-#endif
-        QS_ESTAMP(1 + lw, 0);
-        if (!QS_ENG_EARLY) QS_ENG_BARRIER();   // the consumers' row requests are out (the CU's L1 returns in request order)
-        QS_ESTAMP(1 + lw, 1);
-        // Loader lw moves fills lw, lw + 4, lw + 8, ... WHOLE, as four UNITS of four LDS-DMA loads: unit u = K steps 4u .. 4u+3
-        // (256 bytes of each of the 16 rows; one load = 4 rows x 256 B, lane l -> row l / 16, 16-byte piece (l % 16) ^ row),
-        // which is exactly what consumer u needs of the fill.  It keeps 16 loads in flight and publishes in units: what it
-        // learns from `vmcnt(16)` behind unit j is that unit j - 4 has landed -- and since the memory system paces the issue
-        // (a new load goes out when an old one completes) that is within one unit of the landing itself, at every point of
-        // the stream including its end (drained with vmcnt 12, 8, 4, 0).  Four loaders x 16 KB in flight = what the CU's
-        // queues hold anyway.  (Earlier forms published whole fills behind the issue of the NEXT whole fill: the last two
-        // fills of every loader became visible in one burst at the very end and the consumers needed 1.3 us to work it off.)
-        int units = 0;   // own units issued
-        for (int n = lw; n < n_fills; n += 4) {
-            if (n >= R) {   // ring space: every consumer has taken fill n - R out
-                int guard = 0;
-                while (min_consumed() < n - R + 1 && ++guard < QS_ENG_SPIN_GUARD) __builtin_amdgcn_s_sleep(1);
-            }
-            const int ti = n / FPT, f = n - ti * FPT;
-            const int tile = blockIdx.x + ti * (int)gridDim.x;
-            const u32 dst = ring0 + (u32)(n % R) * 16384u;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++) {
-                    const int row = 4 * gq + (lane >> 4);
-                    const uint8_t* src = a.wq + (size_t)stile_row<EPI>(tile, row, a.I) * Kb + (size_t)f * 1024 + u * 256 +
-                                         (((lane & 15) ^ row) << 4);
-                    glds16<QS_ENG_NT>(src, dst + (u32)(u * 4 + gq) * 1024u);
-                }
-                units++;
-                if (units > 4) {
-                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                    if (lane == 0) lds_flag_store(landed + lw, units - 4);
-                }
-            }
-            QS_ESTAMP(1 + lw, 2 + (units >> 2));       // own fill issued
-        }
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        if (lane == 0) lds_flag_store(landed + lw, units - 3);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        if (lane == 0) lds_flag_store(landed + lw, units - 2);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        if (lane == 0) lds_flag_store(landed + lw, units - 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) lds_flag_store(landed + lw, units);
-        const int own = units >> 2;
-        QS_ESTAMP(1 + lw, 3 + own);
-        QS_ESTAMP_DUMP(1 + lw);
-        return;
-    }
-
-    const int c = lane & 15, m = lane >> 4;   // epilogue lanes: (token m, tile column c)
-    if (wave >= NC + 4) {   // ---------------------------------------------------------------- epilogue waves
-        const int ew = wave - (NC + 4);
-        if (!QS_ENG_EARLY) QS_ENG_BARRIER();
-        const bool ethread = m < a.M;
-        const int mc = m < a.M ? m : 0;
-        int tile = blockIdx.x + ew * (int)gridDim.x;
-        // The channel scales of ALL this wave's tiles are requested now, before the loaders have filled the CU's memory
-        // queue: the vector L1 returns in request order across waves, a 2-byte load issued mid-stream waits behind ~64 KB
-        // of LDS-DMA (2 us; first version: every epilogue sat in s_waitcnt vmcnt(0) for its scale).
-        constexpr int MAXE = EPI == SEPI_RESID ? 2 : 8;   // tiles per epilogue wave (host: ntiles <= 256 * NE * MAXE)
-        f16 swn_all[MAXE], res_all[MAXE];
-#pragma unroll
-        for (int i = 0; i < MAXE; i++) {
-            const int tl = min(blockIdx.x + (ew + i * NE) * (int)gridDim.x, a.ntiles - 1);   // clamped: no branch around a load
-            swn_all[i] = a.ws[stile_row<EPI>(tl, c, a.I)];
-            if (EPI == SEPI_RESID) res_all[i] = a.resid_in[(size_t)mc * a.N + tl * 16 + c];   // the residual element
-        }
-        float xs_pre = 0.0f;
-        if (PRO == PRO_Q) xs_pre = h2f(a.xs[mc]);
-        {
-            int guard = 0;
-            while (lds_min4(rows_done) < 1 && ++guard < QS_ENG_SPIN_GUARD) __builtin_amdgcn_s_sleep(2);
-            asm volatile("" ::: "memory");
-        }
-        const float xs_m = PRO == PRO_Q ? xs_pre : xs_lds[mc];
-        int taken = 0;
-#pragma unroll
-        for (int i = 0; i < MAXE; i++) {
-            const int ti = ew + i * NE;
-            if (ti >= my_tiles) break;
-            const f16 swn = swn_all[i];
-            int guard = 0;
-            while (min_done() < ti + 1 && ++guard < QS_ENG_SPIN_GUARD) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-            const int* rb = red + (ti & 3) * (NC * 64);
-            int sum = 0;
-#pragma unroll
-            for (int w2 = 0; w2 < NC; w2++) sum += rb[w2 * 64 + lane];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // the slot's sums are in registers.  (NE < 4: a wave serves slots ti & 3 = ew, ew + NE, ...; each slot's counter
-            // counts the tiles taken out of THAT slot: tile ti is number ti / 4 + 1 of slot ti & 3)
-            if (lane == 0) lds_flag_store(epi_done + (ti & 3), (ti >> 2) + 1);
-            taken++;
-            const float v = ((float)(sum >> 8) * xs_m) * h2f(swn);  // both operands carried a factor 16
-            const f16 hv = f2h(v);
-            if (EPI == SEPI_RESID) {   // hidden = residual + proj_out, an fp16 add of two fp16 tensors (quarot_llama.py:380,390)
-                if (ethread) a.resid_out[(size_t)m * a.N + tile * 16 + c] = f2h(h2f(res_all[i]) + h2f(hv));
-            }
-            if (EPI == SEPI_GATEUP) {
-                const f16 partner = u2h((uint16_t)__shfl_xor((int)h2u(hv), 8, 64));
-                if (ethread && c < 8) {  // hv = up, partner = gate
-                    const float gt = h2f(partner);
-                    const float act = h2f(f2h(gt / (1.0f + qexpf(-gt))));
-                    a.out[(size_t)m * a.I + tile * 8 + c] = f2h(act * h2f(hv));
-                }
-            }
-            if (ew == 0) QS_ESTAMP(5, ti);
-            tile += NE * (int)gridDim.x;
-        }
-        if (ew == 0) QS_ESTAMP_DUMP(5);
-        return;
-    }
-
-    // ---------------------------------------------------------------- consumers
-    const int cw = wave;
-    const int r = lane & 15, g = lane >> 4;
-    if constexpr (PRO == PRO_Q) {   // (xq, xs) given: consumer cw copies packed row cw into LDS (16 bytes per lane and pass)
-        const int row = cw < a.M ? cw : 0;
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xq) + (size_t)row * Kb;
-        for (int o = lane * 16; o < Kb; o += 1024)
-            *reinterpret_cast<u32x4*>(xq_lds + (size_t)cw * RS + o) = *reinterpret_cast<const u32x4*>(src + o);
-        if (!QS_ENG_EARLY) QS_ENG_BARRIER();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) lds_flag_store(rows_done + cw, 1);
-        int guard = 0;
-        while (lds_min4(rows_done) < 1 && ++guard < QS_ENG_SPIN_GUARD) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-    } else {   // prologue: norm + int4 quant of row cw (consumers 0..3; the others only wait)
-        constexpr bool HASD = PRO == PRO_LNS;
-        LnwRegs<NI> rg;
-        if (cw == 0) QS_ESTAMP(0, 0);
-        if (cw < 4) lnw_load<NI, HASD>(a, cw, rg);   // (wave-uniform branch; the loads it guards are this wave's first)
-        __builtin_amdgcn_sched_barrier(0);
-        if (cw == 0) QS_ESTAMP(0, 1);
-        if (!QS_ENG_EARLY) QS_ENG_BARRIER();
-        if (cw == 0) QS_ESTAMP(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (cw < 4) {
-            if (cw < a.M) lnw_compute<NI, HASD>(a, cw, rg, xq_lds, RS, xs_lds, blockIdx.x == 0 && a.hidden_out != nullptr);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (cw == 0) QS_ESTAMP(0, 3);     // own row quantised
-            if (lane == 0) lds_flag_store(rows_done + cw, 1);
-        }
-        int guard = 0;
-        while (lds_min4(rows_done) < 1 && ++guard < QS_ENG_SPIN_GUARD) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-        if (cw == 0) QS_ESTAMP(0, 4);     // all rows there
-    }
-    // this wave's activation fragments: steps cw, cw + NC, ... of every KiB piece of the row
-    const unsigned char* arow = xq_lds + (size_t)(r & 3) * RS + g * 16 + (4 * cw) * 64;   // + f * 1024 + q * 64
-    constexpr int NAF = AF_REGS ? FPT * SPF : 1;
-    i32x4 af0[NAF], af1[NAF];
-    if constexpr (AF_REGS) {
-#pragma unroll
-        for (int f = 0; f < FPT; f++)
-#pragma unroll
-            for (int q = 0; q < SPF; q++) {
-                const u32x4 av = *reinterpret_cast<const u32x4*>(arow + f * 1024 + q * 64);
-                af0[f * SPF + q] = widen16(av[0], av[1]);
-                af1[f * SPF + q] = widen16(av[2], av[3]);
-            }
-    }
-    // fragment address inside a fill: unit cw, load r / 4 of the unit, lane (r % 4) * 16 + ((step q * 4 + g) ^ r)
-    u32 foff[SPF];
-#pragma unroll
-    for (int q = 0; q < SPF; q++)
-        foff[q] = (u32)(cw * 4 + (r >> 2)) * 1024u + (u32)((((r & 3) << 4) | ((q * 4 + g) ^ r)) << 4);
-    if (cw == 0) QS_ESTAMP(0, 5);
-    // Software pipeline over the fills: the flags AND the fragments of fill n + 1 are read speculatively (flags first:
-    // LDS executes a wave's accesses in order, so fragments read behind flags that already said "landed" are the landed
-    // bytes) while fill n is widened and multiplied; only a fill that had not landed yet is polled for and read again.
-    // One LDS round trip per fill on the critical path instead of three; FPT independent accumulator chains.
-    typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
-    const __attribute__((address_space(3))) unsigned char* ring3 = (const __attribute__((address_space(3))) unsigned char*)ring;
-    struct Spec {
-        i32x4 fl;
-        u32x4 w[SPF];
-    };
-    auto spec_load = [&](Spec& x, int slot_i) {
-        x.fl = *reinterpret_cast<const volatile lds_i32x4_t*>((const lds_int_t*)landed);
-#pragma unroll
-        for (int q = 0; q < SPF; q++)
-            x.w[q] = *reinterpret_cast<const volatile lds_u32x4_t*>(ring3 + (size_t)slot_i * 16384 + foff[q]);
-    };
-    auto confirm = [&](Spec& x, int nn, int slot_i) {   // fill nn is in x.w when this returns
-        const int who = nn & 3, need = 4 * (nn >> 2) + cw + 1;   // unit cw of own fill nn / 4 of loader nn % 4
-        const int have = who == 0 ? x.fl[0] : (who == 1 ? x.fl[1] : (who == 2 ? x.fl[2] : x.fl[3]));
-        if (have < need) {   // (wave-uniform)
-            int guard = 0;
-            while (lds_flag_load(landed + who) < need && ++guard < QS_ENG_SPIN_GUARD) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-            for (int q = 0; q < SPF; q++)
-                x.w[q] = *reinterpret_cast<const volatile lds_u32x4_t*>(ring3 + (size_t)slot_i * 16384 + foff[q]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) lds_flag_store(consumed + cw, nn + 1);
-    };
-    int n = 0, cslot = 0;
-    Spec sp[2];
-    spec_load(sp[0], 0);
-    for (int ti = 0; ti < my_tiles; ti++) {
-        i32x4 acc[FPT];
-#pragma unroll
-        for (int f = 0; f < FPT; f++) {
-            acc[f] = i32x4{0, 0, 0, 0};
-            Spec& cur = sp[f & 1];
-#ifdef QS_ENG_STAMPS2
-            if (cw == 0 && n >= 10) QS_ESTAMP(0, 20 + 5 * (n - 10) + 0);   // before confirm
-#endif
-            confirm(cur, n, cslot);
-            if (cw == 0) QS_ESTAMP(0, 6 + n);     // fill n in registers
-            cslot = cslot + 1 == R ? 0 : cslot + 1;
-            n++;
-            if (n < n_fills) spec_load(sp[(f + 1) & 1], cslot);
-#ifdef QS_ENG_STAMPS2
-            if (cw == 0 && n - 1 >= 10) QS_ESTAMP(0, 20 + 5 * (n - 11) + 1);   // next spec loads issued (+ their wait: the stamp drains lgkmcnt)
-#endif
-            u32x4 av[SPF];
-            if constexpr (!AF_REGS) {
-#pragma unroll
-                for (int q = 0; q < SPF; q++) av[q] = *reinterpret_cast<const u32x4*>(arow + f * 1024 + q * 64);
-            }
-#pragma unroll
-            for (int q = 0; q < SPF; q++) {
-                const i32x4 b0 = widen16(cur.w[q][0], cur.w[q][1]), b1 = widen16(cur.w[q][2], cur.w[q][3]);
-                const i32x4 a0 = AF_REGS ? af0[AF_REGS ? f * SPF + q : 0] : widen16(av[q][0], av[q][1]);
-                const i32x4 a1 = AF_REGS ? af1[AF_REGS ? f * SPF + q : 0] : widen16(av[q][2], av[q][3]);
-                acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc[f], 0, 0, 0);
-                acc[f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc[f], 0, 0, 0);
-            }
-#ifdef QS_ENG_STAMPS2
-            if (cw == 0 && n - 1 >= 10) {
-                asm volatile("" :: "v"(acc[f]));   // (the MFMAs have been issued; s_memrealtime does not wait for their results)
-                QS_ESTAMP(0, 20 + 5 * (n - 11) + 2);
-            }
-#endif
-        }
-#pragma unroll
-        for (int f = 1; f < FPT; f++) acc[0] = acc[0] + acc[f];
-        // post this wave's partial sums into slot ti % 4 of `red` (free once the epilogue has taken tile ti - 4 out of it)
-        if (ti >= 4) {
-            int guard = 0;
-            while (lds_flag_load(epi_done + (ti & 3)) < (ti >> 2) && ++guard < QS_ENG_SPIN_GUARD) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-        }
-        // (the MFMA leaves (token m, column c) in acc[m & 3] of lane (m >> 2) * 16 + c: M <= 4 -> lanes 0..15 hold it all)
-        int* rb = red + (ti & 3) * (NC * 64);
-        if (lane < 16) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) rb[cw * 64 + i * 16 + lane] = acc[0][i];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) lds_flag_store(done + cw, ti + 1);
-#ifdef QS_ENG_STAMPS2
-        if (cw == 0 && n - 1 >= 10) QS_ESTAMP(0, 20 + 5 * (n - 11) + 3);   // tile posted
-#endif
-    }
-    if (cw == 0) QS_ESTAMP_DUMP(0);
-}
-
-// QSPEC_ENGINE=1 selects the loader / consumer forms where they exist (gate_up + norm and down_proj + residual at M <= 4).
-// OFF by default: measured in round 3 (same box, same graph, cold weights) the gate_up form runs 12.5-13.0 us against
-// 13.2-13.4 for the register kernel and the down_proj form 10.4 against 8.5, although the loaders alone reach the LDS-DMA
-// floor (9.65 / 5.6 us): the four consumer waves take ~0.45 us per 16-KiB fill where their instruction count says ~0.2,
-// and run 1-2 us behind the data at the end of the stream ("Stage A").  Bit-identical to the register forms.
-static int g_engine = -1;
-static bool engine_on() {
-    if (g_engine < 0) {
-        const char* e = getenv("QSPEC_ENGINE");
-        g_engine = (e && e[0] == '1') ? 1 : 0;
-    }
-    return g_engine != 0;
-}
-template <int EPI, int PRO, int NI, int FPT, int R>
-static int launch_engine_inst(const StreamArgs& a, hipStream_t st) {
-    const size_t lds = eng_lds_bytes(a.K, R);
-    if (lds > 160 * 1024) return -7;
-    static bool attr_set = false;  // per instantiation
-    auto kern = gemm_w4a4_engine_kernel<EPI, PRO, NI, FPT, R>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -8;
-        attr_set = true;
-    }
-    const int grid = a.ntiles < 256 ? a.ntiles : 256;   // one workgroup per CU
-    if ((a.ntiles + grid - 1) / grid > (EPI == SEPI_RESID ? 2 : 8) * QS_ENG_NE) return -9;   // scales held per epilogue wave
-    hipLaunchKernelGGL(kern, dim3(grid), dim3((QS_ENG_NC + 4 + QS_ENG_NE) * 64), lds, st, a);
-    return 0;
-}
 
 // NW waves; UB steps of 64 packed bytes per wave and batch (K/2 = 64 * NW * UB * NB bytes, NB batches per tile);
 // NI = K / 1024 for the LN prologue (0 otherwise).
@@ -1617,221 +1218,9 @@ static int launch_longk(const StreamArgs& a, hipStream_t st) {
     return 0;
 }
 
-// ------------------------------------------------------------------ self-service LDS-DMA form, M <= 4, K = 4096
-// The register-streaming kernel above with its weight loads replaced by LDS-DMA that every stream wave issues FOR ITSELF:
-// wave w brings its own four 1-KiB pieces of a tile (its K steps of the 16 rows: exactly the bytes its four register loads
-// fetched) into a private quarter of an LDS slot with `global_load_lds_dwordx4 ... nt`, R tiles ahead, and learns that they
-// have landed from its OWN `s_waitcnt vmcnt(4 (R - 1))` -- no loader waves, no flags, no cross-wave hand-off of data.
-// Why it is faster than registers: a register-streaming CU holds ~32 KB of loads in flight (a wave stalls at the issue
-// beyond that) and every tile in flight costs 4 VGPRs x 4 steps; LDS-DMA loads are subject to neither, so R = 4 tiles =
-// 128 KB per CU are requested before the norm prologue has even started, and the stream runs underneath the prologue, the
-// reductions and the epilogues at what the memory system delivers (scripts/micro/ldsdma.hip: 7.3 TB/s with four issuing
-// waves per CU against 6.6 for the register path's pure read).  Why it is simpler than the loader / consumer engine above:
-// the wave that waits for the bytes is the wave that uses them.
-// The stream waves issue NO compiler-visible vector-memory operation after the prologue (hipcc's own vmcnt bookkeeping
-// does not know the asm loads; a tracked load or store in the loop would make it wait for the run-ahead tiles): the
-// epilogue -- channel scales, cos / sin, residual, stores -- belongs to one wave that streams nothing: norm wave 0 after
-// the prologue (split-norm forms) or a wave of its own.  It meets the stream waves at ONE barrier per tile (partial sums
-// posted -> summed; double buffered) and exchanges the rotary / gate partner by a lane shuffle.
-template <int EPI, int PRO, int NI, int R>
-__global__ __launch_bounds__(8 * 64 + 256) void gemm_w4a4_sdma_kernel(StreamArgs a) {
-    static_assert(PRO == PRO_LN1S || PRO == PRO_LNS, "prologues built so far");
-    static_assert(EPI == SEPI_GATEUP || EPI == SEPI_QKV, "epilogues built so far");
-    static_assert(R >= 2 && R <= 4, "tiles in flight");
-    constexpr int NW = 8, UB = 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4;
-    const int Kb = a.K >> 1, RS = Kb + 32;
-    unsigned char* xq_lds = smem;                                        // [4][RS]
-    float* xs_lds = reinterpret_cast<float*>(smem + (size_t)4 * RS);     // [16]
-    int* red = reinterpret_cast<int*>(xs_lds + 16);                      // [2][NW][64]: (token m < 4, column c) at m * 16 + c
-    unsigned char* ring = smem + (((size_t)4 * RS + 64 + 2 * NW * 256 + 1023) & ~(size_t)1023);   // [R][32 KiB]
-    const int my_tiles = (a.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // >= 1
-    constexpr bool HASD = PRO == PRO_LNS;
-
-    if (tid >= NW * 64) {   // ---------------------------------------------------------------- norm waves; wave NW = epilogue
-        const int row = wave - NW;
-        LnwRegs<NI> rg;
-        lnw_load<NI, HASD>(a, row, rg);
-        // epilogue operands of ALL this workgroup's tiles, requested now (before the stream fills the CU's memory queue)
-        const int c = lane & 15, m = lane >> 4;
-        const int mc = m < a.M ? m : 0;
-        constexpr int MAXT = EPI == SEPI_QKV ? 2 : 8;   // tiles per workgroup (host-checked)
-        f16 swn[MAXT], cf[MAXT], sf[MAXT];
-        int64_t pos_m = 0, slot_m = -1;
-        if (row == 0) {
-            if (EPI == SEPI_QKV) {
-                pos_m = a.positions[mc];
-                slot_m = a.slot_mapping[mc];
-            }
-#pragma unroll
-            for (int i = 0; i < MAXT; i++) {
-                const int tl = min((int)blockIdx.x + i * (int)gridDim.x, a.ntiles - 1);   // clamped: no branch around a load
-                swn[i] = a.ws[stile_row<EPI>(tl, c, a.I)];
-                if (EPI == SEPI_QKV) {
-                    const int o = (tl & 7) * 8 + (c & 7);
-                    const f16* cs = a.cos_sin_cache + pos_m * 128;
-                    cf[i] = cs[o];
-                    sf[i] = cs[64 + o];
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();   // #0: every row request is out before any weight request (in-order L1)
-        __builtin_amdgcn_sched_barrier(0);
-        if (row < a.M) lnw_compute<NI, HASD>(a, row, rg, xq_lds, RS, xs_lds, blockIdx.x == 0 && a.hidden_out != nullptr);
-        __syncthreads();                // #1: publishes xq_lds / xs_lds
-        if (row != 0) return;           // retired waves leave the workgroup's later barriers
-        // ---- the epilogue wave: lane = (token m, tile column c)
-        const bool ethread = m < a.M;
-        const float xs_m = xs_lds[mc];
-        int tile = blockIdx.x, par = 0;
-#pragma unroll
-        for (int i = 0; i < MAXT; i++) {
-            if (i >= my_tiles) break;
-            __syncthreads();            // A(i): the stream waves have posted tile i's partial sums
-            const int* rb = red + par * NW * 64;
-            int sum = 0;
-#pragma unroll
-            for (int w2 = 0; w2 < NW; w2++) sum += rb[w2 * 64 + lane];
-            const float v = ((float)(sum >> 8) * xs_m) * h2f(swn[i]);  // both operands carried a factor 16
-            const f16 hv = f2h(v);
-            const f16 partner = u2h((uint16_t)__shfl_xor((int)h2u(hv), 8, 64));
-            if (EPI == SEPI_GATEUP) {
-                if (ethread && c < 8) {  // hv = up, partner = gate
-                    const float gt = h2f(partner);
-                    const float act = h2f(f2h(gt / (1.0f + qexpf(-gt))));
-                    a.out[(size_t)m * a.I + tile * 8 + c] = f2h(act * h2f(hv));
-                }
-            } else {   // SEPI_QKV
-                const int head = tile >> 3, o = (tile & 7) * 8 + (c & 7);
-                const int n = head * 128 + (c >> 3) * 64 + o;
-                f16 res = hv;
-                if (head < a.nq + a.nkv) {
-                    const float cff = h2f(cf[i]), sff = h2f(sf[i]);
-                    const float xf = h2f(c < 8 ? hv : partner), yf = h2f(c < 8 ? partner : hv);
-                    res = c < 8 ? f2h(h2f(f2h(xf * cff)) - h2f(f2h(yf * sff))) : f2h(h2f(f2h(yf * cff)) + h2f(f2h(xf * sff)));
-                }
-                if (ethread) {
-                    a.out[(size_t)m * a.N + n] = res;
-                    if (head >= a.nq && slot_m >= 0) {
-                        const bool is_k = head < a.nq + a.nkv;
-                        const int kvh = is_k ? head - a.nq : head - a.nq - a.nkv;
-                        f16* cache = is_k ? a.key_cache : a.value_cache;
-                        cache[(slot_m * a.nkv + kvh) * 128 + (c >> 3) * 64 + o] = res;
-                    }
-                }
-            }
-            par ^= 1;
-            tile += gridDim.x;
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------- stream waves
-    const u32 ring0 = (u32)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)ring;
-    const u32 my_lds = ring0 + (u32)(wave * UB) * 1024u;    // this wave's quarter-KiB-pieces of slot 0 (+ slot * 32 KiB + u * 1 KiB)
-    auto issue_tile = [&](int ti) {   // this wave's four pieces of the workgroup's ti-th tile
-        const int t = blockIdx.x + ti * (int)gridDim.x;
-        const uint8_t* wp = a.wq + (size_t)stile_row<EPI>(t, r, a.I) * Kb + g * 16;
-        const u32 dst = my_lds + (u32)(ti % R) * 32768u;
-#pragma unroll
-        for (int u = 0; u < UB; u++) glds16<1>(wp + step_off<NW, UB>(wave, u), dst + (u32)u * 1024u);
-    };
-    __builtin_amdgcn_s_barrier();       // #0
-#pragma unroll
-    for (int ti = 0; ti < R; ti++)
-        if (ti < my_tiles) issue_tile(ti);
-    __builtin_amdgcn_s_barrier();       // #1: the packed rows and their scales are in LDS
-    asm volatile("" ::: "memory");
-    // A wave owns the same K steps of every tile: its activation fragments are widened once and stay in registers
-    i32x4 af0[UB], af1[UB];
-    {
-        const unsigned char* arow = xq_lds + (size_t)(r & 3) * RS + g * 16;
-#pragma unroll
-        for (int u = 0; u < UB; u++) {
-            const u32x4 av = *reinterpret_cast<const u32x4*>(arow + step_off<NW, UB>(wave, u));
-            af0[u] = widen16(av[0], av[1]);
-            af1[u] = widen16(av[2], av[3]);
-        }
-    }
-    typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
-    const __attribute__((address_space(3))) unsigned char* my3 =
-        (const __attribute__((address_space(3))) unsigned char*)ring + (size_t)(wave * UB) * 1024 + lane * 16;
-    int par = 0;
-    for (int ti = 0; ti < my_tiles; ti++) {
-        // tile ti's four loads are the oldest of this wave's (4 per tile in flight, in issue order)
-        const int ahead = min(R - 1, my_tiles - 1 - ti);   // tiles issued behind tile ti
-        if (ahead >= 3) vmcnt_le<12>();
-        else if (ahead == 2) vmcnt_le<8>();
-        else if (ahead == 1) vmcnt_le<4>();
-        else vmcnt_le<0>();
-        u32x4 w[UB];
-#pragma unroll
-        for (int u = 0; u < UB; u++)
-            w[u] = *reinterpret_cast<const volatile lds_u32x4_t*>(my3 + (size_t)(ti % R) * 32768 + u * 1024);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef QS_SDMA_LATE_ISSUE
-        if (ti + R < my_tiles) issue_tile(ti + R);   // into the slot just read
+#ifdef QS_EXPERIMENTAL
+#include "experimental/w4a4_sdma.inc"     // self-service LDS-DMA form of the draft GEMMs: QSPEC_SDMA=1..3
 #endif
-        i32x4 acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int u = 0; u < UB; u++) {
-            const i32x4 b0 = widen16(w[u][0], w[u][1]), b1 = widen16(w[u][2], w[u][3]);
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af0[u], b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af1[u], b1, acc, 0, 0, 0);
-        }
-        // (the MFMA leaves (token m, column c) in acc[m & 3] of lane (m >> 2) * 16 + c: M <= 4 -> lanes 0..15 hold it all)
-        int* rb = red + par * NW * 64;
-        if (lane < 16) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) rb[wave * 64 + i * 16 + lane] = acc[i];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // A(ti) (raw: a __syncthreads() here would wait for vmcnt(0), i.e. for the run-ahead tiles)
-#ifdef QS_SDMA_LATE_ISSUE
-        if (ti + R < my_tiles) issue_tile(ti + R);   // into the slot read above
-#endif
-        par ^= 1;
-    }
-}
-
-template <int EPI, int PRO, int NI, int R>
-static int launch_sdma_inst(const StreamArgs& a, hipStream_t st) {
-    const size_t lds = (((size_t)4 * (a.K / 2 + 32) + 64 + 2 * 8 * 256 + 1023) & ~(size_t)1023) + (size_t)R * 32768;
-    if (lds > 160 * 1024) return -7;
-    static bool attr_set = false;  // per instantiation
-    auto kern = gemm_w4a4_sdma_kernel<EPI, PRO, NI, R>;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -8;
-        attr_set = true;
-    }
-    const int grid = a.ntiles < 256 ? a.ntiles : 256;   // one workgroup per CU
-    if ((a.ntiles + grid - 1) / grid > (EPI == SEPI_QKV ? 2 : 8)) return -9;   // epilogue operands held per workgroup
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(8 * 64 + 256), lds, st, a);
-    return 0;
-}
-#ifndef QS_SDMA_R
-#define QS_SDMA_R 2
-#endif
-// QSPEC_SDMA=1 selects the self-service LDS-DMA forms (gate_up / qkv with the norm prologue, M <= 4, K = 4096).  OFF by
-// default: measured in round 3, launches of ONE shape back to back run 12.9 us (R = 2; 13.5 / 13.9 with R = 3 / 4) against
-// 13.65 for the register kernel, and qkv 5.9-6.3 against 6.7-6.8 -- but inside the cycle (and in bench.py's four-shape
-// graph) gate_up does not gain (13.4-13.7 against 13.2-13.4) and the cycle LOSES 1.5 % (7.73-7.76 against 7.62 ms).
-// More run-ahead is worse, not better: what a CU draws is not raised by requesting more (rounds 1 and 2 found the same
-// for register loads), and the waves that issue the run-ahead loads sit in the issue while the queue is full.
-static int g_sdma = -1;   // 0 off, 1 both shapes, 2 qkv only, 3 gate_up only
-template <int EPI>
-static bool sdma_on() {
-    if (g_sdma < 0) {
-        const char* e = getenv("QSPEC_SDMA");
-        g_sdma = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0;
-    }
-    return g_sdma == 1 || (g_sdma == 2 && EPI == SEPI_QKV) || (g_sdma == 3 && EPI == SEPI_GATEUP);
-}
 
 // ------------------------------------------------------------------ W4A16 (verify pass), same streaming skeleton
 // out[m,n] = h( (sum_k f(x[m,k]) * w[n,k]) * f(sw[n]) ), fp32 accumulate  (bitblas.Matmul, quarot_nn/linear.py:102-124)
@@ -2036,59 +1425,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
     finish(tile, par, pre);
 }
 
-// ------------------------------------------------------------------ weight prefetch into the Infinity Cache
-// Reads `bytes` at `p` and throws them away: the lines end up in the 256 MiB memory-side cache (and some in L2).
-// Launched on a side stream while the latency-bound kernels between two GEMMs (attention, Hadamard, ...) leave the
-// HBM idle, so that the next GEMM streams its weights from the cache.  Pure hint: no effect on results.
-__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ p, size_t n16, unsigned* sink) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    u32x4 acc = {0, 0, 0, 0};
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += 4 * stride) {
-        u32x4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const size_t j = i + u * stride;
-            v[u] = p[j < n16 ? j : i];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) acc ^= v[u];
-    }
-    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9E3779B9u && sink) sink[0] = 1;   // keeps the loads alive
-}
-// Tile-aligned form: workgroup b touches tiles b, b + grid, ... of `tile_bytes` each -- the byte ranges the streaming
-// GEMM's workgroup b will read (weight tile t = rows 16 t .. 16 t + 15 of a [N, K/2] matrix = one contiguous range), so
-// that, dispatched alike, the lines wait in the consumer's own XCD's L2.  first_tile / ntiles bound the part touched.
-__global__ __launch_bounds__(256) void prefetch_tiles_kernel(const char* __restrict__ p, size_t tile_bytes, int first_tile,
-                                                             int ntiles, unsigned* sink) {
-    u32x4 acc = {0, 0, 0, 0};
-    const size_t n16 = tile_bytes / 16;
-    for (int t = first_tile + blockIdx.x; t < first_tile + ntiles; t += gridDim.x) {
-        const u32x4* q = reinterpret_cast<const u32x4*>(p + (size_t)t * tile_bytes);
-        for (size_t i = threadIdx.x; i < n16; i += 1024) {
-            u32x4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const size_t j = i + u * 256;
-                v[u] = q[j < n16 ? j : i];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) acc ^= v[u];
-        }
-    }
-    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9E3779B9u && sink) sink[0] = 1;
-}
-int prefetch_tiles(const void* p, size_t tile_bytes, int first_tile, int ntiles, int workgroups, hipStream_t st) {
-    if (ntiles < 1 || workgroups < 1 || tile_bytes % 16) return 0;
-    hipLaunchKernelGGL(prefetch_tiles_kernel, dim3(workgroups), dim3(256), 0, st, reinterpret_cast<const char*>(p), tile_bytes,
-                       first_tile, ntiles, (unsigned*)nullptr);
-    return 0;
-}
-int prefetch_l2(const void* p, size_t bytes, int workgroups, hipStream_t st) {
-    if (bytes < 16 || workgroups < 1) return 0;
-    hipLaunchKernelGGL(prefetch_kernel, dim3(workgroups), dim3(256), 0, st, reinterpret_cast<const u32x4*>(p), bytes / 16,
-                       (unsigned*)nullptr);
-    return 0;
-}
+#ifdef QS_EXPERIMENTAL
+#include "experimental/prefetch.inc"      // weight prefetch launches: qspec_prefetch / qspec_prefetch_tiles
+#endif
 
 // ------------------------------------------------------------------ fp16 x fp16^T (lm_head), same skeleton
 // out[m,n] = h( sum_k f(x[m,k]) f(w[n,k]) ), fp32 accumulate  (nn.Linear lm_head, logits_processor.py:92-97).
@@ -2339,13 +1678,10 @@ __global__ __launch_bounds__(12 * 64) void gemm_f16_sdma_kernel(const f16* __res
         par ^= 1;
     }
 }
-static int g_head_sdma = -1;   // QSPEC_HEAD_SDMA=0: the register-streaming lm_head
+// (dev knob QSPEC_HEAD_SDMA=0: the register-streaming lm_head)
 static bool head_sdma_on() {
-    if (g_head_sdma < 0) {
-        const char* e = getenv("QSPEC_HEAD_SDMA");
-        g_head_sdma = (e && e[0] == '0') ? 0 : 1;
-    }
-    return g_head_sdma != 0;
+    static const int v = QS_DEV_KNOB("QSPEC_HEAD_SDMA", 1);
+    return v != 0;
 }
 
 template <int MT>
@@ -2385,12 +1721,8 @@ int gemm_f16_stream_grid(int N) {
 int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, void* part_max, hipStream_t st) {
     if (!gemm_f16_stream_supported(M, N, K)) return -1;
     const int ntiles = N / 16;
-    static int cap = 0;
-    if (cap == 0) {
-        const char* e = getenv("QSPEC_HEAD_CAP");
-        cap = e ? atoi(e) : 256;   // one workgroup per CU: 6.3 TB/s measured (512: 6.1, 1024: 5.9)
-        if (cap < 1) cap = 256;
-    }
+    static const int cap_knob = QS_DEV_KNOB("QSPEC_HEAD_CAP", 256);   // one workgroup per CU: 6.3 TB/s measured (512: 6.1, 1024: 5.9)
+    const int cap = cap_knob < 1 ? 256 : cap_knob;
     int grid = ntiles;
     if (part_max) {
         grid = gemm_f16_stream_grid(N);
@@ -2439,14 +1771,10 @@ static size_t stream_lds_bytes(int M, int K, int NW, bool staged_rows, int MT) {
            (size_t)3 * NG * RB * 32 * 4;
 }
 
-static int g_stream_cap = 0;  // workgroups per launch above which a workgroup loops over several tiles
+// workgroups per launch above which a workgroup loops over several tiles
 static int stream_cap() {
-    if (g_stream_cap == 0) {
-        const char* e = getenv("QSPEC_STREAM_CAP");
-        g_stream_cap = e ? atoi(e) : 256;   // one workgroup per CU measured best (bench_stream.py)
-        if (g_stream_cap < 1) g_stream_cap = 256;
-    }
-    return g_stream_cap;
+    static const int v = QS_DEV_KNOB("QSPEC_STREAM_CAP", 256);   // one workgroup per CU measured best (bench_stream.py)
+    return v < 1 ? 256 : v;
 }
 
 template <int EPI, int PRO, int NW, int UB, int NI, int MT = 1, int DMA = 0>
@@ -2473,24 +1801,20 @@ static int launch_stream_inst(const StreamArgs& a, hipStream_t st) {
     return 0;
 }
 
-static int g_ln_split = -1;   // QSPEC_LN_SPLIT=0: the norm on the streaming waves themselves
+// (dev knob QSPEC_LN_SPLIT=0: the norm on the streaming waves themselves)
 static bool ln_split() {
-    if (g_ln_split < 0) {
-        const char* e = getenv("QSPEC_LN_SPLIT");
-        g_ln_split = (e && e[0] == '0') ? 0 : 1;
-    }
-    return g_ln_split != 0;
+    static const int v = QS_DEV_KNOB("QSPEC_LN_SPLIT", 1);
+    return v != 0;
 }
 
-static int g_dma_tiles = -1;   // QSPEC_DMA_TILES=0..3: tiles behind the first that a multi-tile workgroup takes through LDS-DMA
+#ifdef QS_EXPERIMENTAL
+// QSPEC_DMA_TILES=0..3: tiles behind the first that a multi-tile workgroup takes through LDS-DMA.  Default 0: 1 tile gains
+// 0.6 us on back-to-back gate_up launches (12.9 against 13.5), 2 / 3 tiles lose (13.45 / 13.75): round 3
 static int dma_tiles() {
-    if (g_dma_tiles < 0) {
-        const char* e = getenv("QSPEC_DMA_TILES");   // default 0: 1 tile gains 0.6 us on back-to-back gate_up launches
-        g_dma_tiles = e ? atoi(e) : 0;               // (12.9 against 13.5), 2 / 3 tiles lose (13.45 / 13.75): round 3
-        if (g_dma_tiles < 0 || g_dma_tiles > 3) g_dma_tiles = 0;
-    }
-    return g_dma_tiles;
+    static const int v = QS_DEV_KNOB("QSPEC_DMA_TILES", 0);
+    return (v < 0 || v > 3) ? 0 : v;
 }
+#endif
 template <int EPI>
 static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
     StreamShape sh;
@@ -2505,8 +1829,10 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
         return -1;
     }
     if (!ln) {
+#ifdef QS_EXPERIMENTAL
         if constexpr (EPI == SEPI_RESID)
             if (a.K == 14336 && a.M <= 4 && a.ntiles <= 256 && engine_on()) return launch_engine_inst<EPI, PRO_Q, 0, 7, 7>(a, st);
+#endif
         if (sh.NW == 8 && sh.UB == 4) return launch_stream_inst<EPI, PRO_Q, 8, 4, 0>(a, st);
         if (sh.NW == 16 && sh.UB == 7) return launch_stream_inst<EPI, PRO_Q, 16, 7, 0>(a, st);
         if (sh.NW == 8 && sh.UB == 8) return launch_stream_inst<EPI, PRO_Q, 8, 8, 0>(a, st);
@@ -2531,6 +1857,7 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
         // (16 waves instead of 8 at M <= 4 -- one row per 256-thread group, 4 waves per SIMD -- measured equal: qkv 9.4 vs
         // 9.1 us, gate_up 15.4 vs 15.6; the prologue is bound by the CU's VALU issue, not by one wave's latency chain)
         if (a.M <= 4 && ln_split()) {   // (K = 8192: the row-wave's 128 values per lane do not fit 168 VGPRs)
+#ifdef QS_EXPERIMENTAL   // the three LDS-DMA forms (Stage A: measured, none is the default)
             if constexpr (EPI == SEPI_GATEUP)
                 if (a.K == 4096 && engine_on()) return launch_engine_inst<EPI, PRO_LN1S, 4, 2, 8>(a, st);
             if constexpr (EPI == SEPI_GATEUP || EPI == SEPI_QKV)
@@ -2541,6 +1868,7 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
                 if (dt == 2) return launch_stream_inst<EPI, PRO_LN1S, 8, 4, 4, 1, 2>(a, st);
                 if (dt == 1) return launch_stream_inst<EPI, PRO_LN1S, 8, 4, 4, 1, 1>(a, st);
             }
+#endif
             if (a.K == 4096) return launch_stream_inst<EPI, PRO_LN1S, 8, 4, 4>(a, st);
             if (a.K == 5120) return launch_stream_inst<EPI, PRO_LN1S, 8, 5, 5>(a, st);
             if (a.K == 2048) return launch_stream_inst<EPI, PRO_LN1S, 4, 4, 2>(a, st);
@@ -2554,8 +1882,10 @@ static int launch_stream(const StreamArgs& a, bool ln, hipStream_t st) {
         return -1;
     }
     if (a.M <= 4 && ln_split()) {
+#ifdef QS_EXPERIMENTAL
         if constexpr (EPI == SEPI_GATEUP || EPI == SEPI_QKV)
             if (a.K == 4096 && sdma_on<EPI>()) return launch_sdma_inst<EPI, PRO_LNS, 4, QS_SDMA_R>(a, st);
+#endif
         if (a.K == 4096) return launch_stream_inst<EPI, PRO_LNS, 8, 4, 4>(a, st);
         if (a.K == 5120) return launch_stream_inst<EPI, PRO_LNS, 8, 5, 5>(a, st);
         if (a.K == 2048) return launch_stream_inst<EPI, PRO_LNS, 4, 4, 2>(a, st);
@@ -2656,11 +1986,7 @@ int gemm_w4a16_stream(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, 
 // go to part [S][M][N].  Returns the slice count to use for (M, N, K), 0 if the shape is not covered.
 int gemm_w4a16_stream_partial_slices(int M, int N, int K) {
     if (gemm_w4a16_stream_supported(M, N, K)) return 0;   // fits unsliced: use the plain entry
-    static int forced = -1;   // QSPEC_W4A16_SLICES (dev knob for sweeps)
-    if (forced < 0) {
-        const char* e = getenv("QSPEC_W4A16_SLICES");
-        forced = e ? atoi(e) : 0;
-    }
+    static const int forced = QS_DEV_KNOB("QSPEC_W4A16_SLICES", 0);   // (dev knob for sweeps)
     if (forced >= 2 && forced <= 4 && K % forced == 0 && gemm_w4a16_stream_supported(M, N, K / forced)) return forced;
     // Four slices first: a workgroup stages the whole [16, K / S] fp16 activation slice (16 * K / S * 2 bytes) for
     // tiles-per-workgroup * 16 * K / S / 2 bytes of weights, and the grid is one workgroup per CU in all, so S slices mean
@@ -2690,12 +2016,14 @@ int gemm_w4a16_partial_finish(const float* part, const f16* ws, f16* out, int M,
 // (32 + 8 + 8) heads x 64 pairs = 3072 = 12 x 256.  OFF by default (QSPEC_QKV_LEVEL=1 switches it on): measured in round 3,
 // bit-identical, but the draft qkv launch takes 7.25-7.38 us against 6.89 and the cycle 7.58-7.65 ms against 7.51-7.54 -- two
 // tile iterations (reduction, barriers, epilogue) in EVERY workgroup cost more than the 16 KB less that the slowest ones stream.
+#ifdef QS_EXPERIMENTAL
 static int qkv_level_workgroups(int nq, int nkv, int N) {
-    static const int on = getenv("QSPEC_QKV_LEVEL") ? atoi(getenv("QSPEC_QKV_LEVEL")) : 0;
+    static const int on = QS_DEV_KNOB("QSPEC_QKV_LEVEL", 0);
     const int pairs = (nq + 2 * nkv) * 64, cap = stream_cap(), classic = N / 16;
     if (!on || pairs % 12 || classic <= cap || classic % cap == 0 || pairs / 12 > cap) return 0;
     return pairs / 12;
 }
+#endif
 
 int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                                const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
@@ -2705,10 +2033,12 @@ int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f1
     a.x = x; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = qkv; a.M = M; a.N = N; a.K = K;
     a.ntiles = N / 16; a.positions = positions; a.cos_sin_cache = cos_sin_cache; a.key_cache = key_cache;
     a.value_cache = value_cache; a.slot_mapping = slot_mapping; a.nq = nq; a.nkv = nkv;
+#ifdef QS_EXPERIMENTAL
     if (const int L = qkv_level_workgroups(nq, nkv, N)) {   // twelve RoPE pairs per workgroup: a full + a half tile
         a.I = L;
         a.ntiles = 2 * L;
     }
+#endif
     return launch_stream16<SEPI_QKV>(a, st);
 }
 
@@ -2793,12 +2123,14 @@ int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* 
     a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = qkv; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
     a.positions = positions; a.cos_sin_cache = cos_sin_cache; a.key_cache = key_cache; a.value_cache = value_cache;
     a.slot_mapping = slot_mapping; a.nq = nq; a.nkv = nkv;
+#ifdef QS_EXPERIMENTAL
     if (!sdma_on<SEPI_QKV>()) {   // (the LDS-DMA forms keep the classic tiles)
         if (const int L = qkv_level_workgroups(nq, nkv, N)) {
             a.I = L;
             a.ntiles = 2 * L;
         }
     }
+#endif
     return launch_stream<SEPI_QKV>(a, x.hidden_in != nullptr, st);
 }
 

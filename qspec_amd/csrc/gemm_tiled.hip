@@ -198,9 +198,14 @@ __global__ __launch_bounds__(256) void gemm_w4a16_tiled_kernel(const f16* __rest
 
 bool gemm_w4a16_tiled_supported(int M, int N, int K) { return M >= 1 && N % 128 == 0 && K % 256 == 0 && K >= 512; }
 
-static int env_int(const char* name, int dflt) {
+static int env_int(const char* name, int dflt) {   // sweep knobs (scripts/sweep_tiled.sh): experimental build only
+#ifdef QS_EXPERIMENTAL
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 
 // Launch plan: token block 32 * MT and K slices S, by a small cost model fitted to a sweep on MI355X

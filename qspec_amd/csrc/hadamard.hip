@@ -675,11 +675,7 @@ int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out
     const float* ws_o = ws + paged_attention_ws_o_offset();
     const float* ws_ml = ws + paged_attention_ws_ml_offset(max_tokens, heads, d, n_splits);
     const bool quant = q != nullptr;
-    static int spread = -1;   // QSPEC_HHM_SPREAD=0: one workgroup per token also for the fp16 form
-    if (spread < 0) {
-        const char* e = getenv("QSPEC_HHM_SPREAD");
-        spread = (e && e[0] == '0') ? 0 : 1;
-    }
+    static const int spread = QS_DEV_KNOB("QSPEC_HHM_SPREAD", 1);   // (0: one workgroup per token also for the fp16 form)
     if (!quant && heads == 32 && spread && T * 8 <= 1024) {
         hipLaunchKernelGGL(heads_hadamard_merge_spread32_kernel<false>, dim3(T, 8), dim3(512), 0, st, ws_o, ws_ml, n_splits,
                            out_f16, had_scale, (float*)nullptr);

@@ -4,6 +4,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+// Dev knobs (environment switches for A/B measurements and sweeps) exist only in the EXPERIMENTAL build
+// (-DQS_EXPERIMENTAL: `make -C qspec_amd/csrc experimental`); in libqspec_hip.so every knob is its default, a constant.
+#ifdef QS_EXPERIMENTAL
+#define QS_DEV_KNOB(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define QS_DEV_KNOB(name, dflt) (dflt)
+#endif
 
 namespace qspec {
 typedef _Float16 f16;
@@ -118,8 +127,10 @@ int gemm_f16_tiled(const f16* x, const f16* w, f16* out, int M, int N, int K, hi
 bool gemm_f16_stream_supported(int M, int N, int K);
 int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, void* part_max, hipStream_t st);
 int gemm_f16_stream_grid(int N);
+#ifdef QS_EXPERIMENTAL
 int prefetch_l2(const void* p, size_t bytes, int workgroups, hipStream_t st);
 int prefetch_tiles(const void* p, size_t tile_bytes, int first_tile, int ntiles, int workgroups, hipStream_t st);
+#endif
 
 // attention.hip
 int rope_kv_write(const int64_t* positions, f16* qkv, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,

@@ -230,7 +230,8 @@ def gate_up_silu_linear(x, x_scale, wq, w_scale, act):
 
 
 def prefetch(t, workgroups: int = 128):
-    """Cache hint (qspec_prefetch): pull tensor `t` into the Infinity Cache on the current stream."""
+    """Cache hint (qspec_prefetch): pull tensor `t` into the Infinity Cache on the current stream.  EXPERIMENTAL build only
+    (QSPEC_HIP_LIB=.../libqspec_hip_experimental.so): measured and left out of the engine."""
     _call("qspec_prefetch", t.data_ptr(), t.numel() * t.element_size(), workgroups, _stream())
 
 

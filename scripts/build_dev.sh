@@ -8,7 +8,7 @@ mkdir -p build_dev/$name
 for f in capi norm_quant hadamard gemm gemm_stream gemm_tiled attention sampler comm; do
   src=qspec_amd/csrc/$f.hip; obj=build_dev/$name/$f.o
   if [ ! -f $obj ] || [ $src -nt $obj ] || [ qspec_amd/csrc/common.cuh -nt $obj ] || [ "$FORCE" = 1 ]; then
-    /opt/rocm/bin/hipcc $extra -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math \
+    /opt/rocm/bin/hipcc $extra -DQS_EXPERIMENTAL -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math \
       -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function -Iqspec_amd/csrc -c $src -o $obj &
   fi
 done

@@ -1381,6 +1381,9 @@ def test_attention_partials_long_splits_then_merge_within_1e3(ops, oracle, ctx_l
     assert_close_1e3(host(out), ref)
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qspec_amd", "csrc",
+                                                    "libqspec_hip_experimental.so")),
+                    reason="experimental library not built (make -C qspec_amd/csrc experimental)")
 @pytest.mark.parametrize("switch,kexpr", [("QSPEC_ATTN_FAST=0", "(long_splits_then_merge or reference_fixture_within) and not dev_forms"),
                                           ("QSPEC_ATTN_NW=8", "(long_splits_then_merge or reference_fixture_within) and not dev_forms"),
                                           ("QSPEC_QKV_LEVEL=1", "qkv and not dev_forms")],
@@ -1394,9 +1397,11 @@ def test_attention_waves_kernel_dev_forms(switch, kexpr):
     import os
     import subprocess
     import sys
+    from qspec_amd import _lib
     k, v = switch.split("=")
     env = dict(os.environ)
     env[k] = v
+    env["QSPEC_HIP_LIB"] = _lib.EXPERIMENTAL_LIB_PATH   # dev knobs and rejected forms exist only in the experimental build
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", kexpr], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
