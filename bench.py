@@ -507,7 +507,7 @@ def main():
         from qspec_amd import parallel
         # the plan of the verify pass (shard the decoder layers or not) comes from the collectives' cost MEASURED here
         model = parallel.build_tp_model(cfg, dev, world, rank, seed=args.seed, lm_head_std=args.lm_head_std,
-                                        tokens=args.batch * (args.k + 1))
+                                        tokens=args.batch * (args.k + 1), draft_tokens=args.batch)
     else:
         model = QuarotLlamaForCausalLM(cfg, dev).init_synthetic(args.seed, args.lm_head_std)
     rho = None if args.agreement.lower() == "none" else float(args.agreement)
@@ -571,6 +571,11 @@ def main():
                                 if model.tp.shard_layers else
                                 "verify pass: vocab-parallel lm_head + all-gather; decoder layers replicated (their collectives "
                                 "would cost more than the weight stream they save at this size); draft pass replicated")),
+                   "tp_draft_pass": (None if world == 1 else
+                                     ("decoder layers replicated (zero collectives on activations); lm_head vocab-parallel + all-gather "
+                                      "of the fp16 logit slices" if model.tp.shard_draft_vocab else
+                                      "replicated, zero collectives (the logits all-gather would cost more than the lm_head stream it saves)")),
+                   "tp_draft_vocab_gather_us": (None if world == 1 else getattr(model.tp, "vocab_gather_us", None)),
                    "tp_collective": (None if world == 1 else model.tp.backend),
                    "tp_plan_basis": (None if world == 1 else getattr(model.tp, "plan_basis", None)),
                    "tp_collective_us": (None if world == 1 else getattr(model.tp, "collective_us", None)),

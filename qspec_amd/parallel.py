@@ -41,6 +41,7 @@ def shard_range(n: int, world: int, rank: int, align: int) -> Tuple[int, int]:
 # and a conservative cost of one small RCCL collective inside the captured graph (128-460 KB over xGMI: latency-bound;
 # NOT measured here -- no multi-GPU box in this round; QSPEC_TP_LAYERS=0/1 overrides the plan).
 STREAM_BYTES_PER_US = 4.5e6
+LM_HEAD_BYTES_PER_US = 6.4e6     # the lm_head's fp16 stream through LDS-DMA: 1.05 GB in 162 us
 COLLECTIVE_US = {2: 12.0, 4: 18.0, 8: 25.0}
 
 
@@ -236,6 +237,13 @@ class TensorParallel:
         self.backend = comm.backend if comm is not None else "none"
         # False: the decoder layers of the verify pass stay replicated (no collectives); lm_head stays vocab-parallel
         self.shard_layers = shard_layers
+        # Draft pass: the decoder layers always run replicated (no collective touches an activation: the online Hadamards
+        # and the per-token abs-max need whole rows), but the lm_head + sampler front end -- 4 x 160 us of the 7.5 ms
+        # cycle, the one draft-side piece that shards without touching a Hadamard row -- may go vocab-parallel: every
+        # rank streams V / world rows of lm_head, the fp16 logit slices are all-gathered ([B, V] fp16: 1 MB at bs = 4) and
+        # every rank runs the same softmax / argmax on the same bits (logits_processor.py:104-107).  Whether that pays
+        # is a measured decision (attach_tp); QSPEC_TP_DRAFT_VOCAB=0/1 forces it.
+        self.shard_draft_vocab = False
         self._bufs = {}   # exchange buffers, allocated once per shape (nothing is allocated inside a captured cycle)
 
     def _buf(self, key, shape, dtype, device):
@@ -385,6 +393,58 @@ def agree_all(tp, ok: bool, dev) -> bool:
     return bool(int(f.item()))
 
 
+def measure_vocab_gather_us(tp: "TensorParallel", B: int, V: int, device, iters: int = 20) -> float:
+    """Time the draft pass's logits exchange -- all_gather_vocab of a [B, V] fp16 matrix, copies included -- on THIS job's
+    communicator (captured where the backend allows, all ranks agreeing on the mode), MAX over ranks, microseconds."""
+    dev = torch.device(device)
+    lo, hi = tp.vocab_range(V)
+    local = torch.zeros(B, hi - lo, dtype=torch.float16, device=dev)
+    out = torch.zeros(B, V, dtype=torch.float16, device=dev)
+
+    def body():
+        tp.all_gather_vocab(local, out, V)
+    body()
+    on_gpu = dev.type == "cuda" and not tp.backend.endswith("gloo") and tp.backend != "threads"
+    fn = body
+    if on_gpu:
+        g = None
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+        except Exception:
+            torch.cuda.synchronize(dev)
+            g = None
+        if agree_all(tp, g is not None, dev):
+            g.replay()
+            fn = g.replay
+    import time
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    us = (time.perf_counter() - t0) / iters * 1e6
+    t = torch.tensor([us], dtype=torch.float64, device=dev if on_gpu else "cpu")
+    if tp.backend != "threads" and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=tp.group)
+    return float(t[0])
+
+
+def shard_draft_vocab_pays(lm_head_bytes: int, world: int, gather_us: float) -> bool:
+    """Vocab-parallel lm_head on the draft pass saves (1 - 1/world) of the lm_head stream per forward and costs the logits
+    all-gather (its copies and launch boundaries inside the measurement)."""
+    return lm_head_bytes * (1.0 - 1.0 / world) / LM_HEAD_BYTES_PER_US > gather_us
+
+
 def shard_layers_pays_measured(layer_weight_bytes: int, world: int, three_collectives_us: float) -> bool:
     """The plan from MEASURED collective cost: sharding saves (1 - 1/world) of the layer's weight stream and costs the
     three collectives (plus their launch boundaries, already inside the measurement)."""
@@ -392,7 +452,7 @@ def shard_layers_pays_measured(layer_weight_bytes: int, world: int, three_collec
     return saved > three_collectives_us
 
 
-def attach_tp(m, rank: int, world: int, tokens: Optional[int] = None, group=None):
+def attach_tp(m, rank: int, world: int, tokens: Optional[int] = None, group=None, draft_tokens: Optional[int] = None):
     """Attach the tensor-parallel context to a model every rank holds in full.  The plan (shard the decoder layers of the
     verify pass or keep them replicated) comes from the collectives' cost MEASURED on this job's communicator when
     `tokens` (the verify pass's T) is given; QSPEC_TP_LAYERS=0/1 forces either plan; without a measurement the
@@ -410,12 +470,20 @@ def attach_tp(m, rank: int, world: int, tokens: Optional[int] = None, group=None
             m.tp.shard_layers = shard_layers_pays_measured(layer_bytes, world,
                                                            m.tp.collective_us["three_collectives_per_layer_us"])
             m.tp.plan_basis = "collective cost measured in this job (parallel.measure_collective_us)"
+    # draft pass: vocab-parallel lm_head + logits all-gather, decided the same way (draft_tokens = the batch size)
+    forced = os.environ.get("QSPEC_TP_DRAFT_VOCAB")
+    m.tp.vocab_gather_us = None
+    if forced is not None:
+        m.tp.shard_draft_vocab = world > 1 and forced != "0"
+    elif world > 1 and draft_tokens is not None:
+        m.tp.vocab_gather_us = measure_vocab_gather_us(m.tp, draft_tokens, cfg.vocab_size, m.device)
+        m.tp.shard_draft_vocab = shard_draft_vocab_pays(m.lm_head.numel() * 2, world, m.tp.vocab_gather_us)
     return m
 
 
 def build_tp_model(cfg, device: str, world: int, rank: int, seed: int = 0, lm_head_std: float = 0.02,
-                   tokens: Optional[int] = None):
+                   tokens: Optional[int] = None, draft_tokens: Optional[int] = None):
     """Same synthetic weights on every rank (same seed), TP context attached (attach_tp)."""
     from .model import QuarotLlamaForCausalLM
     m = QuarotLlamaForCausalLM(cfg, device).init_synthetic(seed, lm_head_std)
-    return attach_tp(m, rank, world, tokens)
+    return attach_tp(m, rank, world, tokens, draft_tokens=draft_tokens)

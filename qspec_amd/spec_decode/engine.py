@@ -379,9 +379,11 @@ class QSpecEngine:
         torch.mul(self.seq_lens, self.step_mask, out=self.eff_lens)
         ops.spec_prepare_draft(self.last_token, self.eff_lens, self.block_tables, bs, self.d_tokens, self.d_pos,
                                self.d_slots, self.d_ctx)
+        tp = self._comm()
+        draft_sv = tp is not None and getattr(tp, "shard_draft_vocab", False)   # vocab-parallel lm_head on the draft pass too
         for i in range(k):
             hs = m.forward(self.d_tokens, self.d_pos, self.kv_caches, self.md_draft, self.scratch_draft, w4a4=True)
-            m.sample_greedy(hs, self.scratch_draft, self.draft_probs_kbv[i], self.draft_ids_kb[i])
+            m.sample_greedy(hs, self.scratch_draft, self.draft_probs_kbv[i], self.draft_ids_kb[i], shard_vocab=draft_sv)
             if i != k - 1:  # _gpu_advance_step (draft_model_runner.py:78-135)
                 ops.spec_advance_draft(bs, self.d_tokens, self.draft_ids_kb[i], self.d_pos, self.d_ctx, self.d_slots,
                                        self.block_tables)

@@ -49,7 +49,14 @@ def _worker(rank, world, port, ret):
     out = torch.empty(T, V, dtype=torch.float16)
     tp.all_gather_vocab(logits_full[:, v0:v1].contiguous(), out, V)
     ok3 = torch.equal(out, logits_full)
-    ret[rank] = (ok1, ok2, ok3, (v0, v1))
+    # the draft pass's plan: the logits all-gather is timed on THIS job's communicator (MAX over the ranks: every rank
+    # must see the same number, or the ranks would take different plans and issue different collectives)
+    from qspec_amd.parallel import agree_all, measure_vocab_gather_us
+    us = measure_vocab_gather_us(tp, 4, 16 * 64, "cpu", iters=3)
+    same = [None] * world
+    dist.all_gather_object(same, us)
+    ok4 = us > 0 and all(v == same[0] for v in same) and agree_all(tp, True, "cpu") and not agree_all(tp, rank == 0, "cpu")
+    ret[rank] = (ok1 and ok4, ok2, ok3, (v0, v1))
     dist.destroy_process_group()
 
 
@@ -78,6 +85,17 @@ def test_tp_plan_shards_layers_only_when_it_pays(monkeypatch):
     assert shard_layers_pays(l8b, 2)
     monkeypatch.setenv("QSPEC_TP_LAYERS", "0")
     assert not shard_layers_pays(l70b, 8)
+
+
+def test_tp_plan_draft_vocab_parallel_only_when_it_pays():
+    """The draft pass's lm_head goes vocab-parallel iff the stream it saves exceeds the measured logits all-gather:
+    Llama-3-8B's 1.05 GB head at 8 ranks saves ~143 us per forward -> pays against a 40 us gather, not against 200 us;
+    a 2048 x 1024 test head never pays."""
+    from qspec_amd.parallel import shard_draft_vocab_pays
+    head = 128256 * 4096 * 2
+    assert shard_draft_vocab_pays(head, 8, 40.0) and not shard_draft_vocab_pays(head, 8, 200.0)
+    assert shard_draft_vocab_pays(head, 2, 40.0) and not shard_draft_vocab_pays(head, 2, 100.0)
+    assert not shard_draft_vocab_pays(2048 * 1024 * 2, 8, 5.0)
 
 
 def test_thread_ranks_collectives_and_column_gathers():

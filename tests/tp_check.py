@@ -110,6 +110,16 @@ def run_rank(rank, world, comm, family, model_full, results):
     gen = eng.generated()
     assert all(len(x) >= 4 for x in gen)
     assert eng.error_flag() == 0, "a device-side hand-off timed out"
+    # (3) the draft pass's lm_head vocab-parallel as well (logit slices all-gathered): every logit is the same dot product
+    # whichever rank streams its lm_head row, so the cycle must emit EXACTLY what it emits with the replicated draft head
+    m.tp.shard_draft_vocab = True
+    eng2 = QSpecEngine(m, 3, B, max_model_len=128, block_size=16, max_new_tokens=32, use_graph=False, seed=5)
+    eng2.add_sequences(prompts)
+    for _ in range(3):
+        eng2.step()
+    assert eng2.generated() == gen, "vocab-parallel draft lm_head changed the tokens"
+    assert torch.equal(eng2.draft_probs_kbv, eng.draft_probs_kbv), "vocab-parallel draft lm_head changed the draft distributions"
+    m.tp.shard_draft_vocab = False
     results[rank] = ([t for x in gen for t in x[:4]], float(rh.max()), float((rh > 1).mean()), float(rl.max()))
 
 
