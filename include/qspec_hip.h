@@ -389,6 +389,19 @@ int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* 
                            int64_t* out_tokens, uint8_t* accepted, int64_t* recovered, int64_t* counters,
                            const int32_t* active_lens, void* workspace, void* stream);
 
+/* TypicalAcceptanceSampler.forward(target_with_bonus_probs, bonus_token_ids, draft_probs, draft_token_ids)
+ *   vllm/model_executor/layers/typical_acceptance_sampler.py:37-172 (MEDUSA 3.3.1), selected by
+ *   draft_token_acceptance_method = "typical_acceptance_sampler" (vllm/spec_decode/spec_decode_worker.py:95-110).
+ *   Deterministic: accepted[b,i] = q[b,i,x] > min(posterior_threshold, posterior_alpha * exp(-H)) with
+ *   H = -sum_v q_v log(q_v + 1e-5) over q = target_with_bonus_probs[:, :-1]; the replacement at the first rejected position is
+ *   argmax_v q (first index on ties); output layout and counters as qspec_rejection_sample (draft_probs is unused by the
+ *   reference and is not an argument).  Strides and workspace as there. */
+int qspec_typical_acceptance_sample(const float* target_with_bonus_probs, const int64_t* bonus_token_ids,
+                                    const int64_t* draft_token_ids, float posterior_threshold, float posterior_alpha, int batch,
+                                    int k, int vocab, int64_t ids_stride_b, int64_t ids_stride_k, int64_t bonus_stride,
+                                    int64_t* out_tokens, uint8_t* accepted, int64_t* recovered, int64_t* counters,
+                                    const int32_t* active_lens, void* workspace, void* stream);
+
 /* ops.advance_step_flashattn(num_seqs, num_queries, block_size, input_tokens, sampled_token_ids,
  *   input_positions, seq_lens, slot_mapping, block_tables)   csrc/prepare_inputs/advance_step.cu:14-64,192
  *   (vllm/attention/backends/flash_attn.py:365-373), num_seqs == num_queries. */

@@ -332,6 +332,24 @@ def rejection_sample(target_with_bonus_probs, bonus_token_ids, draft_probs, draf
     return out, accepted, recovered, counters
 
 
+def typical_acceptance_sample(target_with_bonus_probs, bonus_token_ids, draft_token_ids, posterior_threshold, posterior_alpha):
+    """TypicalAcceptanceSampler.forward (vllm/model_executor/layers/typical_acceptance_sampler.py:37-172):
+    accepted = q[x] > min(posterior_threshold, posterior_alpha * exp(-H)), H = -sum_v q log(q + 1e-5) (fp32 terms as the
+    reference forms them; torch.sum has no specified order: summed in fp64, rounded once), replacement = argmax_v q, then
+    _create_output.  Returns (output [B,k+1] i64, accepted [B,k] bool, recovered [B,k] i64, counters, entropy [B,k] f32)."""
+    q = np.asarray(target_with_bonus_probs, np.float32)[:, :-1]
+    ids = np.asarray(draft_token_ids, np.int64)
+    B, k, V = q.shape
+    cand = q[np.arange(B)[:, None], np.arange(k)[None, :], ids]
+    terms = (q * np.log(q + np.float32(1e-5), dtype=np.float32)).astype(np.float32)
+    H = (-terms.sum(axis=-1, dtype=np.float64)).astype(np.float32)
+    thr = np.minimum(np.float32(posterior_threshold), (expf(-H) * np.float32(posterior_alpha)).astype(np.float32))
+    accepted = cand > thr
+    recovered = np.argmax(q, axis=-1).astype(np.int64)
+    out, counters = create_output(accepted, recovered, ids, np.asarray(bonus_token_ids, np.int64).reshape(B))
+    return out, accepted, recovered, counters, H
+
+
 def create_output(accepted, substitute_token_ids, draft_token_ids, bonus_token_ids):
     """spec_decode_base_sampler.py:69-131."""
     accepted = np.asarray(accepted, bool)

@@ -373,6 +373,21 @@ int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* 
     if (k < 1) return fail("%s: k=%d must be >= 1", op, k);
     return finish(op, qspec::rejection_sample(target_with_bonus_probs, draft_probs, draft_token_ids, bonus_token_ids, uniform, exponential, seed, offset, rng_state, batch, k, vocab, dp_stride_b, dp_stride_k, ids_stride_b, ids_stride_k, bonus_stride, out_tokens, accepted, recovered, counters, active_lens, workspace, ST));
 }
+int qspec_typical_acceptance_sample(const float* target_with_bonus_probs, const int64_t* bonus_token_ids,
+                                    const int64_t* draft_token_ids, float posterior_threshold, float posterior_alpha, int batch,
+                                    int k, int vocab, int64_t ids_stride_b, int64_t ids_stride_k, int64_t bonus_stride,
+                                    int64_t* out_tokens, uint8_t* accepted, int64_t* recovered, int64_t* counters,
+                                    const int32_t* active_lens, void* workspace, void* stream) {
+    const char* op = "qspec_typical_acceptance_sample";
+    if (batch == 0) return 0;
+    NONNULL(op, target_with_bonus_probs); NONNULL(op, bonus_token_ids); NONNULL(op, draft_token_ids); NONNULL(op, out_tokens);
+    NONNULL(op, accepted); NONNULL(op, recovered); NONNULL(op, workspace);
+    if (batch * k > 4096) return fail("%s: batch*k=%d too large", op, batch * k);
+    if (k < 1) return fail("%s: k=%d must be >= 1", op, k);
+    return finish(op, qspec::typical_acceptance_sample(target_with_bonus_probs, draft_token_ids, bonus_token_ids, posterior_threshold,
+                                                       posterior_alpha, batch, k, vocab, ids_stride_b, ids_stride_k, bonus_stride,
+                                                       out_tokens, accepted, recovered, counters, active_lens, workspace, ST));
+}
 int qspec_advance_step_flashattn(int num_seqs, int block_size, int64_t* input_tokens,
                                  const int64_t* sampled_token_ids, int64_t* input_positions, int32_t* seq_lens,
                                  int64_t* slot_mapping, const int32_t* block_tables, int64_t block_tables_stride,

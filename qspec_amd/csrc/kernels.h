@@ -161,6 +161,10 @@ int rejection_sample(const float* target_probs, const float* draft_probs, const 
                      uint64_t offset, uint64_t* rng_state, int B, int k, int V, int64_t dp_sb, int64_t dp_sk,
                      int64_t di_sb, int64_t di_sk, int64_t bonus_stride, int64_t* out_tokens, uint8_t* accepted,
                      int64_t* recovered, int64_t* counters, const int32_t* active_lens, void* ws, hipStream_t st);
+int typical_acceptance_sample(const float* target_probs, const int64_t* draft_ids, const int64_t* bonus_ids,
+                              float posterior_threshold, float posterior_alpha, int B, int k, int V, int64_t di_sb,
+                              int64_t di_sk, int64_t bonus_stride, int64_t* out_tokens, uint8_t* accepted, int64_t* recovered,
+                              int64_t* counters, const int32_t* active_lens, void* ws, hipStream_t st);
 int advance_step(int n, int block_size, int64_t* input_tokens, const int64_t* sampled, int64_t* positions,
                  int32_t* seq_lens, int64_t* slot_mapping, const int32_t* block_tables, int64_t bt_stride,
                  hipStream_t st);

@@ -263,8 +263,43 @@ __global__ __launch_bounds__(256) void rejection_argmax_kernel(const float* __re
     am = block_argmax(am, red_a);
     if (threadIdx.x == 0) part_a[bk * QS_SM_CHUNKS + c] = SmPartA{am.v, am.i};
 }
-// Final step + output assembly + counters (spec_decode_base_sampler.py:94-131); one workgroup.
-// counters[0] += accepted.sum() (non-causal), counters[1] += #(out != -1), counters[2] += B*k.
+// SpecDecodeBaseSampler._create_output + the counters (spec_decode_base_sampler.py:69-131), shared by the rejection and the
+// typical-acceptance sampler: out[b, i] = draft token (i < limit) | recovered (i == limit) | -1; out[b, k] = bonus iff every
+// draft token was accepted; counters[0] += accepted.sum() (non-causal), counters[1] += #(out != -1), counters[2] += B*k.
+// Call from every thread of ONE workgroup, behind the barrier that made accepted / recovered visible.
+__device__ __forceinline__ void create_output(int B, int k, const int64_t* __restrict__ draft_ids, int64_t di_sb, int64_t di_sk,
+                                              const int64_t* __restrict__ bonus_ids, int64_t bonus_stride,
+                                              const uint8_t* accepted, const int64_t* recovered, int64_t* __restrict__ out,
+                                              int64_t* __restrict__ counters, const int32_t* __restrict__ active_lens) {
+    int acc_cnt = 0, emit_cnt = 0, rows_on = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        if (active_lens && active_lens[b] <= 0) {
+            for (int i = 0; i <= k; i++) out[b * (k + 1) + i] = -1;
+            continue;
+        }
+        rows_on++;
+        int limit = k;
+        for (int i = 0; i < k; i++) {
+            if (accepted[b * k + i]) acc_cnt++;
+            else if (limit == k) limit = i;
+        }
+        for (int i = 0; i < k; i++) {
+            int64_t v = i < limit ? draft_ids[b * di_sb + i * di_sk] : (i == limit ? recovered[b * k + i] : -1);
+            out[b * (k + 1) + i] = v;
+            emit_cnt += v != -1;
+        }
+        int64_t last = limit == k ? bonus_ids[b * bonus_stride] : -1;
+        out[b * (k + 1) + k] = last;
+        emit_cnt += last != -1;
+    }
+    if (counters) {
+        if (acc_cnt) atomicAdd(reinterpret_cast<unsigned long long*>(counters), (unsigned long long)acc_cnt);
+        if (emit_cnt) atomicAdd(reinterpret_cast<unsigned long long*>(counters + 1), (unsigned long long)emit_cnt);
+        if (rows_on) atomicAdd(reinterpret_cast<unsigned long long*>(counters + 2), (unsigned long long)rows_on * k);
+    }
+}
+
+// Final step + output assembly + counters; one workgroup.
 __global__ __launch_bounds__(1024) void rejection_output_kernel(
     const float* __restrict__ target_probs, const float* __restrict__ draft_probs,
     const int64_t* __restrict__ draft_ids, const int64_t* __restrict__ bonus_ids, const float* __restrict__ uniform,
@@ -304,32 +339,7 @@ __global__ __launch_bounds__(1024) void rejection_output_kernel(
         recovered[bk] = am.i == 0x7fffffff ? 0 : am.i;
     }
     __syncthreads();
-    int acc_cnt = 0, emit_cnt = 0, rows_on = 0;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        if (active_lens && active_lens[b] <= 0) {
-            for (int i = 0; i <= k; i++) out[b * (k + 1) + i] = -1;
-            continue;
-        }
-        rows_on++;
-        int limit = k;
-        for (int i = 0; i < k; i++) {
-            if (accepted[b * k + i]) acc_cnt++;
-            else if (limit == k) limit = i;
-        }
-        for (int i = 0; i < k; i++) {
-            int64_t v = i < limit ? draft_ids[b * di_sb + i * di_sk] : (i == limit ? recovered[b * k + i] : -1);
-            out[b * (k + 1) + i] = v;
-            emit_cnt += v != -1;
-        }
-        int64_t last = limit == k ? bonus_ids[b * bonus_stride] : -1;
-        out[b * (k + 1) + k] = last;
-        emit_cnt += last != -1;
-    }
-    if (counters) {
-        if (acc_cnt) atomicAdd(reinterpret_cast<unsigned long long*>(counters), (unsigned long long)acc_cnt);
-        if (emit_cnt) atomicAdd(reinterpret_cast<unsigned long long*>(counters + 1), (unsigned long long)emit_cnt);
-        if (rows_on) atomicAdd(reinterpret_cast<unsigned long long*>(counters + 2), (unsigned long long)rows_on * k);
-    }
+    create_output(B, k, draft_ids, di_sb, di_sk, bonus_ids, bonus_stride, accepted, recovered, out, counters, active_lens);
     if (rng_state && threadIdx.x == 0) rng_state[1] = offset + 1;  // after every draw of this call
 }
 
@@ -349,6 +359,78 @@ int rejection_sample(const float* target_probs, const float* draft_probs, const 
     hipLaunchKernelGGL(rejection_output_kernel, dim3(1), dim3(1024), 0, st, target_probs, draft_probs, draft_ids,
                        bonus_ids, uniform, seed, offset, rng_state, part_a, B, k, V, dp_sb, dp_sk, di_sb, di_sk,
                        bonus_stride, accepted, recovered, out_tokens, counters, active_lens);
+    return 0;
+}
+
+// ---------------------------------------------------------------- typical acceptance (MEDUSA 3.3.1)
+// TypicalAcceptanceSampler.forward (vllm/model_executor/layers/typical_acceptance_sampler.py:37-172), deterministic:
+//   accepted[b,i]  = q[b,i,x] > min(posterior_threshold, posterior_alpha * exp(-H)),  H = -sum_v q_v log(q_v + 1e-5)
+//   recovered[b,i] = argmax_v q[b,i,v]           (first index on ties, as torch.argmax)
+// then the shared _create_output.  q = target_with_bonus_probs[:, :-1].  Same launch shape as the rejection sampler: each
+// (b, i) row in QS_SM_CHUNKS chunks over the chip -- the entropy terms in fp32 as the reference forms them (add, log,
+// multiply), summed in fp64 in chunk order and rounded once -- then one workgroup for the decision and the output.
+__global__ __launch_bounds__(256) void typical_entropy_kernel(const float* __restrict__ target_probs, int k, int V,
+                                                              double* __restrict__ part_s, SmPartA* __restrict__ part_a) {
+    __shared__ double red_d[4];
+    __shared__ ArgMax red_a[4];
+    const int c = blockIdx.x, bk = blockIdx.y, b = bk / k, i = bk % k;
+    int lo, hi;
+    sm_chunk_range(V, c, lo, hi);
+    const float* q = target_probs + ((size_t)b * (k + 1) + i) * V;
+    double s = 0.0;
+    ArgMax am{-__builtin_inff(), 0x7fffffff};
+    for (int v = lo + threadIdx.x; v < hi; v += 256) {
+        const float qv = q[v];
+        s += (double)(qv * logf(qv + 1e-5f));
+        if (qv > am.v) {
+            am.v = qv;
+            am.i = v;
+        }
+    }
+    s = block_sum_f64(s, red_d);
+    am = block_argmax(am, red_a);
+    if (threadIdx.x == 0) {
+        part_s[bk * QS_SM_CHUNKS + c] = s;
+        part_a[bk * QS_SM_CHUNKS + c] = SmPartA{am.v, am.i};
+    }
+}
+__global__ __launch_bounds__(1024) void typical_output_kernel(
+    const float* __restrict__ target_probs, const int64_t* __restrict__ draft_ids, const int64_t* __restrict__ bonus_ids,
+    float posterior_threshold, float posterior_alpha, const double* part_s, const SmPartA* part_a, int B, int k, int V,
+    int64_t di_sb, int64_t di_sk, int64_t bonus_stride, uint8_t* __restrict__ accepted, int64_t* __restrict__ recovered,
+    int64_t* __restrict__ out, int64_t* __restrict__ counters, const int32_t* __restrict__ active_lens) {
+    for (int bk = threadIdx.x; bk < B * k; bk += blockDim.x) {
+        const int b = bk / k, i = bk % k;
+        double tot = 0.0;
+        ArgMax am{-__builtin_inff(), 0x7fffffff};
+        for (int c = 0; c < QS_SM_CHUNKS; c++) {
+            tot += part_s[bk * QS_SM_CHUNKS + c];
+            SmPartA pa = part_a[bk * QS_SM_CHUNKS + c];
+            am = argmax_combine(am, ArgMax{pa.v, pa.i});
+        }
+        const float H = -(float)tot;
+        const float thr = fminf(posterior_threshold, qexpf(-H) * posterior_alpha);
+        const int64_t x = draft_ids[b * di_sb + i * di_sk];
+        const float cand = target_probs[((size_t)b * (k + 1) + i) * V + x];
+        const bool row_on = !active_lens || active_lens[b] > 0;
+        accepted[bk] = (row_on && cand > thr) ? 1 : 0;
+        recovered[bk] = am.i == 0x7fffffff ? 0 : am.i;
+    }
+    __syncthreads();
+    create_output(B, k, draft_ids, di_sb, di_sk, bonus_ids, bonus_stride, accepted, recovered, out, counters, active_lens);
+}
+int typical_acceptance_sample(const float* target_probs, const int64_t* draft_ids, const int64_t* bonus_ids,
+                              float posterior_threshold, float posterior_alpha, int B, int k, int V, int64_t di_sb,
+                              int64_t di_sk, int64_t bonus_stride, int64_t* out_tokens, uint8_t* accepted, int64_t* recovered,
+                              int64_t* counters, const int32_t* active_lens, void* ws, hipStream_t st) {
+    if (B == 0) return 0;
+    if (k < 1) return -1;
+    SmPartA* part_a = reinterpret_cast<SmPartA*>(ws);
+    double* part_s = reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + (size_t)B * k * QS_SM_CHUNKS * 8);
+    hipLaunchKernelGGL(typical_entropy_kernel, dim3(QS_SM_CHUNKS, B * k), dim3(256), 0, st, target_probs, k, V, part_s, part_a);
+    hipLaunchKernelGGL(typical_output_kernel, dim3(1), dim3(1024), 0, st, target_probs, draft_ids, bonus_ids, posterior_threshold,
+                       posterior_alpha, part_s, part_a, B, k, V, di_sb, di_sk, bonus_stride, accepted, recovered, out_tokens,
+                       counters, active_lens);
     return 0;
 }
 

@@ -607,6 +607,21 @@ def rejection_sample(target_with_bonus_probs, bonus_token_ids, draft_probs, draf
           _opt(active_lens, "active_lens", _I32), _sampler_ws(B * k, draft_probs.device, workspace).data_ptr(), _stream())
 
 
+def typical_acceptance_sample(target_with_bonus_probs, bonus_token_ids, draft_token_ids, posterior_threshold: float,
+                              posterior_alpha: float, out_tokens, accepted, recovered, counters=None, workspace=None,
+                              active_lens=None):
+    B, k1, V = target_with_bonus_probs.shape
+    k = k1 - 1
+    if draft_token_ids.dtype != _I64 or bonus_token_ids.dtype != _I64 or not target_with_bonus_probs.is_cuda:
+        raise RuntimeError("ids must be int64; all tensors on the GPU")
+    _call("qspec_typical_acceptance_sample", _chk(target_with_bonus_probs, "target_with_bonus_probs", _F32),
+          bonus_token_ids.data_ptr(), draft_token_ids.data_ptr(), float(posterior_threshold), float(posterior_alpha), B, k, V,
+          draft_token_ids.stride(0), draft_token_ids.stride(1),
+          bonus_token_ids.stride(0) if bonus_token_ids.numel() > 1 else 1, _chk(out_tokens, "out_tokens", _I64),
+          _chk(accepted, "accepted", _U8), _chk(recovered, "recovered", _I64), _opt(counters, "counters", _I64),
+          _opt(active_lens, "active_lens", _I32), _sampler_ws(B * k, target_with_bonus_probs.device, workspace).data_ptr(), _stream())
+
+
 def advance_step_flashattn(num_seqs, num_queries, block_size, input_tokens, sampled_token_ids, input_positions,
                            seq_lens, slot_mapping, block_tables):
     """ops.advance_step_flashattn (vllm/_custom_ops.py; csrc/prepare_inputs/advance_step.cu:192)."""

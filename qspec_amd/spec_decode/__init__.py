@@ -2,6 +2,7 @@
 from .engine import QSpecEngine  # noqa: F401
 from .metrics import AsyncMetricsCollector, SpecDecodeWorkerMetrics  # noqa: F401
 from .rejection_sampler import RejectionSampler  # noqa: F401
+from .typical_acceptance_sampler import TypicalAcceptanceSampler  # noqa: F401
 from .worker import (CompletionSequenceGroupOutput, DeviceHandoffTimeout, ExecuteModelRequest, Logprob,  # noqa: F401
                      SamplerOutput, SamplingParams, SequenceData, SequenceGroupMetadata, SequenceOutput,
                      SpecDecodeWorker, SpeculativeConfig, create_spec_worker)

@@ -61,7 +61,7 @@ def n_splits_for(ctx: int, n_groups: int = 0) -> int:
 class QSpecEngine:
     def __init__(self, model: QuarotLlamaForCausalLM, num_speculative_tokens: int = 3, max_batch: int = 4,
                  max_model_len: int = 1024, block_size: int = 16, max_new_tokens: int = 1024, use_graph: bool = True,
-                 seed: int = 0, num_blocks: Optional[int] = None):
+                 seed: int = 0, num_blocks: Optional[int] = None, acceptance_sampler=None):
         self.model = model
         self.cfg = cfg = model.config
         if max_model_len > cfg.max_position_embeddings:
@@ -135,7 +135,9 @@ class QSpecEngine:
         self.recoveries = 0                                         # cycles re-run without device-side hand-offs
         self.accepted = torch.zeros(B, k, dtype=torch.uint8, device=dev)
         self.recovered = torch.zeros(B, k, dtype=i64, device=dev)
-        self.sampler = RejectionSampler(seed=seed)
+        # the acceptance sampler (spec_decode_worker.py:95-110): RejectionSampler by default, or the instance handed in
+        # (TypicalAcceptanceSampler) -- same call surface, same counters
+        self.sampler = acceptance_sampler if acceptance_sampler is not None else RejectionSampler(seed=seed)
         self.sampler.init_gpu_tensors(str(dev))
         self.scratch_draft = Scratch(cfg, B, B, 1, n_splits, dev)
         self.scratch_verify = Scratch(cfg, T, B, k + 1, n_splits, dev)

@@ -165,7 +165,9 @@ class SpeculativeConfig:
     num_speculative_tokens: int = 3
     speculative_disable_mqa_scorer: bool = False
     speculative_disable_by_batch_size: Optional[int] = None
-    draft_token_acceptance_method: str = "rejection_sampler"
+    draft_token_acceptance_method: str = "rejection_sampler"       # or "typical_acceptance_sampler"
+    typical_acceptance_sampler_posterior_threshold: float = 0.09    # vllm/config.py defaults
+    typical_acceptance_sampler_posterior_alpha: float = 0.3
     disable_logprobs: bool = True        # vllm/config.py:1788-1789: logprobs are off during speculation by default
     disable_log_stats: bool = False
 
@@ -220,8 +222,8 @@ def create_spec_worker(*args, **kwargs) -> "SpecDecodeWorker":
         if getattr(par, "pipeline_parallel_size", 1) > 1:                           # :61-63
             raise NotImplementedError("Speculative decoding is currently incompatible with pipeline parallelism")
         method = getattr(spec, "draft_token_acceptance_method", "rejection_sampler")
-        if method != "rejection_sampler":
-            raise NotImplementedError("only the rejection sampler is on the QSpec path")
+        if method not in ("rejection_sampler", "typical_acceptance_sampler"):       # :95-110
+            raise ValueError(f"draft_token_acceptance_method {method!r}: expected rejection_sampler or typical_acceptance_sampler")
         mc, cc, sc = vllm_config.model_config, vllm_config.cache_config, vllm_config.scheduler_config
         model_type = getattr(mc.hf_config, "model_type", "llama_quarot")
         if model_type not in ("llama_quarot", "llama"):
@@ -247,8 +249,9 @@ def create_spec_worker(*args, **kwargs) -> "SpecDecodeWorker":
     if kwargs.get("pipeline_parallel_size", 1) > 1:
         raise NotImplementedError("Speculative decoding is currently incompatible with pipeline parallelism")
     spec = kwargs.get("speculative_config") or SpeculativeConfig()
-    if spec.draft_token_acceptance_method != "rejection_sampler":
-        raise NotImplementedError("only the rejection sampler is on the QSpec path")
+    if spec.draft_token_acceptance_method not in ("rejection_sampler", "typical_acceptance_sampler"):
+        raise ValueError(f"draft_token_acceptance_method {spec.draft_token_acceptance_method!r}: expected rejection_sampler or "
+                         "typical_acceptance_sampler")
     cfg = kwargs.get("model_config", "llama-3-8b")
     if isinstance(cfg, str):
         cfg = CONFIGS[cfg]
@@ -388,7 +391,7 @@ class SpecDecodeWorker:
         blocks_per_seq = (per_seq + k + 2 + self.block_size - 1) // self.block_size
         n_blocks = self.max_num_seqs * blocks_per_seq
         eng = self._engine_factory(self._model, k, self.max_num_seqs, self.max_model_len, self.block_size,
-                                   seed=self._seed, num_blocks=n_blocks)
+                                   seed=self._seed, num_blocks=n_blocks, **self._sampler_kwargs())
         kv_bytes = n_blocks * self.cache_block_size_bytes()
         tables = [list(range(b * blocks_per_seq, (b + 1) * blocks_per_seq)) for b in range(self.max_num_seqs)]
         eng.add_sequences_to(list(range(self.max_num_seqs)), [[0] * per_seq] * self.max_num_seqs, tables)
@@ -430,9 +433,19 @@ class SpecDecodeWorker:
                              "increasing `gpu_memory_utilization` or decreasing `max_model_len` when initializing the engine.")
         self.engine = self._engine_factory(self._model, self.speculative_config.num_speculative_tokens,
                                            self.max_num_seqs, self.max_model_len, self.block_size, seed=self._seed,
-                                           num_blocks=num_gpu_blocks)
+                                           num_blocks=num_gpu_blocks, **self._sampler_kwargs())
         self._metrics = AsyncMetricsCollector(self.engine.sampler)
         self._metrics.init_gpu_tensors(self._rank)
+
+    def _sampler_kwargs(self) -> dict:
+        """spec_decode_worker.py:95-110: the acceptance sampler named by `draft_token_acceptance_method`."""
+        spec = self.speculative_config
+        if getattr(spec, "draft_token_acceptance_method", "rejection_sampler") != "typical_acceptance_sampler":
+            return {}
+        from .typical_acceptance_sampler import TypicalAcceptanceSampler
+        return {"acceptance_sampler": TypicalAcceptanceSampler(
+            posterior_threshold=getattr(spec, "typical_acceptance_sampler_posterior_threshold", 0.09),
+            posterior_alpha=getattr(spec, "typical_acceptance_sampler_posterior_alpha", 0.3), seed=self._seed)}
 
     def get_cache_block_size_bytes(self):
         raise NotImplementedError  # as the reference (:1259-1268)

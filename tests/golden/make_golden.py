@@ -9,7 +9,8 @@ What is imported from the reference (by file path; nothing is copied):
       (needs the names `fast_hadamard_transform` / `fast_hadamard_transform_cuda` to exist at
        import time; they are CUDA extension modules absent here, so two EMPTY module objects are
        registered -- none of the functions called below touch them)
-  * vllm/model_executor/layers/{spec_decode_base_sampler,rejection_sampler}.py   RejectionSampler on CPU
+  * vllm/model_executor/layers/{spec_decode_base_sampler,rejection_sampler,typical_acceptance_sampler}.py
+      RejectionSampler and TypicalAcceptanceSampler on CPU
       (imported under an empty package shell `vllm` providing only envs.VLLM_USE_FLASHINFER_SAMPLER,
        logger.init_logger and platforms.current_platform.simple_compile_backend = "eager")
   * third-party/ao/test/test_rowwise_scaled_linear_cutlass.py:64-84 is a formula, restated below
@@ -388,6 +389,52 @@ def gen_sym_quant_w4a16():
     np.savez_compressed(os.path.join(OUT, "sym_quant_w4a16.npz"), **out)
 
 
+def gen_typical_acceptance():
+    """Run the reference TypicalAcceptanceSampler (vllm/model_executor/layers/typical_acceptance_sampler.py) on CPU: it is
+    deterministic, so inputs + outputs are the whole fixture.  Flavours: random peaked distributions, draft = target argmax
+    (all accepted), one-hot targets (entropy 0: threshold = min(eps, alpha)), near-uniform targets (high entropy: a tiny
+    threshold), and thresholds / alphas across the reference's defaults (0.09 / 0.3, spec_decode_worker.py:95-110)."""
+    import_ref_sampler()
+    ta = load_by_path("vllm.model_executor.layers.typical_acceptance_sampler",
+                      f"{REF}/vllm/model_executor/layers/typical_acceptance_sampler.py")
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    idx = 0
+    for (B, k, V, thr, alpha) in [(4, 3, 257, 0.09, 0.3), (3, 5, 1000, 0.09, 0.3), (10, 5, 512, 0.3, 0.6), (1, 1, 64, 0.01, 0.1),
+                                  (8, 4, 2048, 0.09, 0.3)]:
+        for flavour in ("random", "argmax", "onehot", "flat"):
+            if flavour == "random":
+                tq = torch.softmax(torch.randn(B, k + 1, V, generator=g) * 4, -1)
+                ids = torch.multinomial(tq[:, :k].reshape(-1, V), 1, generator=g).reshape(B, k)
+                ids = torch.where(torch.rand(B, k, generator=g) < 0.5, ids, torch.randint(0, V, (B, k), generator=g))
+            elif flavour == "argmax":
+                tq = torch.softmax(torch.randn(B, k + 1, V, generator=g) * 6, -1)
+                ids = tq[:, :k].argmax(-1)
+            elif flavour == "onehot":
+                tq = torch.zeros(B, k + 1, V)
+                hot = torch.randint(0, V, (B, k + 1), generator=g)
+                tq[torch.arange(B)[:, None], torch.arange(k + 1)[None], hot] = 1
+                agree = torch.rand(B, k, generator=g) < 0.6
+                ids = torch.where(agree, hot[:, :k], torch.randint(0, V, (B, k), generator=g))
+            else:
+                tq = torch.softmax(torch.randn(B, k + 1, V, generator=g) * 0.05, -1)
+                ids = torch.randint(0, V, (B, k), generator=g)
+            bonus = torch.randint(0, V, (B, 1), generator=g)
+            sampler = ta.TypicalAcceptanceSampler(posterior_threshold=thr, posterior_alpha=alpha)
+            sampler.init_tensors(device="cpu", device_type="cpu")
+            o = sampler(tq, bonus, draft_probs=None, draft_token_ids=ids)
+            key = f"t{idx}_"
+            out[key + "tq"], out[key + "ids"], out[key + "bonus"] = tq.numpy().astype(np.float32), ids.numpy(), bonus.numpy()
+            out[key + "params"] = np.array([thr, alpha], np.float64)
+            out[key + "out"] = o.numpy()
+            out[key + "accepted"] = sampler._evaluate_accepted_tokens(tq[:, :-1], ids).numpy()
+            out[key + "counters"] = np.array([int(sampler.num_accepted_tokens), int(sampler.num_emitted_tokens),
+                                              int(sampler.num_draft_tokens)], np.int64)
+            idx += 1
+    out["cases"] = np.array(idx)
+    np.savez_compressed(os.path.join(OUT, "typical_acceptance.npz"), **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference checkout is only present in the build container"
     gen_pack()
@@ -397,6 +444,7 @@ if __name__ == "__main__":
     gen_attention()
     gen_rope_cache_softmax()
     gen_sym_quant_w4a16()
+    gen_typical_acceptance()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

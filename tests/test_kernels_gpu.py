@@ -1408,6 +1408,39 @@ def test_attention_waves_kernel_dev_forms(switch, kexpr):
     assert " passed" in r.stdout
 
 
+def test_typical_acceptance_sampler_reference_fixture(ops, oracle, golden_dir):
+    """TypicalAcceptanceSampler on the GPU against the REFERENCE class run on CPU (tests/golden/typical_acceptance.npz, 20
+    deterministic cases): output layout, accept masks, counters exact; the replacement token = the target's argmax; through
+    the class with the reference's call surface, with strided draft ids and an inactive row."""
+    from qspec_amd.spec_decode import TypicalAcceptanceSampler
+    g = np.load(os.path.join(golden_dir, "typical_acceptance.npz"))
+    for i in range(int(g["cases"])):
+        thr, alpha = (float(v) for v in g[f"t{i}_params"])
+        tq, ids, bonus = g[f"t{i}_tq"], g[f"t{i}_ids"], g[f"t{i}_bonus"]
+        B, k = ids.shape
+        s = TypicalAcceptanceSampler(thr, alpha)
+        s.init_gpu_tensors(DEV)
+        acc = torch.empty(B, k, dtype=torch.uint8, device=DEV); rec = torch.empty(B, k, dtype=torch.int64, device=DEV)
+        ids_kb = dev(np.ascontiguousarray(ids.T))                      # step-major draft ids, as the engine holds them
+        out = s(dev(tq), dev(bonus), None, ids_kb.transpose(0, 1), accepted=acc, recovered=rec)
+        torch.cuda.synchronize()
+        assert np.array_equal(host(out), g[f"t{i}_out"]), i
+        assert np.array_equal(host(acc).astype(bool), g[f"t{i}_accepted"]), i
+        assert s.counters.tolist() == list(g[f"t{i}_counters"]), i
+        assert np.array_equal(host(rec), tq[:, :-1].argmax(-1)), i
+        o2, a2, r2, c2, _ = oracle.typical_acceptance_sample(tq, bonus, ids, thr, alpha)
+        assert np.array_equal(host(out), o2) and np.array_equal(host(acc).astype(bool), a2)
+    # an empty batch slot emits nothing and is not counted
+    tq, ids, bonus = g["t8_tq"], g["t8_ids"], g["t8_bonus"]
+    B, k = ids.shape
+    s = TypicalAcceptanceSampler(*(float(v) for v in g["t8_params"]))
+    s.init_gpu_tensors(DEV)
+    lens = torch.ones(B, dtype=torch.int32, device=DEV); lens[3] = 0
+    out = s(dev(tq), dev(bonus), None, dev(ids), active_lens=lens)
+    ref = g["t8_out"].copy(); ref[3] = -1
+    assert np.array_equal(host(out), ref) and int(s.counters[2]) == (B - 1) * k
+
+
 # ------------------------------------------------------------------ the reference's own pure-torch formulas (fixtures)
 # tests/golden/{attention,rope_cache_softmax}.npz: outputs of ref_paged_attn (tests/kernels/test_flash_attn.py:19-75),
 # RotaryEmbedding.forward_native (rotary_embedding.py:201-229), the reshape_and_cache_flash reference loop

@@ -455,6 +455,31 @@ def test_full_depth_distance_to_true_math(oracle):
     assert np.array_equal(ref_l.astype(np.float32).argmax(-1)[clear], true_l.argmax(-1)[clear])
 
 
+def test_engine_cycle_with_typical_acceptance_sampler(tiny, oracle):
+    """The cycle with draft_token_acceptance_method = typical_acceptance_sampler: the engine's output must be what the
+    reference rule (the oracle's restatement, pinned to the reference class by tests/golden/typical_acceptance.npz) gives on
+    the GPU's own target distribution and draft tokens; the captured graph replays it; counters follow."""
+    from qspec_amd.spec_decode import QSpecEngine, TypicalAcceptanceSampler
+    rng = np.random.default_rng(21)
+    prompts = [rng.integers(0, tiny.config.vocab_size, n).tolist() for n in (20, 31, 8, 50)]
+    gens = []
+    for use_graph in (False, True):
+        eng = QSpecEngine(tiny, 3, 4, max_model_len=256, block_size=16, max_new_tokens=64, use_graph=use_graph, seed=5,
+                          acceptance_sampler=TypicalAcceptanceSampler(0.09, 0.3))
+        eng.add_sequences(prompts)
+        for _ in range(4):
+            eng.step()
+            torch.cuda.synchronize()
+            out, acc, rec, c, _ = oracle.typical_acceptance_sample(eng.target_probs.cpu().numpy(), eng.target_tokens[:, 3].cpu().numpy(),
+                                                                   eng.draft_ids_kb.t().cpu().numpy(), 0.09, 0.3)
+            assert np.array_equal(eng.out_tokens.cpu().numpy(), out)
+            assert np.array_equal(eng.accepted.cpu().numpy().astype(bool), acc)
+        m = eng.metrics()
+        assert m.draft_tokens == 4 * 4 * 3 and m.emitted_tokens >= 16
+        gens.append(eng.generated())
+    assert gens[0] == gens[1]
+
+
 def test_graph_replay_equals_eager(tiny):
     """The captured hipGraph of the cycle produces the same tokens as the eager cycle (same Philox stream)."""
     from qspec_amd.spec_decode import QSpecEngine

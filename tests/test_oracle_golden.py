@@ -302,3 +302,20 @@ def test_w4a16_against_reference_dequantised_matmul(oracle, golden_dir):
             e_ref = np.abs(ref - exact) / den
             if x.shape[1] >= 4096:   # the reference form's weight rounding shows from K ~ 4 k on
                 assert np.sqrt((e_or ** 2).mean()) <= np.sqrt((e_ref ** 2).mean()) * 1.5, (idx, name)
+
+
+def test_typical_acceptance_matches_reference_run(oracle, golden_dir):
+    """The oracle's TypicalAcceptanceSampler against the reference class itself run on CPU (make_golden.py: deterministic, 20
+    cases over four flavours): output layout, accept masks and the three counters, exactly."""
+    g = _load(golden_dir, "typical_acceptance.npz")
+    n = int(g["cases"])
+    assert n == 20
+    seen = set()
+    for i in range(n):
+        thr, alpha = g[f"t{i}_params"]
+        out, acc, rec, c, H = oracle.typical_acceptance_sample(g[f"t{i}_tq"], g[f"t{i}_bonus"], g[f"t{i}_ids"], thr, alpha)
+        assert np.array_equal(out, g[f"t{i}_out"]), i
+        assert np.array_equal(acc, g[f"t{i}_accepted"]), i
+        assert list(c) == list(g[f"t{i}_counters"]), i
+        seen |= set(np.unique(acc).tolist())
+    assert seen == {False, True}

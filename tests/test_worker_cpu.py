@@ -28,8 +28,9 @@ class FakeSampler:
 class FakeEngine:
     """The QSpecEngine surface the worker uses, with scripted outputs: out_script(step_index, slots) -> [B, k+1]."""
 
-    def __init__(self, model, k, B, max_model_len, block_size, seed=0, num_blocks=None):
+    def __init__(self, model, k, B, max_model_len, block_size, seed=0, num_blocks=None, acceptance_sampler=None):
         self.k, self.B = k, B
+        self.acceptance_sampler = acceptance_sampler
         self.num_blocks = num_blocks
         self.err_script = []          # error words the next read_outputs() calls return (then 0)
         self.recoveries = 0
@@ -516,6 +517,27 @@ def test_engine_free_slot_forgets_a_brought_block_table():
     eng._len_ub[1] = 5
     eng.free_slot(1)
     assert eng.block_tables[1].tolist() == [4, 5, 6, 7] and eng._capacity[1] == 64 and eng._bt_host[1] is None
+
+
+def test_acceptance_method_selects_the_sampler():
+    """spec_decode_worker.py:95-110: draft_token_acceptance_method picks RejectionSampler (default) or
+    TypicalAcceptanceSampler with the two posterior parameters; anything else is refused."""
+    from qspec_amd.spec_decode import TypicalAcceptanceSampler
+    w = make_worker()
+    assert w.engine.acceptance_sampler is None                       # the engine's default: RejectionSampler
+    spec = SpeculativeConfig(3, draft_token_acceptance_method="typical_acceptance_sampler",
+                             typical_acceptance_sampler_posterior_threshold=0.2, typical_acceptance_sampler_posterior_alpha=0.5)
+    w = create_spec_worker(model_config=CFG, model=object(), speculative_config=spec, max_num_seqs=2, max_model_len=256,
+                           block_size=16, device="cpu", engine_factory=FakeEngine, disable_log_stats=True,
+                           memory_probe=fake_memory_probe)
+    w.init_device()
+    nb, _ = w.determine_num_available_blocks()
+    w.initialize_cache(nb, 0)
+    s = w.engine.acceptance_sampler
+    assert isinstance(s, TypicalAcceptanceSampler) and (s._posterior_threshold, s._posterior_alpha) == (0.2, 0.5)
+    with pytest.raises(ValueError, match="draft_token_acceptance_method"):
+        create_spec_worker(model_config=CFG, model=object(), speculative_config=SpeculativeConfig(3, draft_token_acceptance_method="x"),
+                           engine_factory=FakeEngine, device="cpu")
 
 
 def test_failed_admission_gives_the_slots_back():
