@@ -389,6 +389,21 @@ int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* 
                            int64_t* out_tokens, uint8_t* accepted, int64_t* recovered, int64_t* counters,
                            const int32_t* active_lens, void* workspace, void* stream);
 
+/* Sampler.forward for rows that are NOT plain greedy (vllm/model_executor/layers/sampler.py:216-316):
+ *   l = float(logits) / temperature[row] (a temperature < 1e-5 marks a greedy row of a mixed batch: divisor 1.0, token =
+ *   argmax; sampling_metadata.py:413-417), _apply_top_k_top_p (:387-413; top_k <= 0 or >= vocab: off; top_p >= 1: off),
+ *   probs = softmax(masked l) fp32 [tokens, vocab], token = argmax(probs / Exp(1)) (_multinomial :585-604).
+ *   temperature / top_k / top_p: per-row device arrays, each may be NULL (1.0 / off / off).
+ *   exponential [tokens, vocab] fp32: injected draws (tests); NULL -> Philox(seed, offset) as qspec_rejection_sample, with
+ *   rng_state (device uint64[2]) overriding the scalars and advanced by the call.
+ *   Tokens with EQUAL logits at the top-p boundary are kept or masked together (the reference's unstable sort splits such a
+ *   group arbitrarily); everything else follows the reference element for element.
+ *   workspace: qspec_sample_workspace_bytes(tokens), zero-filled ONCE by the caller (every call leaves it zeroed). */
+size_t qspec_sample_workspace_bytes(int rows);
+int qspec_sample_top_k_top_p(const qspec_half* logits, const float* temperature, const int32_t* top_k, const float* top_p,
+                             const float* exponential, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* probs,
+                             int64_t* token, int64_t token_stride, int tokens, int vocab, void* workspace, void* stream);
+
 /* TypicalAcceptanceSampler.forward(target_with_bonus_probs, bonus_token_ids, draft_probs, draft_token_ids)
  *   vllm/model_executor/layers/typical_acceptance_sampler.py:37-172 (MEDUSA 3.3.1), selected by
  *   draft_token_acceptance_method = "typical_acceptance_sampler" (vllm/spec_decode/spec_decode_worker.py:95-110).

@@ -332,6 +332,45 @@ def rejection_sample(target_with_bonus_probs, bonus_token_ids, draft_probs, draf
     return out, accepted, recovered, counters
 
 
+def sample_top_k_top_p(logits, temperature, top_k, top_p, exponential):
+    """Sampler.forward for non-greedy rows (vllm/model_executor/layers/sampler.py:216-316) with the exponential draws injected:
+    l = f32(logits) / T; _apply_top_k_top_p (:387-413) op for op -- ascending sort, top-k threshold = sorted[V - k] (ties kept),
+    softmax of the rest, ascending fp32 cumsum (sequential, as torch on CPU), mask where cumsum <= 1 - p, never the last --;
+    probs = softmax(masked l); token = argmax(probs / E) (_multinomial :585-604), argmax(probs) for rows with T < 1e-5.
+    The final softmax uses the oracle's own exp (qexpf) and an fp64 denominator like softmax_argmax.
+    Returns (probs [T,V] f32, token [T] i64, keep mask [T,V] bool)."""
+    lg = np.asarray(logits, np.float16).astype(np.float32)
+    Tn, V = lg.shape
+    temperature = np.ones(Tn, np.float32) if temperature is None else np.asarray(temperature, np.float32)
+    top_k = np.full(Tn, -1, np.int64) if top_k is None else np.asarray(top_k, np.int64)
+    top_p = np.ones(Tn, np.float32) if top_p is None else np.asarray(top_p, np.float32)
+    probs = np.zeros((Tn, V), np.float32)
+    keep = np.ones((Tn, V), bool)
+    tok = np.zeros(Tn, np.int64)
+    for t in range(Tn):
+        greedy = temperature[t] < 1e-5
+        l = (lg[t] / (np.float32(1.0) if greedy else temperature[t])).astype(np.float32)
+        order = np.argsort(l, kind="stable")
+        ls = l[order].copy()
+        k = int(top_k[t])
+        if k <= 0 or k > V:
+            k = V
+        ls[ls < ls[V - k]] = -np.inf
+        e = np.exp((ls - ls[-1]).astype(np.float64))
+        ps = (e / e.sum()).astype(np.float32)
+        cs = np.cumsum(ps, dtype=np.float32)
+        m = cs <= np.float32(1.0) - top_p[t]
+        m[-1] = False
+        ls[m] = -np.inf
+        keep[t, order] = np.isfinite(ls)
+        mx = l[keep[t]].max()
+        ex = np.where(keep[t], expf((l - mx).astype(np.float32)), np.float32(0.0)).astype(np.float32)
+        z = np.float32(ex.astype(np.float64).sum())
+        probs[t] = (ex / z).astype(np.float32)
+        tok[t] = int(np.argmax(probs[t])) if greedy else int(np.argmax((probs[t] / np.asarray(exponential, np.float32)[t]).astype(np.float32)))
+    return probs, tok, keep
+
+
 def typical_acceptance_sample(target_with_bonus_probs, bonus_token_ids, draft_token_ids, posterior_threshold, posterior_alpha):
     """TypicalAcceptanceSampler.forward (vllm/model_executor/layers/typical_acceptance_sampler.py:37-172):
     accepted = q[x] > min(posterior_threshold, posterior_alpha * exp(-H)), H = -sum_v q log(q + 1e-5) (fp32 terms as the

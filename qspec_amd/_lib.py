@@ -89,6 +89,8 @@ SIGNATURES = {
     "qspec_lm_head_softmax_argmax": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "qspec_rejection_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _i, _i, _i, _i64, _i64, _i64, _i64,
                                     _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "qspec_sample_workspace_bytes": (_sz, [_i]),
+    "qspec_sample_top_k_top_p": (_i, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     "qspec_typical_acceptance_sample": (_i, [_vp, _vp, _vp, _f, _f, _i, _i, _i, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qspec_advance_step_flashattn": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qspec_spec_prepare_draft": (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -373,6 +373,18 @@ int qspec_rejection_sample(const float* target_with_bonus_probs, const int64_t* 
     if (k < 1) return fail("%s: k=%d must be >= 1", op, k);
     return finish(op, qspec::rejection_sample(target_with_bonus_probs, draft_probs, draft_token_ids, bonus_token_ids, uniform, exponential, seed, offset, rng_state, batch, k, vocab, dp_stride_b, dp_stride_k, ids_stride_b, ids_stride_k, bonus_stride, out_tokens, accepted, recovered, counters, active_lens, workspace, ST));
 }
+size_t qspec_sample_workspace_bytes(int rows) { return qspec::sample_ws_bytes(rows); }
+int qspec_sample_top_k_top_p(const qspec_half* logits, const float* temperature, const int32_t* top_k, const float* top_p,
+                             const float* exponential, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* probs,
+                             int64_t* token, int64_t token_stride, int tokens, int vocab, void* workspace, void* stream) {
+    const char* op = "qspec_sample_top_k_top_p";
+    if (tokens < 0) return fail("%s: tokens < 0", op);
+    if (tokens == 0) return 0;
+    NONNULL(op, logits); NONNULL(op, probs); NONNULL(op, token); NONNULL(op, workspace);
+    if (vocab < 1) return fail("%s: vocab < 1", op);
+    return finish(op, qspec::sample_top_k_top_p(CH(logits), temperature, top_k, top_p, exponential, seed, offset, rng_state, probs,
+                                                token, token_stride, tokens, vocab, workspace, ST));
+}
 int qspec_typical_acceptance_sample(const float* target_with_bonus_probs, const int64_t* bonus_token_ids,
                                     const int64_t* draft_token_ids, float posterior_threshold, float posterior_alpha, int batch,
                                     int k, int vocab, int64_t ids_stride_b, int64_t ids_stride_k, int64_t bonus_stride,

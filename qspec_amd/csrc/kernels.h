@@ -161,6 +161,10 @@ int rejection_sample(const float* target_probs, const float* draft_probs, const 
                      uint64_t offset, uint64_t* rng_state, int B, int k, int V, int64_t dp_sb, int64_t dp_sk,
                      int64_t di_sb, int64_t di_sk, int64_t bonus_stride, int64_t* out_tokens, uint8_t* accepted,
                      int64_t* recovered, int64_t* counters, const int32_t* active_lens, void* ws, hipStream_t st);
+size_t sample_ws_bytes(int rows);
+int sample_top_k_top_p(const f16* logits, const float* temperature, const int32_t* top_k, const float* top_p,
+                       const float* exponential, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* probs,
+                       int64_t* token, int64_t token_stride, int T, int V, void* ws, hipStream_t st);
 int typical_acceptance_sample(const float* target_probs, const int64_t* draft_ids, const int64_t* bonus_ids,
                               float posterior_threshold, float posterior_alpha, int B, int k, int V, int64_t di_sb,
                               int64_t di_sk, int64_t bonus_stride, int64_t* out_tokens, uint8_t* accepted, int64_t* recovered,

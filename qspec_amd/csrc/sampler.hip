@@ -434,6 +434,256 @@ int typical_acceptance_sample(const float* target_probs, const int64_t* draft_id
     return 0;
 }
 
+// ---------------------------------------------------------------- Sampler.forward, the non-greedy rows
+// vllm/model_executor/layers/sampler.py:216-316: l = float(logits) / temperature; _apply_top_k_top_p (:387-413: ascending
+// sort; keep the top_k largest -- ties at the k-th value kept --; softmax of what is left; mask where the ASCENDING cumulative
+// probability is <= 1 - top_p, never the last); probs = softmax(masked l); token = argmax(probs / Exp(1)) (_multinomial
+// :585-604) or, for rows with temperature < 1e-5 (greedy requests of a mixed batch: scaled by 1.0, sampling_metadata.py:413-417),
+// argmax(probs).
+//
+// No sort.  The logits are fp16 and l is monotonic in the logit for a positive temperature, so the ORDER of a row is the
+// order of 65536 possible keys: (1) a histogram of the row's keys (integer atomics: deterministic); (2) one workgroup per row
+// walks the keys in descending order -- 64 per thread, exclusive block scans of the counts and of the probability mass
+// count x exp(l - max) in fp64 -- and finds the top-k key (the k-th largest value), the mass Z_k of what top-k keeps, the
+// top-p key (the lowest key whose strictly-larger keys hold less than top_p x Z_k of the mass: the reference's ascending-
+// cumsum rule evaluated per group of EQUAL logits -- inside such a group the reference masks whichever members its unstable
+// sort happened to put first; here a boundary group stays whole, deterministic) and the final denominator; (3) an
+// elementwise pass writes probs ONCE and leaves per-chunk argmax partials of probs / noise; (4) a last small launch
+// combines them.  The histogram is left zeroed for the next call.
+#define QS_TK_KEYS 65536
+__device__ __forceinline__ uint32_t tk_key(f16 h) {   // order-preserving: larger logit -> larger key
+    const uint16_t b = __builtin_bit_cast(uint16_t, h);
+    return (b & 0x8000u) ? (uint32_t)(uint16_t)~b : (uint32_t)(b | 0x8000u);
+}
+__device__ __forceinline__ float tk_val(uint32_t key) {   // the logit of a key
+    const uint16_t b = (key & 0x8000u) ? (uint16_t)(key & 0x7FFFu) : (uint16_t)~key;
+    return h2f(__builtin_bit_cast(f16, b));
+}
+struct TkRow {      // what pass 3 needs of a row
+    uint32_t tau;   // keys >= tau are kept
+    float temp;     // the divisor (1.0 for greedy rows)
+    float mx;       // max l
+    float z;        // float(sum of exp(l - mx) over the kept tokens)
+    int greedy;
+    int pad[3];
+};
+__global__ __launch_bounds__(256) void topk_hist_kernel(const f16* __restrict__ logits, uint32_t* __restrict__ hist, int V) {
+    const int c = blockIdx.x, t = blockIdx.y;
+    int lo, hi;
+    sm_chunk_range(V, c, lo, hi);
+    const f16* l = logits + (size_t)t * V;
+    uint32_t* h = hist + (size_t)t * QS_TK_KEYS;
+    for (int v = lo + threadIdx.x; v < hi; v += 256) {
+        const f16 x = l[v];
+        if (x == x) atomicAdd(h + tk_key(x), 1u);   // (a NaN logit takes no part)
+    }
+}
+__global__ __launch_bounds__(1024) void topk_select_kernel(uint32_t* __restrict__ hist, const float* __restrict__ temperature,
+                                                            const int32_t* __restrict__ top_k, const float* __restrict__ top_p,
+                                                            TkRow* __restrict__ rows, int V) {
+    __shared__ uint32_t s_cnt[16];
+    __shared__ double s_mass[16];
+    __shared__ uint32_t s_u[4];
+    __shared__ double s_zk, s_z;
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* h = hist + (size_t)t * QS_TK_KEYS;
+    const float traw = temperature ? temperature[t] : 1.0f;
+    const bool greedy = traw < 1e-5f;
+    const float temp = greedy ? 1.0f : traw;
+    int kk = top_k ? top_k[t] : -1;
+    if (kk <= 0 || kk > V) kk = V;
+    const double pp = top_p ? (double)top_p[t] : 1.0;
+    // thread tid owns keys 65535 - 64 tid - j, j = 0 .. 63 (descending)
+    const uint32_t k_hi = 65535u - 64u * tid;
+    // (the thread's 64 counts are re-read from the L2-resident histogram in every pass below: held in registers they spill)
+#define QS_TK_CNT(j) (h[k_hi - (j)])
+    uint32_t c_loc = 0, first = 0xFFFFFFFFu;
+    for (int j = 0; j < 64; j++) {
+        const uint32_t cj = QS_TK_CNT(j);
+        c_loc += cj;
+        if (cj && first == 0xFFFFFFFFu) first = 64u * tid + j;   // descending position of the row's largest key
+    }
+    // the row maximum = the first non-empty key in descending order
+    uint32_t fm = first;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) fm = min(fm, (uint32_t)__shfl_xor((int)fm, m, 64));
+    if (lane == 0) s_cnt[wave] = fm;
+    __syncthreads();
+    uint32_t pos_max = s_cnt[0];
+    for (int w2 = 1; w2 < 16; w2++) pos_max = min(pos_max, s_cnt[w2]);
+    __syncthreads();
+    const float mx = pos_max == 0xFFFFFFFFu ? 0.0f : tk_val(65535u - pos_max) / temp;
+    double m_loc = 0.0;
+    for (int j = 0; j < 64; j++) {
+        const uint32_t cj = QS_TK_CNT(j);
+        if (cj) m_loc += (double)cj * (double)qexpf(tk_val(k_hi - j) / temp - mx);
+    }
+    // exclusive block scans (thread order = descending keys): counts and mass
+    uint32_t c_inc = c_loc;
+    double m_inc = m_loc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t oc = (uint32_t)__shfl_up((int)c_inc, d, 64);
+        const double om = __shfl_up(m_inc, d, 64);
+        if (lane >= d) {
+            c_inc += oc;
+            m_inc += om;
+        }
+    }
+    if (lane == 63) {
+        s_cnt[wave] = c_inc;
+        s_mass[wave] = m_inc;
+    }
+    __syncthreads();
+    uint32_t c_ex = c_inc - c_loc;
+    double m_ex = m_inc - m_loc;
+    for (int w2 = 0; w2 < wave; w2++) {
+        c_ex += s_cnt[w2];
+        m_ex += s_mass[w2];
+    }
+    if (tid == 0) {
+        s_u[0] = 0xFFFFFFFFu;   // descending position of the top-k key
+        s_u[1] = 0xFFFFFFFFu;   // descending position of the first key top-p masks
+    }
+    __syncthreads();
+    // (a) top-k: the key at which the descending cumulative count reaches k; Z_k = the mass down to and including it
+    {
+        uint32_t run = c_ex;
+        double mrun = m_ex;
+        for (int j = 0; j < 64; j++) {
+            const uint32_t cj = QS_TK_CNT(j);
+            if (cj) {
+                const double w = (double)cj * (double)qexpf(tk_val(k_hi - j) / temp - mx);
+                if (run < (uint32_t)kk && run + cj >= (uint32_t)kk) {   // exactly one (thread, j) in the row
+                    s_u[0] = 64u * tid + j;
+                    s_zk = mrun + w;
+                }
+                run += cj;
+                mrun += w;
+            }
+        }
+        if (tid == 1023 && run < (uint32_t)kk) {   // fewer than k finite logits: everything is kept
+            s_u[0] = 65535u;
+            s_zk = mrun;
+        }
+    }
+    __syncthreads();
+    const uint32_t pos_k = s_u[0];
+    const double zk = s_zk;
+    // (b) top-p: the first key (descending) whose strictly-larger keys already hold >= p Z_k of the mass is masked, and
+    // everything below it; a group of equal logits is kept or masked as a whole
+    {
+        double mrun = m_ex;
+        uint32_t best = 0xFFFFFFFFu;
+        for (int j = 0; j < 64; j++) {
+            const uint32_t cj = QS_TK_CNT(j);
+            if (cj) {
+                const uint32_t pos = 64u * tid + j;
+                if (best == 0xFFFFFFFFu && pos <= pos_k && pos != pos_max && mrun >= pp * zk) best = pos;
+                mrun += (double)cj * (double)qexpf(tk_val(k_hi - j) / temp - mx);
+            }
+        }
+        if (best != 0xFFFFFFFFu) atomicMin(&s_u[1], best);
+    }
+    __syncthreads();
+    const uint32_t pos_p = s_u[1];                                       // first masked position, or none
+    const uint32_t pos_last = pos_p == 0xFFFFFFFFu ? pos_k : min(pos_k, pos_p - 1);   // last kept position (descending)
+    // (c) the final denominator: the mass of positions <= pos_last (pos_last itself may be an empty key: the position just
+    // above the first masked one); the thread whose 64 positions contain pos_last publishes it
+    {
+        double mrun = m_ex;
+        for (int j = 0; j < 64; j++) {
+            const uint32_t cj = QS_TK_CNT(j);
+            if (cj) {
+                if (64u * tid + j <= pos_last) mrun += (double)cj * (double)qexpf(tk_val(k_hi - j) / temp - mx);
+                QS_TK_CNT(j) = 0u;   // leave the histogram zeroed for the next call (this is the last pass over it)
+            }
+        }
+        if ((pos_last >> 6) == (uint32_t)tid) s_z = mrun;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        TkRow r;
+        r.tau = 65535u - pos_last;
+        // (between pos_last and the next non-empty key nothing lives, so "key >= tau" keeps exactly positions <= pos_last)
+        r.temp = temp;
+        r.mx = mx;
+        r.z = (float)s_z;
+        r.greedy = greedy ? 1 : 0;
+        r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        rows[t] = r;
+    }
+#undef QS_TK_CNT
+}
+__global__ __launch_bounds__(256) void topk_write_kernel(const f16* __restrict__ logits, const TkRow* __restrict__ rows,
+                                                         const float* __restrict__ exponential, uint64_t seed, uint64_t offset,
+                                                         const uint64_t* __restrict__ rng_state, float* __restrict__ probs,
+                                                         SmPartA* __restrict__ part_a, int V) {
+    __shared__ ArgMax red_a[4];
+    const int c = blockIdx.x, t = blockIdx.y;
+    int lo, hi;
+    sm_chunk_range(V, c, lo, hi);
+    const TkRow r = rows[t];
+    if (rng_state) {
+        seed = rng_state[0];
+        offset = rng_state[1];
+    }
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const f16* l = logits + (size_t)t * V;
+    float* p = probs + (size_t)t * V;
+    ArgMax am{-__builtin_inff(), 0x7fffffff};
+    for (int v = lo + threadIdx.x; v < hi; v += 256) {
+        const f16 x = l[v];
+        float pv = 0.0f;
+        if (x == x && tk_key(x) >= r.tau) pv = qexpf(h2f(x) / r.temp - r.mx) / r.z;
+        p[v] = pv;
+        float val = pv;
+        if (!r.greedy) {
+            float e;
+            if (exponential) {
+                e = exponential[(size_t)t * V + v];
+            } else {
+                uint32_t rr[4];
+                philox4x32((uint32_t)v, 0x40000000u | (uint32_t)t, (uint32_t)offset, (uint32_t)(offset >> 32), k0, k1, rr);
+                e = -__logf(u01_open(rr[0]));
+            }
+            val = pv / e;
+        }
+        if (val > am.v) {
+            am.v = val;
+            am.i = v;
+        }
+    }
+    am = block_argmax(am, red_a);
+    if (threadIdx.x == 0) part_a[t * QS_SM_CHUNKS + c] = SmPartA{am.v, am.i};
+}
+__global__ __launch_bounds__(256) void topk_token_kernel(const SmPartA* __restrict__ part_a, int64_t* __restrict__ token,
+                                                         int64_t token_stride, uint64_t* __restrict__ rng_state, int T) {
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const ArgMax am = sm_row_max(part_a, t);
+        token[t * token_stride] = am.i == 0x7fffffff ? 0 : am.i;
+    }
+    if (rng_state && threadIdx.x == 0) rng_state[1] = rng_state[1] + 1;   // after every draw of this call
+}
+// ws: [rows][65536] u32 histogram (zero-filled ONCE by the caller, left zeroed by every call) | [rows] TkRow | [rows][CHUNKS] SmPartA
+size_t sample_ws_bytes(int rows) {
+    return (size_t)rows * QS_TK_KEYS * 4 + (size_t)rows * sizeof(TkRow) + (size_t)rows * QS_SM_CHUNKS * sizeof(SmPartA);
+}
+int sample_top_k_top_p(const f16* logits, const float* temperature, const int32_t* top_k, const float* top_p,
+                       const float* exponential, uint64_t seed, uint64_t offset, uint64_t* rng_state, float* probs,
+                       int64_t* token, int64_t token_stride, int T, int V, void* ws, hipStream_t st) {
+    if (T == 0) return 0;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(ws);
+    TkRow* rows = reinterpret_cast<TkRow*>(reinterpret_cast<char*>(ws) + (size_t)T * QS_TK_KEYS * 4);
+    SmPartA* part_a = reinterpret_cast<SmPartA*>(reinterpret_cast<char*>(rows) + (size_t)T * sizeof(TkRow));
+    hipLaunchKernelGGL(topk_hist_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, logits, hist, V);
+    hipLaunchKernelGGL(topk_select_kernel, dim3(T), dim3(1024), 0, st, hist, temperature, top_k, top_p, rows, V);
+    hipLaunchKernelGGL(topk_write_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, logits, rows, exponential, seed, offset,
+                       rng_state, probs, part_a, V);
+    hipLaunchKernelGGL(topk_token_kernel, dim3(1), dim3(256), 0, st, part_a, token, token_stride, rng_state, T);
+    return 0;
+}
+
 // advance_step_flashattn_kernel without the CUDA-graph padding branch (num_seqs == num_queries).
 __global__ void advance_step_kernel(int n, int block_size, int64_t* __restrict__ input_tokens,
                                     const int64_t* __restrict__ sampled, int64_t* __restrict__ positions,

@@ -422,6 +422,16 @@ class QuarotLlamaForCausalLM:
             logits_hook(logits)
         ops.softmax_argmax(logits, probs, token)
 
+    def sample(self, hidden_states, scratch: Scratch, probs, token, temperature, top_k, top_p, rng_state,
+               shard_vocab: bool = False, logits_hook=None, exponential=None):
+        """compute_logits + Sampler.forward for batches with non-greedy rows (sampler.py:216-316): temperature, top-k / top-p,
+        softmax, multinomial by exponential noise; rows whose temperature is 0 take the argmax.  probs [T, V] fp32 (the
+        PROCESSED distribution: what the rejection sampler must see), token [T]."""
+        logits = self.compute_logits(hidden_states, scratch, shard_vocab=shard_vocab)
+        if logits_hook is not None:
+            logits_hook(logits)
+        ops.sample_top_k_top_p(logits, probs, token, temperature, top_k, top_p, exponential=exponential, rng_state=rng_state)
+
     # ------------------------------------------------------------------ module-wise path (reference op order)
     def forward_modulewise(self, input_ids, positions, kv_caches, attn_metadata: AttentionMetadata, w4a4=False):
         cfg, md = self.config, attn_metadata

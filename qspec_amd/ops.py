@@ -607,6 +607,29 @@ def rejection_sample(target_with_bonus_probs, bonus_token_ids, draft_probs, draf
           _opt(active_lens, "active_lens", _I32), _sampler_ws(B * k, draft_probs.device, workspace).data_ptr(), _stream())
 
 
+_sample_ws = {}
+
+
+def sample_workspace(rows: int, device):
+    """Histogram workspace of sample_top_k_top_p: zero-filled once per (device, stream, rows), left zeroed by every call."""
+    key = _ws_key(device) + (rows,)
+    if key not in _sample_ws:
+        _sample_ws[key] = torch.zeros(int(_lib.load().qspec_sample_workspace_bytes(rows)), dtype=torch.uint8, device=device)
+    return _sample_ws[key]
+
+
+def sample_top_k_top_p(logits, probs, token, temperature=None, top_k=None, top_p=None, exponential=None, seed: int = 0,
+                       offset: int = 0, rng_state=None, workspace=None):
+    """Sampler.forward for non-greedy rows (sampler.py:216-316): temperature, top-k / top-p masking, softmax, multinomial by
+    exponential noise.  temperature / top_p [T] fp32, top_k [T] int32 on the device (None: 1.0 / off)."""
+    T, V = logits.shape
+    ws = workspace if workspace is not None else sample_workspace(T, logits.device)
+    _call("qspec_sample_top_k_top_p", _chk(logits, "logits", _F16), _opt(temperature, "temperature", _F32),
+          _opt(top_k, "top_k", _I32), _opt(top_p, "top_p", _F32), _opt(exponential, "exponential", _F32), seed, offset,
+          _opt(rng_state, "rng_state", _I64), _chk(probs, "probs", _F32), token.data_ptr(), token.stride(0) if token.dim() else 1,
+          T, V, ws.data_ptr(), _stream())
+
+
 def typical_acceptance_sample(target_with_bonus_probs, bonus_token_ids, draft_token_ids, posterior_threshold: float,
                               posterior_alpha: float, out_tokens, accepted, recovered, counters=None, workspace=None,
                               active_lens=None):

@@ -145,6 +145,20 @@ class QSpecEngine:
         self.md_verify = AttentionMetadata(self.v_slots, self.block_tables, self.v_ctx, self.v_qstart, k + 1, n_splits)
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._graph_draft: Optional[torch.cuda.CUDAGraph] = None   # fallback: proposer only (verify pass eager)
+        # ---- sampling parameters per slot (Sampler.forward's SamplingTensors, sampler.py:216-316).  temperature 0 = greedy
+        # (vLLM resets top_k / top_p of such requests itself, sampling_params.py).  While every occupied slot is greedy the
+        # cycle is the greedy one above (fused lm_head + softmax); as soon as one is not, the cycle samples EVERY row through
+        # ops.sample_top_k_top_p (greedy rows take the argmax there) -- a second captured graph, same state, same RNG stream
+        self.samp_temp = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.samp_topk = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        self.samp_topp = torch.ones(B, dtype=torch.float32, device=dev)
+        self.v_samp_temp = torch.zeros(T, dtype=torch.float32, device=dev)     # the same, one row per verify token
+        self.v_samp_topk = torch.full((T,), -1, dtype=torch.int32, device=dev)
+        self.v_samp_topp = torch.ones(T, dtype=torch.float32, device=dev)
+        self._samp_host = [(0.0, -1, 1.0)] * B
+        self._mode_sampling = False
+        self._graph_s: Optional[torch.cuda.CUDAGraph] = None       # the cycle with the sampling front end
+        self._graph_draft_s: Optional[torch.cuda.CUDAGraph] = None
         # test hooks: injected random draws for the rejection sampler (eager mode only)
         self.inject_uniform: Optional[torch.Tensor] = None
         self.inject_exponential: Optional[torch.Tensor] = None
@@ -216,7 +230,7 @@ class QSpecEngine:
         logits = self.model.compute_logits(hs[last].contiguous(), s)
         probs = torch.empty(n, cfg.vocab_size, dtype=torch.float32, device=dev)
         tok = torch.empty(n, dtype=torch.int64, device=dev)
-        ops.softmax_argmax(logits, probs, tok)
+        self._first_token(logits, probs, tok, list(slots))
         for i, (b, T) in enumerate(zip(slots, lens)):
             self.seq_lens[b] = T + 1
             self.last_token[b] = tok[i]
@@ -257,7 +271,7 @@ class QSpecEngine:
         logits = self.model.compute_logits(hs[T - 1:T], s)
         probs = torch.empty(1, cfg.vocab_size, dtype=torch.float32, device=dev)
         tok = torch.empty(1, dtype=torch.int64, device=dev)
-        ops.softmax_argmax(logits, probs, tok)
+        self._first_token(logits, probs, tok, [b])
         self.seq_lens[b] = T + 1
         self.last_token[b] = tok[0]
         self.gen_tokens[b].fill_(-1)
@@ -269,12 +283,22 @@ class QSpecEngine:
         if sync:
             torch.cuda.synchronize()
 
+    def _first_token(self, logits, probs, tok, slots: List[int]) -> None:
+        """The target's first token of freshly admitted prompts: greedy, or sampled with the slots' parameters."""
+        if all(self._samp_host[b][0] < 1e-5 for b in slots):
+            ops.softmax_argmax(logits, probs, tok)
+            return
+        idx = torch.tensor(slots, dtype=torch.int64, device=self.device)
+        ops.sample_top_k_top_p(logits, probs, tok, self.samp_temp[idx].contiguous(), self.samp_topk[idx].contiguous(),
+                               self.samp_topp[idx].contiguous(), rng_state=self.sampler.rng_state)
+
     def free_slot(self, slot: int) -> None:
         """The request in `slot` has finished (EOS / max_tokens / aborted): the slot goes back to empty."""
         self.seq_lens[slot] = 0
         self.gen_lens[slot] = 0
         self._len_ub[slot] = 0
         self._gen_ub[slot] = 0
+        self.set_sampling_params(slot)          # back to greedy
         if self._bt_host[slot] is not None:
             # the request's blocks go back to the scheduler: the slot must not keep a table (and a capacity) that the
             # next admission could pass validation against.  Contiguous mode: the slot's own default range again;
@@ -288,6 +312,24 @@ class QSpecEngine:
                 self._capacity[slot] = 0
             self._bt_host[slot] = None
         self.n_active = sum(1 for v in self._len_ub if v > 0)
+
+    def set_sampling_params(self, slot: int, temperature: float = 0.0, top_k: int = -1, top_p: float = 1.0) -> None:
+        """The request in `slot` samples with these parameters (vllm/sampling_params.py; temperature < 1e-5 = greedy, for
+        which vLLM itself resets top_k / top_p).  Uploaded only when they change."""
+        if temperature < 1e-5:
+            temperature, top_k, top_p = 0.0, -1, 1.0
+        want = (float(temperature), int(top_k) if top_k and top_k > 0 else -1, float(top_p))
+        if self._samp_host[slot] == want:
+            return
+        k1 = self.k + 1
+        self.samp_temp[slot] = want[0]; self.samp_topk[slot] = want[1]; self.samp_topp[slot] = want[2]
+        self.v_samp_temp[slot * k1:(slot + 1) * k1] = want[0]
+        self.v_samp_topk[slot * k1:(slot + 1) * k1] = want[1]
+        self.v_samp_topp[slot * k1:(slot + 1) * k1] = want[2]
+        self._samp_host[slot] = want
+
+    def _sampling_on(self) -> bool:
+        return any(self._samp_host[b][0] >= 1e-5 for b in range(self.B) if self._len_ub[b] > 0)
 
     def set_block_table(self, slot: int, blocks: Sequence[int]) -> None:
         """The scheduler's block table of the request in `slot` (vLLM SequenceGroupMetadata.block_tables); it must
@@ -385,7 +427,11 @@ class QSpecEngine:
         draft_sv = tp is not None and getattr(tp, "shard_draft_vocab", False)   # vocab-parallel lm_head on the draft pass too
         for i in range(k):
             hs = m.forward(self.d_tokens, self.d_pos, self.kv_caches, self.md_draft, self.scratch_draft, w4a4=True)
-            m.sample_greedy(hs, self.scratch_draft, self.draft_probs_kbv[i], self.draft_ids_kb[i], shard_vocab=draft_sv)
+            if self._mode_sampling:   # draft tokens are SAMPLED from the processed draft distribution (sampler.py:216-316)
+                m.sample(hs, self.scratch_draft, self.draft_probs_kbv[i], self.draft_ids_kb[i], self.samp_temp, self.samp_topk,
+                         self.samp_topp, self.sampler.rng_state, shard_vocab=draft_sv)
+            else:
+                m.sample_greedy(hs, self.scratch_draft, self.draft_probs_kbv[i], self.draft_ids_kb[i], shard_vocab=draft_sv)
             if i != k - 1:  # _gpu_advance_step (draft_model_runner.py:78-135)
                 ops.spec_advance_draft(bs, self.d_tokens, self.draft_ids_kb[i], self.d_pos, self.d_ctx, self.d_slots,
                                        self.block_tables)
@@ -399,8 +445,13 @@ class QSpecEngine:
                                 self.v_pos, self.v_slots, self.v_ctx)
         hs = m.forward(self.v_tokens, self.v_pos, self.kv_caches, self.md_verify, self.scratch_verify, w4a4=False)
         hook = self._verify_logits_hook(draft_ids)
-        m.sample_greedy(hs, self.scratch_verify, self.target_probs.view(B * (k + 1), -1), self.target_tokens.view(-1),
-                        shard_vocab=True, logits_hook=hook)
+        if self._mode_sampling:
+            m.sample(hs, self.scratch_verify, self.target_probs.view(B * (k + 1), -1), self.target_tokens.view(-1),
+                     self.v_samp_temp, self.v_samp_topk, self.v_samp_topp, self.sampler.rng_state, shard_vocab=True,
+                     logits_hook=hook)
+        else:
+            m.sample_greedy(hs, self.scratch_verify, self.target_probs.view(B * (k + 1), -1), self.target_tokens.view(-1),
+                            shard_vocab=True, logits_hook=hook)
         # _verify_tokens (:861-970): bonus = the target's own token at the last position
         self.sampler.forward(self.target_probs, self.target_tokens[:, k], draft_probs, draft_ids, out=self.out_tokens,
                              accepted=self.accepted, recovered=self.recovered, uniform=self.inject_uniform,
@@ -455,20 +506,23 @@ class QSpecEngine:
         for b in on:                       # until the caller reports / syncs the real numbers: the worst case
             self._len_ub[b] += self.k + 1
             self._gen_ub[b] += self.k + 1
+        self._mode_sampling = self._sampling_on()     # (every rank sees the same requests: the same decision)
         if not self.use_graph:
             self._cycle_body()
             return
-        if self._graph is None and self._graph_draft is None:
+        full, draft = (self._graph_s, self._graph_draft_s) if self._mode_sampling else (self._graph, self._graph_draft)
+        if full is None and draft is None:
             self._capture()
             if not self.use_graph:
                 self._cycle_body()
                 return
-        if self._graph is not None:
-            self._graph.replay()
+            full, draft = (self._graph_s, self._graph_draft_s) if self._mode_sampling else (self._graph, self._graph_draft)
+        if full is not None:
+            full.replay()
         else:   # the verify pass could not be captured (its collectives): proposer from its graph, scorer eagerly.
             # The same bracket as _cycle_body: the state snapshot sits at the head of the draft graph (_capture), the
             # error words are collected behind the eager verify pass -- read_outputs() / recover() work in this mode too
-            self._graph_draft.replay()
+            draft.replay()
             self._verify_body()
             self._collect_errors()
 
@@ -502,7 +556,10 @@ class QSpecEngine:
                     self._snapshot()
                     self._draft_body()
                 torch.cuda.synchronize()
-                self._graph_draft = gd
+                if self._mode_sampling:
+                    self._graph_draft_s = gd
+                else:
+                    self._graph_draft = gd
                 warnings.warn(f"hipGraph capture of the whole cycle failed ({exc!r}); "
                               "the draft pass replays from a graph, the verify pass runs eagerly")
             except Exception as exc2:
@@ -516,7 +573,10 @@ class QSpecEngine:
         for t, s in zip((self.seq_lens, self.last_token, self.gen_tokens, self.gen_lens, self.sampler.counters,
                          self.sampler.rng_state), state):
             t.copy_(s)
-        self._graph = g
+        if self._mode_sampling:
+            self._graph_s = g
+        else:
+            self._graph = g
 
     # ------------------------------------------------------------------ results
     def generated(self) -> List[List[int]]:

@@ -66,6 +66,11 @@ class SamplingParams:
     max_tokens: int = 16
     ignore_eos: bool = False
     seed: Optional[int] = None
+    # Sampler.forward's inputs (sampler.py:216-316).  temperature 0 = greedy -- the reference's demo and BASELINE.json's configs;
+    # vLLM's own default is 1.0, a caller coming from vLLM passes its SamplingParams object and with it the real value
+    temperature: float = 0.0
+    top_k: int = -1
+    top_p: float = 1.0
 
 
 @dataclass
@@ -541,10 +546,13 @@ class SpecDecodeWorker:
             raise RuntimeError(f"no free sequence slot for request {prompts[len(free)].request_id}: "
                                f"max_num_seqs={self.max_num_seqs} are running")
         slots, toks, tables = free[:len(prompts)], [], []
-        for s in prompts:
+        for s, b in zip(prompts, slots):
             seq_id, data = self._only_seq(s)
             toks.append(data.get_token_ids())
             tables.append(s.block_tables.get(seq_id) if s.block_tables else None)
+            sp = s.sampling_params   # before the prompt pass: the first token is sampled with them too
+            self.engine.set_sampling_params(b, getattr(sp, "temperature", 0.0) or 0.0, getattr(sp, "top_k", -1) or -1,
+                                            getattr(sp, "top_p", 1.0) if sp is not None else 1.0)
         try:
             self.engine.add_sequences_to(slots, toks, tables)
         except Exception:

@@ -20,6 +20,8 @@ What is imported from the reference (by file path; nothing is copied):
   * vllm/model_executor/layers/rotary_embedding.py:47-70,136-150,201-229   RotaryEmbedding._compute_cos_sin_cache,
       forward_native, _apply_rotary_emb -- loaded with a three-line `CustomOp` base (an nn.Module with a `register`
       decorator) and an empty `vllm._custom_ops` (forward_native touches neither)
+  * vllm/model_executor/layers/sampler.py   _apply_top_k_top_p (:387-413) and _multinomial (:585-604): the module itself needs
+      msgspec (absent); the two function definitions are compiled from the reference file and run (gen_sampling)
   * third-party/QuaRot/quarot/functional/quantization.py   sym_quant / sym_dequant (the a3 / a6 pins, gen_sym_quant_w4a16)
   * tests/kernels/test_cache.py:295-304 (reshape_and_cache_flash's reference loop) and
     vllm/model_executor/layers/sampler.py:278-287 (greedy probs / logprobs / argmax) are a five-line loop and three
@@ -435,6 +437,68 @@ def gen_typical_acceptance():
     np.savez_compressed(os.path.join(OUT, "typical_acceptance.npz"), **out)
 
 
+def _ref_function(path, *names):
+    """Functions of a reference module that cannot be imported as a whole (vllm/model_executor/layers/sampler.py pulls in
+    msgspec-backed vllm.sequence): the file is parsed, the named top-level function definitions are compiled FROM THE
+    REFERENCE FILE and executed here with torch in scope.  Nothing is copied; the reference's own code runs."""
+    import ast
+    from typing import List, Optional
+    tree = ast.parse(open(path).read(), filename=path)
+    ns = {"torch": torch, "Optional": Optional, "List": List, "SequenceGroupToSample": object}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            mod = ast.Module(body=[node], type_ignores=[])
+            exec(compile(mod, path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def gen_sampling():
+    """Non-greedy Sampler.forward (sampler.py:216-316) on CPU with the reference's own _apply_top_k_top_p (:387-413) and
+    _multinomial (:585-604) executed from the reference file, temperature scaling and softmax as :266-287; the exponential
+    draws of _multinomial are recorded (torch.Tensor.exponential_ replaced by a recorded array, as for the rejection sampler).
+    Rows of DISTINCT fp16 logits (no ties: the reference's top-p rule then has no sort-order ambiguity) and, separately, rows
+    with many equal logits (ties: compared outside the boundary group only)."""
+    apply_tk_tp, multinomial = _ref_function(f"{REF}/vllm/model_executor/layers/sampler.py", "_apply_top_k_top_p", "_multinomial")
+    g = torch.Generator().manual_seed(13)
+    out = {}
+    V = 6007
+    allh = torch.arange(-2 ** 15, 2 ** 15, dtype=torch.int32).to(torch.int16).view(torch.float16)
+    pool = allh[torch.isfinite(allh) & (allh.abs() < 12) & (allh.abs() > 1e-3)]
+    pool = torch.unique(pool)
+    cases = [(1.0, -1, 1.0), (0.7, 50, 1.0), (1.3, -1, 0.9), (0.8, 40, 0.95), (1.0, 1, 1.0), (2.0, 5000, 0.5), (0.5, -1, 0.3),
+             (1.0, 7, 0.01), (0.9, 6007, 0.999)]
+    T = len(cases)
+    for name, ties in (("distinct", False), ("ties", True)):
+        if ties:
+            logits = (torch.randn(T, V, generator=g) * 2).to(torch.float16)
+            logits = (logits * 4).round() / 4                      # quarter steps: dozens of equal logits everywhere
+            logits = logits.to(torch.float16)
+        else:
+            logits = torch.stack([pool[torch.randperm(pool.numel(), generator=g)[:V]] for _ in range(T)])
+            # a peaked shape: scale a few so that top-p cuts somewhere interesting
+        temperature = torch.tensor([c[0] for c in cases], dtype=torch.float32)
+        top_k = torch.tensor([V if c[1] == -1 else c[1] for c in cases], dtype=torch.int32)   # vLLM maps -1 to vocab_size
+        top_p = torch.tensor([c[2] for c in cases], dtype=torch.float32)
+        lf = logits.to(torch.float)
+        lf.div_(temperature.unsqueeze(dim=1))
+        masked = apply_tk_tp(lf.clone(), top_p, top_k)
+        probs = torch.softmax(masked, dim=-1, dtype=torch.float)
+        E = torch.empty(T, V).exponential_(1.0, generator=g)
+        orig = torch.Tensor.exponential_
+        try:
+            torch.Tensor.exponential_ = lambda self, *a, **kw: self.copy_(E)
+            tok = multinomial(probs.clone(), 1).view(-1)
+        finally:
+            torch.Tensor.exponential_ = orig
+        out[name + "_logits"] = logits.numpy()
+        out[name + "_temperature"], out[name + "_top_k"], out[name + "_top_p"] = temperature.numpy(), top_k.numpy(), top_p.numpy()
+        out[name + "_E"] = E.numpy()
+        out[name + "_keep"] = torch.isfinite(masked).numpy()
+        out[name + "_probs"] = probs.numpy()
+        out[name + "_token"] = tok.numpy()
+    np.savez_compressed(os.path.join(OUT, "sampling.npz"), **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference checkout is only present in the build container"
     gen_pack()
@@ -445,6 +509,7 @@ if __name__ == "__main__":
     gen_rope_cache_softmax()
     gen_sym_quant_w4a16()
     gen_typical_acceptance()
+    gen_sampling()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1408,6 +1408,55 @@ def test_attention_waves_kernel_dev_forms(switch, kexpr):
     assert " passed" in r.stdout
 
 
+def test_sample_top_k_top_p_reference_fixture(ops, oracle, golden_dir):
+    """The non-greedy sampler front end (temperature, top-k, top-p, softmax, multinomial by exponential noise) on the GPU against
+    the reference's own _apply_top_k_top_p / _multinomial run on CPU (tests/golden/sampling.npz).  Distinct logits: the kept
+    set and the tokens exact, probabilities within 1e-6.  Equal logits: identical outside the boundary group, which is kept
+    WHOLE here (the reference's unstable sort splits it arbitrarily); twice in a row on the self-cleaning workspace; and a
+    greedy row (temperature 0) inside the batch takes the argmax."""
+    g = np.load(os.path.join(golden_dir, "sampling.npz"))
+    for name in ("distinct", "ties"):
+        lg = g[name + "_logits"]
+        T, V = lg.shape
+        for rep in range(2):
+            probs = torch.full((T, V), -1.0, dtype=torch.float32, device=DEV)
+            tok = torch.full((T,), -1, dtype=torch.int64, device=DEV)
+            ops.sample_top_k_top_p(dev(lg), probs, tok, dev(g[name + "_temperature"]), dev(g[name + "_top_k"]), dev(g[name + "_top_p"]),
+                                   exponential=dev(g[name + "_E"]))
+            pr, tk = host(probs), host(tok)
+            rk, rp, rt = g[name + "_keep"], g[name + "_probs"], g[name + "_token"]
+            assert np.allclose(pr.sum(1), 1.0, atol=1e-5)
+            for t in range(T):
+                kept = pr[t] > 0
+                if name == "distinct":
+                    assert np.array_equal(kept, rk[t]), (t, kept.sum(), rk[t].sum())
+                    assert np.abs(pr[t] - rp[t]).max() <= 1e-6 and tk[t] == rt[t], t
+                else:
+                    b = lg[t][rk[t]].min()
+                    off = lg[t] != b
+                    assert np.array_equal(kept[off], rk[t][off]), t
+                    assert kept[~off].all()                    # the boundary group as a whole
+        ws = ops.sample_workspace(T, torch.device(DEV))
+        assert int(ws[:T * 65536 * 4].view(torch.int32).abs().max().item()) == 0      # the histogram is left zeroed
+    # a mixed batch: row 0 greedy (temperature 0), row 1 sampled; defaults (None) = temperature 1, no masking
+    lg = g["distinct_logits"][:2]
+    probs = torch.empty(2, lg.shape[1], dtype=torch.float32, device=DEV); tok = torch.empty(2, dtype=torch.int64, device=DEV)
+    ops.sample_top_k_top_p(dev(lg), probs, tok, dev(np.array([0.0, 1.0], np.float32)), exponential=dev(g["distinct_E"][:2]))
+    p0, t0 = oracle.softmax_argmax(lg)
+    assert host(tok)[0] == t0[0] and np.array_equal(host(probs)[0], p0[0])
+    pr, tk, _ = oracle.sample_top_k_top_p(lg, np.array([0.0, 1.0], np.float32), None, None, g["distinct_E"][:2])
+    assert np.array_equal(host(tok), tk) and np.abs(host(probs) - pr).max() <= 1e-7
+    # Philox path: a valid distribution, a token inside the kept set, and a new draw on every call
+    rng = torch.tensor([123, 0], dtype=torch.int64, device=DEV)
+    seen = set()
+    for _ in range(8):
+        ops.sample_top_k_top_p(dev(g["distinct_logits"][1:2]), probs[:1], tok[:1], dev(np.array([0.7], np.float32)),
+                               dev(np.array([50], np.int32)), rng_state=rng)
+        assert host(probs)[0][int(host(tok)[0])] > 0
+        seen.add(int(host(tok)[0]))
+    assert int(rng[1].item()) == 8 and len(seen) > 1
+
+
 def test_typical_acceptance_sampler_reference_fixture(ops, oracle, golden_dir):
     """TypicalAcceptanceSampler on the GPU against the REFERENCE class run on CPU (tests/golden/typical_acceptance.npz, 20
     deterministic cases): output layout, accept masks, counters exact; the replacement token = the target's argmax; through

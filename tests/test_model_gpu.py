@@ -480,6 +480,48 @@ def test_engine_cycle_with_typical_acceptance_sampler(tiny, oracle):
     assert gens[0] == gens[1]
 
 
+def test_engine_cycle_with_sampled_requests(tiny, oracle):
+    """A mixed batch: slots 0 / 1 greedy, slots 2 / 3 sampling (temperature, top-k, top-p).  The whole cycle then goes through
+    the sampling front end (ops.sample_top_k_top_p): every distribution the rejection sampler sees is the PROCESSED one (sums to
+    1, at most top_k non-zeros for the sampled rows), draft tokens lie in its support, greedy rows propose their argmax, the
+    output follows _create_output on the GPU's own accept mask, the captured graph replays the eager cycle token for token,
+    and a batch that is greedy again goes back to the greedy graph."""
+    from qspec_amd.spec_decode import QSpecEngine
+    rng = np.random.default_rng(23)
+    prompts = [rng.integers(0, tiny.config.vocab_size, n).tolist() for n in (20, 31, 8, 50)]
+    gens = []
+    for use_graph in (False, True):
+        eng = QSpecEngine(tiny, 3, 4, max_model_len=256, block_size=16, max_new_tokens=64, use_graph=use_graph, seed=9)
+        eng.set_sampling_params(2, temperature=0.8, top_k=50, top_p=0.9)
+        eng.set_sampling_params(3, temperature=1.2, top_k=-1, top_p=0.5)
+        eng.add_sequences(prompts)
+        for _ in range(4):
+            eng.step()
+            torch.cuda.synchronize()
+            assert eng._mode_sampling
+            dp = eng.draft_probs_kbv.transpose(0, 1).cpu().numpy()        # [B, k, V]
+            tp = eng.target_probs.cpu().numpy()
+            ids = eng.draft_ids_kb.t().cpu().numpy()
+            assert np.allclose(dp.sum(-1), 1.0, atol=1e-4) and np.allclose(tp.sum(-1), 1.0, atol=1e-4)
+            assert ((dp[2] > 0).sum(-1) <= 50).all() and ((tp[2] > 0).sum(-1) <= 50).all()
+            assert ((dp[3] > 0).sum(-1) < tiny.config.vocab_size).all()      # top-p 0.5 cuts something
+            for b in range(4):
+                for i in range(3):
+                    assert dp[b, i, ids[b, i]] > 0
+            assert np.array_equal(ids[:2], dp[:2].argmax(-1))                 # greedy rows of the mixed batch
+            out, _ = oracle.create_output(eng.accepted.cpu().numpy().astype(bool), eng.recovered.cpu().numpy(), ids,
+                                          eng.target_tokens[:, 3].cpu().numpy())
+            assert np.array_equal(eng.out_tokens.cpu().numpy(), out)
+        gens.append(eng.generated())
+        if use_graph:
+            assert eng._graph_s is not None and eng._graph is None
+            eng.set_sampling_params(2); eng.set_sampling_params(3)            # all greedy again: the greedy cycle and its graph
+            eng.step()
+            torch.cuda.synchronize()
+            assert not eng._mode_sampling and eng._graph is not None
+    assert gens[0] == gens[1]
+
+
 def test_graph_replay_equals_eager(tiny):
     """The captured hipGraph of the cycle produces the same tokens as the eager cycle (same Philox stream)."""
     from qspec_amd.spec_decode import QSpecEngine

@@ -319,3 +319,24 @@ def test_typical_acceptance_matches_reference_run(oracle, golden_dir):
         assert list(c) == list(g[f"t{i}_counters"]), i
         seen |= set(np.unique(acc).tolist())
     assert seen == {False, True}
+
+
+def test_sampling_top_k_top_p_matches_reference_functions(oracle, golden_dir):
+    """The oracle's non-greedy sampler against the reference's own _apply_top_k_top_p / _multinomial (compiled from the reference
+    file and run on CPU by make_golden.py, exponential draws recorded): rows of distinct logits -- keep masks and tokens exact,
+    probabilities to 1e-6 --; rows with many equal logits -- the same outside the group of equal logits at the top-p boundary,
+    which the reference's unstable sort splits arbitrarily."""
+    g = _load(golden_dir, "sampling.npz")
+    for name in ("distinct", "ties"):
+        lg = g[name + "_logits"]
+        pr, tok, keep = oracle.sample_top_k_top_p(lg, g[name + "_temperature"], g[name + "_top_k"], g[name + "_top_p"], g[name + "_E"])
+        rk, rp, rt = g[name + "_keep"], g[name + "_probs"], g[name + "_token"]
+        assert rk.sum(1).min() >= 1 and (rk.sum(1) < lg.shape[1]).any()
+        for t in range(lg.shape[0]):
+            if name == "distinct":
+                assert np.array_equal(keep[t], rk[t]), t
+                assert np.abs(pr[t] - rp[t]).max() <= 1e-6 and tok[t] == rt[t], t
+            else:
+                b = lg[t][rk[t]].min()                       # the boundary group: the lowest logit the reference kept
+                off = lg[t] != b
+                assert np.array_equal(keep[t][off], rk[t][off]), t

@@ -61,6 +61,10 @@ class FakeEngine:
     def set_block_table(self, slot, blocks):
         self.block_tables[slot] = list(blocks)
 
+    def set_sampling_params(self, slot, temperature=0.0, top_k=-1, top_p=1.0):
+        self.sampling = getattr(self, "sampling", {})
+        self.sampling[slot] = (temperature, top_k, top_p)
+
     def _script(self, slots):
         self.out_tokens.fill_(-1)
         out = self.out_script(self.steps, slots) if self.out_script else None
@@ -538,6 +542,18 @@ def test_acceptance_method_selects_the_sampler():
     with pytest.raises(ValueError, match="draft_token_acceptance_method"):
         create_spec_worker(model_config=CFG, model=object(), speculative_config=SpeculativeConfig(3, draft_token_acceptance_method="x"),
                            engine_factory=FakeEngine, device="cpu")
+
+
+def test_sampling_params_reach_the_engine_before_the_prompt_pass():
+    """temperature / top_k / top_p of a request (vllm/sampling_params.py) are handed to the engine at admission, before the
+    prompt pass (its first token is sampled with them); no SamplingParams = greedy."""
+    w = make_worker()
+    a = SequenceGroupMetadata("a", True, {1: SequenceData([1, 2, 3])}, sampling_params=SamplingParams(temperature=0.7, top_k=40, top_p=0.95))
+    b = SequenceGroupMetadata("b", True, {2: SequenceData([4, 5])})
+    w.execute_model(ExecuteModelRequest([a, b], num_lookahead_slots=0))
+    assert w.engine.sampling == {0: (0.7, 40, 0.95), 1: (0.0, -1, 1.0)}
+    order = [c[0] for c in w.engine.calls]
+    assert order == ["add", "add"]
 
 
 def test_failed_admission_gives_the_slots_back():
