@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -66,15 +67,19 @@ float run(const unsigned char* pool, size_t layer_bytes, int L, int B, int ctx, 
 
 int main() {
     hipStream_t st; CK(hipStreamCreate(&st));
-    const int nkv = 8;
-    struct Case { const char* name; int B, ctx, sps, n_splits; } cases[] = {
-        {"config 3: bs 32, ctx 512, 1 split ", 32, 512, 640, 1},
-        {"config 3: bs 32, ctx 512, 2 splits", 32, 512, 640, 2},
-        {"headline: bs 4, ctx 512, 8 splits ", 4, 512, 640, 8},
-        {"bs 32, ctx 2048, 1 split          ", 32, 2048, 2176, 1},
+    struct Case { const char* name; int B, ctx, sps, n_splits, nkv; } cases[] = {
+        {"config 3: bs 32, ctx 512, 1 split ", 32, 512, 640, 1, 8},
+        {"config 3: bs 32, ctx 512, 2 splits", 32, 512, 640, 2, 8},
+        {"headline: bs 4, ctx 512, 8 splits ", 4, 512, 640, 8, 8},
+        {"bs 32, ctx 2048, 1 split          ", 32, 2048, 2176, 1, 8},
+        {"Llama-2-13B: bs 4, ctx 512, 3 splits, 40 kv heads (rows of a head at a 10-KiB stride)", 4, 512, 640, 3, 40},
+        {"Llama-2-13B: bs 4, ctx 512, 6 splits, 40 kv heads", 4, 512, 640, 6, 40},
     };
     unsigned* out; CK(hipMalloc(&out, 1 << 20));
+    const char* only = getenv("KVREAD_ONLY");   // substring filter on the case name (counter passes)
     for (auto& c : cases) {
+        if (only && !strstr(c.name, only)) continue;
+        const int nkv = c.nkv;
         const size_t layer_bytes = 2ull * c.B * c.sps * nkv * 256;   // K then V
         const int L = (int)((600ull << 20) / layer_bytes) > 8 ? 8 : (int)((600ull << 20) / layer_bytes);
         unsigned char* pool; CK(hipMalloc(&pool, layer_bytes * L)); CK(hipMemset(pool, 1, layer_bytes * L));

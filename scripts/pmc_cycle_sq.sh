@@ -3,11 +3,11 @@
 # the counter tool's limit of outstanding dispatches).   scripts/pmc_cycle_sq.sh [batch k]  -> stdout
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/pmc_cycle_sq
-batch=${1:-4}; k=${2:-3}
+batch=${1:-4}; k=${2:-3}; model=${3:-llama-3-8b}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS \
-    --kernel-trace --output-format csv -d $out/p -- python3 $root/scripts/profile_cycle.py --steps 6 --batch $batch --k $k --plain-engine --sync-every-step > $out/p.log 2>&1 || { echo "pass failed"; tail -5 $out/p.log; exit 3; }
+    --kernel-trace --output-format csv -d $out/p -- python3 $root/scripts/profile_cycle.py --steps 6 --model $model --batch $batch --k $k --plain-engine --sync-every-step > $out/p.log 2>&1 || { echo "pass failed"; tail -5 $out/p.log; exit 3; }
 cd $root
 python3 - <<PY
 import csv, glob, collections

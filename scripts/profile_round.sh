@@ -12,7 +12,7 @@ mkdir -p $out $root/profiles
 cd /tmp
 # (1) the bench command itself
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -- python3 $root/bench.py --steps 50 --warmup 5 \
-    --no-cpu-baseline --model $model --batch $batch --k $k > $out/bench.log 2>&1
+    --no-cpu-baseline --other-configs none --model $model --batch $batch --k $k > $out/bench.log 2>&1
 # (2) decode cycles only (no prompt pass in the process)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/cycle -- python3 $root/scripts/profile_cycle.py --steps 20 \
     --model $model --batch $batch --k $k > $out/cycle.log 2>&1
@@ -25,7 +25,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc -- pyt
 cd $root
 suffix=""; [ "$model $batch $k" != "llama-3-8b 4 3" ] && suffix="_${model}_bs${batch}_k${k}"
 f=$(find $out/bench -name '*kernel_stats.csv' | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --model $model --batch $batch --k $k"; grep '^{' $out/bench.log | cut -c1-400; python3 scripts/summarize_prof.py $f; } > profiles/${tag}_bench${suffix}_kernel_stats.txt
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --other-configs none --model $model --batch $batch --k $k"; grep '^{' $out/bench.log | cut -c1-400; python3 scripts/summarize_prof.py $f; } > profiles/${tag}_bench${suffix}_kernel_stats.txt
 f=$(find $out/cycle -name '*kernel_stats.csv' | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- python3 scripts/profile_cycle.py --steps 20 --model $model --batch $batch --k $k   (decode cycles only)"; cat $out/cycle.log | grep cycle_ms; python3 scripts/summarize_prof.py $f; } > profiles/${tag}_cycle${suffix}_kernel_stats.txt
 f=$(find $out/pmc -name '*counter_collection.csv' 2>/dev/null | head -1)
