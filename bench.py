@@ -11,8 +11,8 @@ configs[1]: Llama-3-8B QSpec, k=3, bs=4, synthetic weights and prompts (SURVEY.m
 the timed region (inputs resident in HBM when timing starts).
 
 One JSON line on rank 0.  The hardware quantity is `ms_per_step` (one cycle; identical with the synthetic knob on or
-off): the --steps region is timed `--repeats` (3) times back to back and the MEDIAN region is reported, every region listed in
-`ms_per_step_repeats`.  With N = 1 and the default workload the line also carries `other_configs`: the other BASELINE.json
+off): the --steps region is timed `--repeats` (3) times, every repeat from the SAME sequence state (context lengths, tokens, RNG
+state restored: the repeats are the same work), and the MEDIAN region is reported, every region listed in `ms_per_step_repeats`.  With N = 1 and the default workload the line also carries `other_configs`: the other BASELINE.json
 configs' shapes (k=5 bs=32; Llama-2-13B; Llama-3-70B; TinyLlama) built, timed the same way and freed one after the other on
 this GPU, each with its own `ms_per_step`, `value` and dominant-kernel `roofline`.  `value` = emitted tokens per second of the whole job at the SYNTHETIC draft/target agreement named in
 `config.agreement` (random int4 weights agree ~1-4 %; the reference's trained checkpoint 0.96; SURVEY.md 8d
@@ -94,6 +94,19 @@ def make_bench_engine_class():
 
         def set_agreement(self, rho):
             self._rho = rho
+
+        # the sequence state at the start of the timed regions: every repeat of the --steps region starts from the SAME
+        # state (same context lengths, same tokens, same RNG state), so the repeats time the same work -- without it the
+        # context grows by ~(k+1) tokens per cycle and a later region is a different (longer-context) workload
+        def save_region_state(self):
+            return ([t.clone() for t in (self.seq_lens, self.gen_lens, self.last_token, self.sampler.rng_state)],
+                    list(self._len_ub), list(self._gen_ub))
+
+        def restore_region_state(self, state):
+            tensors, len_ub, gen_ub = state
+            for t, s in zip((self.seq_lens, self.gen_lens, self.last_token, self.sampler.rng_state), tensors):
+                t.copy_(s)
+            self._len_ub, self._gen_ub = list(len_ub), list(gen_ub)
 
         def _verify_logits_hook(self, draft_ids):
             if self._rho is None:
@@ -400,7 +413,7 @@ def timed_run(QSpecEngine, model, k, batch, prompts, prompt_len, agreement, warm
     """W untimed cycles, then `repeats` timed regions of exactly `steps` cycles each, every region bracketed by a barrier +
     torch.cuda.synchronize() on both sides, MAX over ranks per region.  Returns the engine and one record per region:
     (seconds, accepted, emitted, draft tokens)."""
-    total = warmup + repeats * steps + 2
+    total = warmup + steps + 2          # (every repeat restarts from the state behind the warm-up)
     eng = QSpecEngine(model, k, batch, max_model_len=prompt_len + total * (k + 1) + 32, block_size=16,
                       max_new_tokens=total * (k + 1) + 8, use_graph=True, seed=seed)
     eng.set_agreement(agreement)
@@ -408,7 +421,10 @@ def timed_run(QSpecEngine, model, k, batch, prompts, prompt_len, agreement, warm
     for _ in range(warmup):
         eng.step()
     regions = []
-    for _ in range(repeats):
+    state0 = eng.save_region_state()
+    for r in range(repeats):
+        if r:
+            eng.restore_region_state(state0)
         barrier(world)
         c0 = eng.sampler.counters.clone()
         barrier(world)
