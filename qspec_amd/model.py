@@ -433,7 +433,10 @@ class QuarotLlamaForCausalLM:
         ops.sample_top_k_top_p(logits, probs, token, temperature, top_k, top_p, exponential=exponential, rng_state=rng_state)
 
     # ------------------------------------------------------------------ module-wise path (reference op order)
-    def forward_modulewise(self, input_ids, positions, kv_caches, attn_metadata: AttentionMetadata, w4a4=False):
+    def forward_modulewise(self, input_ids, positions, kv_caches, attn_metadata: AttentionMetadata, w4a4=False,
+                           attn_override=None):
+        """attn_override (tests): per layer an fp16 [T, q_size] tensor that REPLACES the attention output of that layer
+        (teacher forcing of the one stage whose fp32 summation order the hardware fixes)."""
         cfg, md = self.config, attn_metadata
         kw = {"w4a4": w4a4}
         T = input_ids.numel()
@@ -457,6 +460,8 @@ class QuarotLlamaForCausalLM:
             attn = torch.empty(T, cfg.q_size, dtype=torch.float16, device=self.device)
             ops.paged_attention(qkv, qkv.shape[1], kc, vc, md.block_tables, md.ctx_lens, md.q_start, T, md.max_q_len,
                                 cfg.num_attention_heads, self.sm_scale, md.n_splits, ws, attn)
+            if attn_override is not None:
+                attn.copy_(attn_override[li])
             a = attn.view(-1, cfg.num_attention_heads, cfg.head_dim)
             a = head_had(a.transpose(-1, -2).reshape(-1, cfg.num_attention_heads), **kw)          # :231
             a = a.view(-1, cfg.head_dim, cfg.num_attention_heads).transpose(-1, -2).reshape(T, cfg.hidden_size).contiguous()

@@ -455,6 +455,62 @@ def test_full_depth_distance_to_true_math(oracle):
     assert np.array_equal(ref_l.astype(np.float32).argmax(-1)[clear], true_l.argmax(-1)[clear])
 
 
+def test_draft_divergence_is_the_attention_outputs_last_bit(oracle):
+    """The cause behind the statistical (not exact) bars on end-to-end draft distributions, shown directly: a
+    3-layer model at the Llama-3-8B width, 32 decode tokens over a random paged KV history (the config-3 draft shape), three
+    input draws.  The attention output is the ONE stage of the draft layer whose bits the hardware fixes (2^x instruction, MFMA
+    summation order): un-forced, a few hundred of its 131 k fp16 values per layer differ from the oracle's in the last bit
+    (asserted: within 1e-3, and not all equal); most of those differences are absorbed by the head Hadamard + int4 quantiser,
+    the rest is what occasionally flips an int4 abs-max and a whole row with it.  With NOTHING but each layer's attention
+    output teacher-forced from the oracle, every row of the final hidden state and every K / V row written are bit-identical
+    to the oracle (asserted for every draw): every other stage is exact, so attention's last bit is the whole difference."""
+    from oracle.model import OracleModel
+    from qspec_amd import ops as _ops
+    from qspec_amd.model import QuarotLlamaConfig, QuarotLlamaForCausalLM
+    cfg = QuarotLlamaConfig(4096, 14336, 32, 8, 3, 2048, 1e-5, 500000.0, 1024, "llama-3-8b-3layer")
+    model = QuarotLlamaForCausalLM(cfg, DEV).init_synthetic(seed=3, lm_head_std=0.05)
+    om = OracleModel.from_torch_model(model, 16)
+    total_rows = total_bits = 0
+    for draw in range(3):
+        rng = np.random.default_rng(31 + draw)
+        ctx_lens = [int(c) for c in rng.integers(40, 500, 32)]
+        inp = make_inputs(model, rng, ctx_lens, 1)
+        kv_np = [(k.copy(), v.copy()) for k, v in inp["kv_np"]]
+        ref, trace = om.forward(inp["ids"], inp["pos"], kv_np, inp["slots"], inp["bt"], inp["ctx"], inp["q_start"], True,
+                                return_trace=True)
+        grabbed = []
+        real = _ops.paged_attention
+
+        def spy(q, q_stride, kc, vc, bt, ctx, qs, tokens, max_q, nh, sm, ns, ws, out):
+            real(q, q_stride, kc, vc, bt, ctx, qs, tokens, max_q, nh, sm, ns, ws, out)
+            grabbed.append(out.clone())
+
+        def run(override, watch=False):
+            kv = [(torch.from_numpy(k).to(DEV), torch.from_numpy(v).to(DEV)) for k, v in inp["kv_np"]]
+            if watch:
+                _ops.paged_attention = spy
+            try:
+                out = model.forward_modulewise(inp["ids_t"], inp["pos_t"], kv, inp["md"], w4a4=True, attn_override=override)
+                torch.cuda.synchronize()
+            finally:
+                _ops.paged_attention = real
+            return out.cpu().numpy(), kv
+        plain, _ = run(None, watch=True)
+        forced, kv_f = run([torch.from_numpy(trace[f"attn_{li}"]).to(DEV) for li in range(cfg.num_hidden_layers)])
+        assert np.array_equal(forced.view(np.uint16), ref.view(np.uint16)), draw        # every row bit-identical
+        for li in range(cfg.num_hidden_layers):
+            assert np.array_equal(kv_f[li][0].cpu().numpy().view(np.uint16), kv_np[li][0].view(np.uint16)), (draw, li)
+            assert np.array_equal(kv_f[li][1].cpu().numpy().view(np.uint16), kv_np[li][1].view(np.uint16)), (draw, li)
+        # layer 0's attention has identical inputs on both sides: within 1e-3 of the oracle's
+        a_hip, a_ref = grabbed[0].cpu().numpy(), trace["attn_0"]
+        assert np.abs(a_hip.astype(np.float64) - a_ref.astype(np.float64)).max() <= 1e-3 * max(1.0, float(np.abs(a_ref).max()))
+        total_bits += int((a_hip.view(np.uint16) != a_ref.view(np.uint16)).sum())
+        total_rows += int((plain.view(np.uint16) != ref.view(np.uint16)).any(axis=1).sum())
+    print(f"3 draws x 32 rows x 3 layers: layer-0 attention outputs differing in the last bit(s): {total_bits} of {3 * 32 * 4096}; "
+          f"rows of the final hidden state differing un-forced: {total_rows} of 96; with attention forced: 0")
+    assert total_bits > 0        # the difference this test is about exists
+
+
 def test_engine_cycle_with_typical_acceptance_sampler(tiny, oracle):
     """The cycle with draft_token_acceptance_method = typical_acceptance_sampler: the engine's output must be what the
     reference rule (the oracle's restatement, pinned to the reference class by tests/golden/typical_acceptance.npz) gives on
