@@ -1525,6 +1525,111 @@ __global__ __launch_bounds__(NW * 64) void gemm_f16_stream_kernel(const f16* __r
     }
 }
 
+// ---- long rows (K = 8192, Llama-3-70B's lm_head: 2.1 GB): NB batches of NW x UB steps per tile, as gemm_w4a4_longk_kernel
+// does for the int4 GEMM -- 16 waves x 16 steps of fp16 fragments do not fit the 128-VGPR budget of 1024 threads, two batches
+// of 8 do (64 VGPRs of activation fragments + 32 of weights).  Each weight register is refilled with the same step of the next
+// batch (the next tile's first batch behind the last one) right behind its consumer.  Same sums per output in the same wave
+// order as gemm_f16_kernel's, fp32; same HeadMax partials as gemm_f16_stream_kernel.
+template <int NW, int UB, int NB>
+__global__ __launch_bounds__(NW * 64) void gemm_f16_longk_kernel(const f16* __restrict__ x, const f16* __restrict__ wt,
+                                                                 f16* __restrict__ out, int M, int N, int K, int ntiles,
+                                                                 HeadMax* __restrict__ part_max) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = reinterpret_cast<float*>(smem);   // [2][NW][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int c = tid & 15, m = tid >> 4;
+    const bool ethread = m < M;
+    const int ridx = (m & 3) * 64 + ((m >> 2) & 3) * 16 + c;
+    constexpr int BB = UB * NW * 64;               // bytes of a weight row per batch
+    f16x8 af[NB][UB];
+    {
+        const unsigned char* xrow = reinterpret_cast<const unsigned char*>(x + (size_t)(r < M ? r : 0) * K) + g * 16;
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int u = 0; u < UB; u++) af[b][u] = *reinterpret_cast<const f16x8*>(xrow + (size_t)b * BB + step_off<NW, UB>(wave, u));
+    }
+    int tile = blockIdx.x, par = 0;
+    const int my_tiles = (ntiles - tile + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto wptr = [&](int t, int b) -> const unsigned char* {
+        return reinterpret_cast<const unsigned char*>(wt + (size_t)(t * 16 + r) * K) + (size_t)b * BB + g * 16;
+    };
+    f16x8 w[UB];
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const unsigned char* wp0 = wptr(tile, 0);
+#pragma unroll
+        for (int u = 0; u < UB; u++) w[u] = wload<f16x8>(wp0 + step_off<NW, UB>(wave, u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float best_v = -__builtin_inff();
+    int best_i = 0x7fffffff;
+    auto finish = [&](int t, int par) {
+        float* rb = red + par * NW * 256;
+#pragma unroll
+        for (int i = 0; i < 4; i++) rb[wave * 256 + i * 64 + lane] = acc[i];
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        if (ethread) {
+            float sum = rb[ridx];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[w2 * 256 + ridx];
+            const f16 hv = f2h(sum);
+            out[(size_t)m * N + t * 16 + c] = hv;
+            const float fv = h2f(hv);
+            if (fv > best_v) {          // tiles come in increasing column order: a tie keeps the first column
+                best_v = fv;
+                best_i = t * 16 + c;
+            }
+        }
+    };
+    for (int q = 0; q < my_tiles - 1; q++) {
+        const int nt = tile + gridDim.x;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const unsigned char* wp = b + 1 < NB ? wptr(tile, b + 1) : wptr(nt, 0);
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[b][u], w[u], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                w[u] = wload<f16x8>(wp + step_off<NW, UB>(wave, u));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        finish(tile, par);
+        par ^= 1;
+        tile = nt;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[b][u], w[u], acc, 0, 0, 0);
+            if (b + 1 < NB) {
+                __builtin_amdgcn_sched_barrier(0);
+                w[u] = wload<f16x8>(wptr(tile, b + 1) + step_off<NW, UB>(wave, u));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    finish(tile, par);
+    if (part_max) {   // the 16 columns of a row sit in 16 consecutive lanes: larger value, then smaller column, wins
+#pragma unroll
+        for (int mk = 1; mk < 16; mk <<= 1) {
+            const float ov = __shfl_xor(best_v, mk, 64);
+            const int oi = __shfl_xor(best_i, mk, 64);
+            if (ov > best_v || (ov == best_v && oi < best_i)) {
+                best_v = ov;
+                best_i = oi;
+            }
+        }
+        if (ethread && c == 0) part_max[(size_t)m * gridDim.x + blockIdx.x] = HeadMax{best_v, best_i};
+    }
+}
+
 // ---- the same lm_head with its 1 GB weight stream through self-service LDS-DMA (K = 4096, M <= 16).
 // The draft GEMMs did not gain from LDS-DMA (what is above their floor is the launch's fixed
 // sequence, not stream time); THIS launch is 99 % stream: 31 tiles of 128 KB per workgroup, where the register path's
@@ -1706,7 +1811,7 @@ static int gemm_f16_sdma_launch(const f16* x, const f16* w, f16* out, int M, int
     return gemm_f16_sdma_launch_inst<1>(x, w, out, M, N, ntiles, grid, pm, st);
 }
 bool gemm_f16_stream_supported(int M, int N, int K) {
-    return M >= 1 && M <= 16 && N % 16 == 0 && (K == 1024 || K == 2048 || K == 4096 || K == 5120);
+    return M >= 1 && M <= 16 && N % 16 == 0 && (K == 1024 || K == 2048 || K == 4096 || K == 5120 || K == 8192);
 }
 int gemm_f16_stream_grid(int N) {
     const int ntiles = N / 16;
@@ -1733,6 +1838,11 @@ int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, v
     HeadMax* pm = reinterpret_cast<HeadMax*>(part_max);
     if (K == 4096 && ntiles >= 4 * grid && head_sdma_on()) {   // a long stream: LDS-DMA (see gemm_f16_sdma_kernel)
         return gemm_f16_sdma_launch(x, w, out, M, N, ntiles, grid, pm, st);
+    }
+    if (K == 8192) {   // 256 steps of 64 bytes per row = 16 waves x 4 steps x 4 batches (8 x 2: 20 VGPRs spilled at 1024 threads)
+        hipLaunchKernelGGL((gemm_f16_longk_kernel<16, 4, 4>), dim3(grid), dim3(16 * 64), (size_t)2 * 16 * 1024, st, x, w, out, M, N,
+                           K, ntiles, pm);
+        return 0;
     }
 #define QS_F16S(NWV, UBV) hipLaunchKernelGGL((gemm_f16_stream_kernel<NWV, UBV>), dim3(grid), dim3(NWV * 64), (size_t)2 * NWV * 1024, st, x, w, out, M, N, K, ntiles, pm)
     if (K == 4096) QS_F16S(8, 16);

@@ -35,6 +35,7 @@ for M in Ms:
             us3 = t(lambda: torch.matmul(x, wd.t(), out=out))
             line += f" | dequant+lib {us2:8.1f} us | lib only {us3:8.1f} us {fl/us3/1e6:7.1f} TF"
         print(line, flush=True)
+if "--no-head" in sys.argv or os.environ.get("QSPEC_TILED_MT"): sys.exit(0)
 # ---- lm_head (fp16 x fp16)
 N, K = 128256, 4096
 w = (torch.randn(N, K, device=dev) * 0.02).half()

@@ -574,7 +574,7 @@ def test_ln_prologue_rejects_aliasing_and_big_m(ops, oracle):
     assert not ops.ln_linear_s4s4_supported(4, 128, 3072)
 
 
-@pytest.mark.parametrize("M,N,K", [(4, 1000, 4096), (16, 128256, 256), (20, 2048, 2048)])
+@pytest.mark.parametrize("M,N,K", [(4, 1000, 4096), (16, 128256, 256), (20, 2048, 2048), (8, 4096, 8192), (16, 1040, 8192), (1, 32, 8192)])
 def test_linear_f16_within_1e3(ops, oracle, M, N, K):
     rng = np.random.default_rng(N)
     x = rand_hidden(rng, M, K)
@@ -890,7 +890,7 @@ def test_softmax_argmax(ops, oracle, T, V):
     assert np.array_equal(host(probs).view(np.uint32), p0.view(np.uint32))
 
 
-@pytest.mark.parametrize("T,V,K", [(4, 128256, 4096), (16, 128256, 4096), (1, 128256, 4096), (3, 32000, 2048), (16, 2048, 1024)])
+@pytest.mark.parametrize("T,V,K", [(4, 128256, 4096), (16, 128256, 4096), (1, 128256, 4096), (3, 32000, 2048), (16, 2048, 1024), (8, 16384, 8192)])
 def test_lm_head_softmax_argmax_fused_front_end(ops, oracle, T, V, K):
     """lm_head launch (row maxima from its epilogue) + denominator + write-once probabilities == the two-step path
     (qspec_linear_f16 + qspec_softmax_argmax) bit for bit, and == the oracle's softmax of the GPU's own logits
