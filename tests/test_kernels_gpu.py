@@ -1457,6 +1457,56 @@ def test_sample_top_k_top_p_reference_fixture(ops, oracle, golden_dir):
     assert int(rng[1].item()) == 8 and len(seen) > 1
 
 
+def test_sample_top_k_top_p_edge_rows_and_full_vocabulary(ops, oracle):
+    """Edge rows against the oracle (whose rule is the reference's, test_oracle_golden.py): a uniform row (every logit equal:
+    one group of V tokens -- kept whole whatever top-k / top-p say, a 128 k count in one histogram bin), a row at the fp16
+    ceiling, -inf logits (never kept), top_k = 1, top_p -> 0, a vocabulary that is no multiple of 8; then the full Llama-3
+    vocabulary at 16 rows (the verify pass's shape) with DISTINCT-per-row-ordering logits: kept sets equal, tokens equal."""
+    rng = np.random.default_rng(5)
+    V = 1003
+    lg = (rng.standard_normal((6, V)) * 3).astype(np.float16)
+    lg[0] = np.float16(0.25)                                  # uniform
+    lg[1, 17] = np.float16(60000.0)                           # the fp16 ceiling: everything else underflows
+    lg[2, ::3] = -np.inf                                      # masked-out tokens of a previous stage
+    temp = np.array([1.0, 1.0, 0.8, 1.0, 1.5, 0.6], np.float32)
+    top_k = np.array([5, -1, 40, 1, -1, 900], np.int32)
+    top_p = np.array([0.3, 0.9, 0.95, 1.0, 1e-6, 0.999], np.float32)
+    E = rng.exponential(1.0, (6, V)).astype(np.float32)
+    probs = torch.empty(6, V, dtype=torch.float32, device=DEV); tok = torch.empty(6, dtype=torch.int64, device=DEV)
+    ops.sample_top_k_top_p(dev(lg), probs, tok, dev(temp), dev(top_k), dev(top_p), exponential=dev(E))
+    pr, tk = host(probs), host(tok)
+    assert np.allclose(pr.sum(1), 1.0, atol=1e-5) and not np.isnan(pr).any()
+    assert (pr[0] > 0).all() and np.allclose(pr[0], 1.0 / V, rtol=1e-5)             # the uniform group stays whole
+    assert pr[1, 17] == 1.0 and tk[1] == 17
+    assert (pr[2, ::3] == 0).all()
+    assert (pr[3] > 0).sum() == (lg[3] == lg[3].max()).sum() and lg[3][tk[3]] == lg[3].max()      # top_k = 1 (+ ties)
+    assert (pr[4] > 0).sum() == (lg[4] == lg[4].max()).sum()                         # top_p -> 0: the top group only
+    po, to, keep = oracle.sample_top_k_top_p(lg, temp, top_k, top_p, E)
+    for t in (1, 2, 5):                                       # rows whose boundary group is a single token: the oracle's rule exactly
+        b = lg[t][keep[t]].min()
+        if (lg[t] == b).sum() == 1:
+            assert np.array_equal(pr[t] > 0, keep[t]) and tk[t] == to[t], t
+    # the full vocabulary, 16 rows
+    V, T = 128256, 16
+    base = np.linspace(-12, 12, 60000).astype(np.float16)
+    base = np.unique(base)                                     # ~50 k distinct fp16 values: ties are unavoidable at V = 128 k
+    lg = np.stack([base[rng.integers(0, base.size, V)] for _ in range(T)])
+    temp = rng.uniform(0.5, 1.5, T).astype(np.float32); top_k = rng.integers(1, 200, T).astype(np.int32)
+    top_p = rng.uniform(0.5, 1.0, T).astype(np.float32)
+    E = rng.exponential(1.0, (T, V)).astype(np.float32)
+    probs = torch.empty(T, V, dtype=torch.float32, device=DEV); tok = torch.empty(T, dtype=torch.int64, device=DEV)
+    ops.sample_top_k_top_p(dev(lg), probs, tok, dev(temp), dev(top_k), dev(top_p), exponential=dev(E))
+    pr, tk = host(probs), host(tok)
+    po, to, keep = oracle.sample_top_k_top_p(lg, temp, top_k, top_p, E)
+    assert np.allclose(pr.sum(1), 1.0, atol=1e-5)
+    for t in range(T):
+        b = lg[t][keep[t]].min()
+        off = lg[t] != b
+        assert np.array_equal((pr[t] > 0)[off], keep[t][off]) and (pr[t] > 0)[~off].all(), t
+        if np.array_equal(pr[t] > 0, keep[t]):
+            assert tk[t] == to[t] and np.abs(pr[t] - po[t]).max() <= 1e-6, t
+
+
 def test_typical_acceptance_sampler_reference_fixture(ops, oracle, golden_dir):
     """TypicalAcceptanceSampler on the GPU against the REFERENCE class run on CPU (tests/golden/typical_acceptance.npz, 20
     deterministic cases): output layout, accept masks, counters exact; the replacement token = the target's argmax; through
