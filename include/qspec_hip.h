@@ -471,6 +471,46 @@ int qspec_spec_snapshot(int batch, int restore, int32_t* seq_lens, int32_t* gen_
 int qspec_collect_error_words(int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3, int clear, int64_t* out,
                               void* stream);
 
+/* Activation layout of the verify pass at <= 16 tokens (no reference counterpart: the reference's fp16 GEMM is
+ * bitblas.Matmul on row-major x, quarot_nn/linear.py:122).  The W4A16 GEMMs above consume x as v_mfma_f32_16x16x32_f16
+ * operand fragments; reading row-major x means one pass through LDS per launch to regroup it.  The `_xp` twins below
+ * move that regrouping into the PRODUCER's store: the norm, the head transform and the MLP transform write a
+ * FRAGMENT-MAJOR tile of always 16 rows x K halves (rows >= tokens are never read back into a result):
+ *     offset(r, k) = ((((k / 128) * 4 + ((k % 128) / 8) % 4) * 64 + ((k % 128) / 32) * 16 + r) * 8 + p(k % 8),
+ *     p(e) = 2 * (e % 4) + e / 4
+ * (8 consecutive halves = the two 4-half operand registers of k-group g at k and k+4 of one 16x16x32 instruction pair),
+ * and the GEMM twins load their operand registers straight from it.  Every `_xp` entry computes exactly the bits of
+ * its row-major twin -- only where a value is stored or loaded changes.  Same prototypes, same error codes; an `_xp`
+ * call at a shape without a fragment-major form fails (ask qspec_w4a16_act_layout_supported(M, K) first: 1 = the GEMMs
+ * at (M tokens, K) read the tile).  Producers: out / out_f16 is the tile (tokens <= 16; heads_hadamard_merged: 32 heads,
+ * q == NULL; mlp_hadamard: workspace != NULL, q == NULL; mix_merged_spread: part_amax == NULL).  Consumers: x is the tile. */
+int qspec_w4a16_act_layout_supported(int M, int K);
+int qspec_mlp_hadamard_act_layout_supported(int tokens, int intermediate, int K);   /* 1: qspec_mlp_hadamard_xp exists here */
+int qspec_add_rms_norm_fp16_xp(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const qspec_half* delta,
+                               float eps, int tokens, int hidden, void* stream);
+int qspec_add_rms_norm_fp16_partial_xp(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const float* part,
+                                       const qspec_half* ws, int slices, float eps, int tokens, int hidden, void* stream);
+int qspec_heads_hadamard_merged_xp(const void* attn_workspace, int max_tokens, int n_splits, qspec_half* out_f16, int8_t* q,
+                                   qspec_half* scale, float had_scale, float clip_ratio, int tokens, int heads,
+                                   int head_dim, void* stream);
+int qspec_heads_hadamard_mix_merged_spread_xp(const void* attn_workspace, int max_tokens, int n_splits, const qspec_half* hadK,
+                                              int K, qspec_half* out_f16, float* part_amax, float had_scale, int tokens,
+                                              int heads, int head_dim, void* stream);
+int qspec_mlp_hadamard_xp(const qspec_half* act, const qspec_half* hadK, qspec_half* out_f16, int8_t* q, qspec_half* scale,
+                          float had_scale, float clip_ratio, int tokens, int intermediate, int K, void* workspace,
+                          void* stream);
+int qspec_w4a16_linear_xp(const qspec_half* x, const int8_t* wq, const qspec_half* ws, const qspec_half* bias,
+                          qspec_half* out, int M, int N, int K, void* workspace, void* stream);
+int qspec_w4a16_linear_partial_xp(const qspec_half* x, const int8_t* wq, float* part, int M, int N, int K, int slices,
+                                  void* stream);
+int qspec_qkv_rope_linear_w4a16_xp(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M,
+                                   int N, int K, const int64_t* positions, const qspec_half* cos_sin_cache,
+                                   qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
+                                   int num_heads, int num_kv_heads, int head_size, int rot_dim, void* workspace,
+                                   void* stream);
+int qspec_gate_up_silu_linear_w4a16_xp(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
+                                       int intermediate, int K, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

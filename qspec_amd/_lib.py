@@ -101,6 +101,15 @@ SIGNATURES = {
     "qspec_collect_error_words": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
 }
 
+# Fragment-major activation tiles (include/qspec_hip.h, "activation layout"): each of these has an `_xp` twin with the same
+# prototype, reading / writing the 16-row tile in MFMA operand order instead of row-major.
+XP_TWINS = ("qspec_add_rms_norm_fp16", "qspec_add_rms_norm_fp16_partial", "qspec_heads_hadamard_merged",
+            "qspec_heads_hadamard_mix_merged_spread", "qspec_mlp_hadamard", "qspec_w4a16_linear",
+            "qspec_w4a16_linear_partial", "qspec_qkv_rope_linear_w4a16", "qspec_gate_up_silu_linear_w4a16")
+SIGNATURES.update({name + "_xp": SIGNATURES[name] for name in XP_TWINS})
+SIGNATURES["qspec_w4a16_act_layout_supported"] = (_i, [_i, _i])
+SIGNATURES["qspec_mlp_hadamard_act_layout_supported"] = (_i, [_i, _i, _i])
+
 
 # entry points only the experimental build exports (csrc/experimental/qspec_hip_experimental.h): bound when present
 EXPERIMENTAL_SIGNATURES = {

@@ -42,9 +42,17 @@ static int tiled_min_m() {
     return v <= 0 ? (1 << 30) : v;
 }
 
+// The `_xp` entry points (fragment-major activation tiles between the verify pass's producers and its W4A16 GEMMs) are the base
+// entry points called with this flag raised: one body per op.  Thread-local, raised only for the duration of an `_xp` call.
+static thread_local int g_xp = 0;
+struct XpScope {
+    XpScope() { g_xp = 1; }
+    ~XpScope() { g_xp = 0; }
+};
+
 extern "C" {
 
-int qspec_abi_version(void) { return 5; }
+int qspec_abi_version(void) { return 6; }
 const char* qspec_last_error(void) { return g_err; }
 
 int qspec_rms_norm_general_fuse_sum_i4(int8_t* out_q, const qspec_half* x, qspec_half* input_sum, qspec_half* scaling,
@@ -83,7 +91,13 @@ int qspec_add_rms_norm_fp16(qspec_half* out, qspec_half* hidden_out, const qspec
     NONNULL(op, out); NONNULL(op, x);
     if (delta) NONNULL(op, hidden_out);
     if (hidden % 1024 || hidden > 8192 || hidden <= 0) return fail("%s: hidden=%d must be a multiple of 1024, <= 8192", op, hidden);
-    return finish(op, qspec::ln_fp16(CH(x), CH(delta), H(hidden_out), H(out), eps, tokens, hidden, ST));
+    if (g_xp && tokens > 16) return fail("%s: the fragment-major layout is a 16-row tile (tokens=%d)", op, tokens);
+    return finish(op, qspec::ln_fp16(CH(x), CH(delta), H(hidden_out), H(out), eps, tokens, hidden, ST, g_xp));
+}
+int qspec_add_rms_norm_fp16_xp(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const qspec_half* delta,
+                               float eps, int tokens, int hidden, void* stream) {
+    XpScope xp;
+    return qspec_add_rms_norm_fp16(out, hidden_out, x, delta, eps, tokens, hidden, stream);
 }
 int qspec_fuse_sym_quant(const qspec_half* x, qspec_half* scale, int8_t* q, float clip_ratio, int tokens, int k,
                          void* stream) {
@@ -203,8 +217,10 @@ int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* 
     if (M == 0 || N == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, out);
     if (N % 16 || K % 128 || K <= 0) return fail("%s: need N %% 16 == 0 and K %% 128 == 0 (N=%d K=%d)", op, N, K);
+    if (g_xp && !(!bias && use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K) && qspec::gemm_w4a16_xperm_supported(M, K)))
+        return fail("%s: no fragment-major form for (M=%d N=%d K=%d): ask qspec_w4a16_act_layout_supported", op, M, N, K);
     if (!bias && use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K))
-        return finish(op, qspec::gemm_w4a16_stream(CH(x), 0, wq, 0, CH(ws), H(out), M, N, K, ST));
+        return finish(op, qspec::gemm_w4a16_stream(CH(x), 0, wq, 0, CH(ws), H(out), M, N, K, ST, g_xp));
     // long K (down_proj): K slices of a built length, raw sums in the workspace (behind its ticket counters), finish
     const int S = (!bias && use_stream() && workspace) ? qspec::gemm_w4a16_stream_partial_slices(M, N, K) : 0;
     if (S > 0 && (size_t)S * M * N * sizeof(float) + 8192 <= qspec::gemm_w4a16_ws_bytes()) {
@@ -218,6 +234,15 @@ int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* 
                                                   workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 8192) : nullptr,
                                                   workspace ? qspec::gemm_w4a16_ws_bytes() - 8192 : 0, ST));
     return finish(op, qspec::gemm_w4a16(CH(x), wq, CH(ws), CH(bias), H(out), M, N, K, workspace, ST));
+}
+int qspec_mlp_hadamard_act_layout_supported(int tokens, int intermediate, int K) {
+    return qspec::mlp_hadamard_xperm_supported(tokens, intermediate, K) ? 1 : 0;
+}
+int qspec_w4a16_act_layout_supported(int M, int K) { return use_stream() && qspec::gemm_w4a16_xperm_supported(M, K) ? 1 : 0; }
+int qspec_w4a16_linear_xp(const qspec_half* x, const int8_t* wq, const qspec_half* ws, const qspec_half* bias,
+                          qspec_half* out, int M, int N, int K, void* workspace, void* stream) {
+    XpScope xp;
+    return qspec_w4a16_linear(x, wq, ws, bias, out, M, N, K, workspace, stream);
 }
 int qspec_linear_f16(const qspec_half* x, const qspec_half* w, qspec_half* out, int M, int N, int K, void* stream) {
     const char* op = "qspec_linear_f16";
@@ -289,7 +314,16 @@ int qspec_heads_hadamard_merged(const void* attn_workspace, int max_tokens, int 
     if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
     if (head_dim != 128 || !(heads == 32 || heads == 64))
         return fail("%s: built for head_dim 128 and 32 / 64 heads (got %d x %d)", op, heads, head_dim);
-    return finish(op, qspec::heads_hadamard_merge((const float*)attn_workspace, max_tokens, n_splits, H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, heads, head_dim, ST));
+    if (g_xp && (q || heads != 32 || tokens > 16))
+        return fail("%s: the fragment-major fp16 output exists for 32 heads, <= 16 tokens, no quantiser", op);
+    return finish(op, qspec::heads_hadamard_merge((const float*)attn_workspace, max_tokens, n_splits, H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, heads, head_dim, ST, g_xp));
+}
+int qspec_heads_hadamard_merged_xp(const void* attn_workspace, int max_tokens, int n_splits, qspec_half* out_f16, int8_t* q,
+                                   qspec_half* scale, float had_scale, float clip_ratio, int tokens, int heads,
+                                   int head_dim, void* stream) {
+    XpScope xp;
+    return qspec_heads_hadamard_merged(attn_workspace, max_tokens, n_splits, out_f16, q, scale, had_scale, clip_ratio, tokens, heads,
+                                       head_dim, stream);
 }
 int qspec_heads_hadamard_merged_spread_supported(int tokens, int heads, int head_dim) {
     return tokens >= 0 && tokens * 8 <= 1024 && heads == 32 && head_dim == 128;
@@ -319,8 +353,16 @@ int qspec_heads_hadamard_mix_merged_spread(const void* attn_workspace, int max_t
     if (!qspec::heads_hadamard_mix_merge_spread_supported(tokens, heads, head_dim, K))
         return fail("%s: needs head_dim 128, heads = K * 2^p <= 64 with 2 <= K <= 172, at most 128 tokens (got %d x %d, K = %d, %d tokens)",
                     op, heads, head_dim, K, tokens);
+    if (g_xp && (part_amax || tokens > 16)) return fail("%s: the fragment-major fp16 output: <= 16 tokens, no part_amax", op);
     return finish(op, qspec::heads_hadamard_mix_merge_spread((const float*)attn_workspace, max_tokens, n_splits, CH(hadK), H(out_f16),
-                                                             part_amax, had_scale, tokens, heads, head_dim, K, ST));
+                                                             part_amax, had_scale, tokens, heads, head_dim, K, ST, g_xp));
+}
+int qspec_heads_hadamard_mix_merged_spread_xp(const void* attn_workspace, int max_tokens, int n_splits, const qspec_half* hadK,
+                                              int K, qspec_half* out_f16, float* part_amax, float had_scale, int tokens,
+                                              int heads, int head_dim, void* stream) {
+    XpScope xp;
+    return qspec_heads_hadamard_mix_merged_spread(attn_workspace, max_tokens, n_splits, hadK, K, out_f16, part_amax, had_scale, tokens,
+                                                  heads, head_dim, stream);
 }
 int qspec_embedding(const int64_t* ids, const qspec_half* table, qspec_half* out, int tokens, int hidden, int vocab,
                     void* stream) {
@@ -476,7 +518,15 @@ int qspec_mlp_hadamard(const qspec_half* act, const qspec_half* hadK, qspec_half
     if (K > 1) NONNULL(op, hadK);
     if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
     if (intermediate % 8) return fail("%s: intermediate %% 8 != 0", op);
-    return finish(op, qspec::silu_mul_hadamard(CH(act), CH(hadK), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, intermediate, K, 1, workspace, ST));
+    if (g_xp && (q || tokens > 16 || !workspace))
+        return fail("%s: the fragment-major fp16 output exists in the spread forms (workspace), <= 16 tokens, no quantiser", op);
+    return finish(op, qspec::silu_mul_hadamard(CH(act), CH(hadK), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, intermediate, K, 1, workspace, ST, g_xp));
+}
+int qspec_mlp_hadamard_xp(const qspec_half* act, const qspec_half* hadK, qspec_half* out_f16, int8_t* q, qspec_half* scale,
+                          float had_scale, float clip_ratio, int tokens, int intermediate, int K, void* workspace,
+                          void* stream) {
+    XpScope xp;
+    return qspec_mlp_hadamard(act, hadK, out_f16, q, scale, had_scale, clip_ratio, tokens, intermediate, K, workspace, stream);
 }
 int qspec_qkv_rope_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
                                qspec_half* qkv, int M, int N, int K, const int64_t* positions,
@@ -505,9 +555,20 @@ int qspec_qkv_rope_linear_w4a16(const qspec_half* x, const int8_t* wq, const qsp
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, qkv); NONNULL(op, positions);
     NONNULL(op, cos_sin_cache); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
     if (head_size != 128 || rot_dim != 128) return fail("%s: head_size and rot_dim must be 128", op);
+    if (g_xp && !(use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K) && qspec::gemm_w4a16_xperm_supported(M, K)))
+        return fail("%s: no fragment-major form for (M=%d N=%d K=%d)", op, M, N, K);
     if (use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K))
-        return finish(op, qspec::gemm_w4a16_stream_qkv_rope(CH(x), wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST));
+        return finish(op, qspec::gemm_w4a16_stream_qkv_rope(CH(x), wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST, g_xp));
     return finish(op, qspec::gemm_w4a16_qkv_rope(CH(x), wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, workspace, ST));
+}
+int qspec_qkv_rope_linear_w4a16_xp(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M,
+                                   int N, int K, const int64_t* positions, const qspec_half* cos_sin_cache,
+                                   qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
+                                   int num_heads, int num_kv_heads, int head_size, int rot_dim, void* workspace,
+                                   void* stream) {
+    XpScope xp;
+    return qspec_qkv_rope_linear_w4a16(x, wq, ws, qkv, M, N, K, positions, cos_sin_cache, key_cache, value_cache, slot_mapping,
+                                       num_heads, num_kv_heads, head_size, rot_dim, workspace, stream);
 }
 int qspec_gate_up_silu_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
                                    qspec_half* act, int M, int intermediate, int K, void* stream) {
@@ -526,9 +587,16 @@ int qspec_gate_up_silu_linear_w4a16(const qspec_half* x, const int8_t* wq, const
     const char* op = "qspec_gate_up_silu_linear_w4a16";
     if (M == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
+    if (g_xp && !(use_stream() && qspec::gemm_w4a16_stream_supported(M, 2 * intermediate, K) && qspec::gemm_w4a16_xperm_supported(M, K)))
+        return fail("%s: no fragment-major form for (M=%d I=%d K=%d)", op, M, intermediate, K);
     if (use_stream() && qspec::gemm_w4a16_stream_supported(M, 2 * intermediate, K))
-        return finish(op, qspec::gemm_w4a16_stream_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, 0, intermediate, ST));
+        return finish(op, qspec::gemm_w4a16_stream_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, 0, intermediate, ST, g_xp));
     return finish(op, qspec::gemm_w4a16_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, 0, intermediate, workspace, ST));
+}
+int qspec_gate_up_silu_linear_w4a16_xp(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
+                                       int intermediate, int K, void* workspace, void* stream) {
+    XpScope xp;
+    return qspec_gate_up_silu_linear_w4a16(x, wq, ws, act, M, intermediate, K, workspace, stream);
 }
 
 int qspec_w4a16_linear_ksliced(const qspec_half* x, int64_t ldx, const int8_t* wq, int64_t ldw_bytes,
@@ -618,7 +686,13 @@ int qspec_w4a16_linear_partial(const qspec_half* x, const int8_t* wq, float* par
     const int planned = qspec::gemm_w4a16_stream_partial_slices(M, N, K);
     if (slices < 2 || slices > 8 || K % slices || (planned ? slices != planned : !qspec::gemm_w4a16_stream_supported(M, N, K / slices)))
         return fail("%s: (M=%d N=%d K=%d) takes %d slices (qspec_w4a16_linear_partial_slices), got %d", op, M, N, K, planned, slices);
-    return finish(op, qspec::gemm_w4a16_stream_partial(CH(x), 0, wq, 0, part, M, N, K, slices, ST));
+    if (g_xp && !qspec::gemm_w4a16_xperm_supported(M, K / slices)) return fail("%s: no fragment-major form for slices of %d", op, K / slices);
+    return finish(op, qspec::gemm_w4a16_stream_partial(CH(x), 0, wq, 0, part, M, N, K, slices, ST, g_xp));
+}
+int qspec_w4a16_linear_partial_xp(const qspec_half* x, const int8_t* wq, float* part, int M, int N, int K, int slices,
+                                  void* stream) {
+    XpScope xp;
+    return qspec_w4a16_linear_partial(x, wq, part, M, N, K, slices, stream);
 }
 int qspec_add_rms_norm_fp16_partial(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const float* part,
                                     const qspec_half* ws, int slices, float eps, int tokens, int hidden, void* stream) {
@@ -628,7 +702,13 @@ int qspec_add_rms_norm_fp16_partial(qspec_half* out, qspec_half* hidden_out, con
     NONNULL(op, out); NONNULL(op, x); NONNULL(op, part); NONNULL(op, ws); NONNULL(op, hidden_out);
     if (slices < 1) return fail("%s: slices < 1", op);
     if (hidden % 1024 || hidden > 8192 || hidden <= 0) return fail("%s: hidden=%d must be a multiple of 1024, <= 8192", op, hidden);
-    return finish(op, qspec::ln_fp16_partial(CH(x), part, CH(ws), slices, H(hidden_out), H(out), eps, tokens, hidden, ST));
+    if (g_xp && tokens > 16) return fail("%s: the fragment-major layout is a 16-row tile (tokens=%d)", op, tokens);
+    return finish(op, qspec::ln_fp16_partial(CH(x), part, CH(ws), slices, H(hidden_out), H(out), eps, tokens, hidden, ST, g_xp));
+}
+int qspec_add_rms_norm_fp16_partial_xp(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const float* part,
+                                       const qspec_half* ws, int slices, float eps, int tokens, int hidden, void* stream) {
+    XpScope xp;
+    return qspec_add_rms_norm_fp16_partial(out, hidden_out, x, part, ws, slices, eps, tokens, hidden, stream);
 }
 int qspec_rowwise_scaled_linear_s4s4_partial_slices(int M, int N, int K) { return qspec::gemm_w4a4_stream_partial_slices(M, N, K); }
 int qspec_rowwise_scaled_linear_s4s4_partial(const int8_t* xq, const int8_t* wq, int32_t* ipart, int M, int N, int K, int slices,

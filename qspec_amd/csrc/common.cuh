@@ -7,6 +7,17 @@
 
 namespace qspec {
 
+// FRAGMENT-MAJOR layout of a 16-row fp16 activation tile [16, K] (K % 128 == 0), the layout the W4A16 streaming kernel's
+// MFMA fragments have (gemm_stream.hip, XP): [K / 128 steps][4 dwords][4 k-groups][16 rows][8 halves in the dequantiser's
+// order 0,4,1,5,2,6,3,7].  A wave then takes a fragment with ONE fully coalesced 1-KiB load instead of the workgroup copying
+// the tile through LDS.  Offset (in halves) of element (row r < 16, column k):
+__host__ __device__ __forceinline__ size_t w4a16_xperm_offset(int r, int k) {
+    const int kstep = k >> 7, rem = k & 127, g = rem >> 5, dd = (rem >> 3) & 3, e = k & 7;
+    const int pos = ((e & 3) << 1) | (e >> 2);           // 0,1,2,3,4,5,6,7 -> 0,2,4,6,1,3,5,7
+    return ((((size_t)kstep * 4 + dd) * 64 + g * 16 + r) << 3) + pos;
+}
+
+
 typedef _Float16 f16;
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));

@@ -76,6 +76,7 @@ struct StreamArgs {
     int64_t ldx, ldw;       // W4A16: activation row stride (halves) / packed weight row stride (bytes); 0 = dense
     int tile0;              // W4A16: first tile of the launch (column-parallel shards)
     float* part;            // W4A16 SEPI_PARTIAL: [gridDim.y][M][N] raw fp32 sums of K slice blockIdx.y (K = slice length)
+    int xperm;              // W4A16: x is the 16-row activation tile in fragment-major layout (w4a16_xperm_offset)
     int* ipart;             // W4A4 SEPI_IPART: [gridDim.y][M][N] raw int32 sums of K slice blockIdx.y (ldx / ldw = row strides in BYTES)
     const uint8_t* wq;      // [N, K/2]
     const f16* ws;          // [N]
@@ -1238,7 +1239,10 @@ __device__ __forceinline__ f16x8 sshuffle_act8(u32x4 a) {  // 8 consecutive fp16
     return __builtin_bit_cast(f16x8, o);
 }
 
-template <int EPI, int NW, int UB>
+// XP: the activations arrive in FRAGMENT-MAJOR layout (a.x = the 16-row tile as [K / 128 steps][4 dwords][4 k-groups][16 rows][8
+// halves, dequantiser order]: w4a16_xperm_offset) -- what this kernel's MFMA fragments are -- so a wave takes its fragments
+// straight from memory with fully coalesced 1-KiB loads: no LDS staging pass, no barrier in front of the first MFMA.
+template <int EPI, int NW, int UB, bool XP = false>
 __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1311,8 +1315,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
             *reinterpret_cast<u32x4*>(buf + (size_t)row * SBMAX + ((q ^ row) << 4)) = src[i];
         }
     };
-    stage_load(areg[0], 0);
-    if (NST > 1) stage_load(areg[1], 1);
+    f16x8 af[UB][4];
+    if constexpr (XP) {
+        const f16* xp = a.x + (kofs >> 7) * 2048 + (size_t)lane * 8;     // (step, dword) blocks of 64 lanes x 8 halves
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int kstep = step_off<NW, UB>(wave, u) >> 6;            // this wave's step u = K step kstep of the row
+#pragma unroll
+            for (int dd = 0; dd < 4; dd++) af[u][dd] = *reinterpret_cast<const f16x8*>(xp + ((size_t)kstep * 4 + dd) * 512);
+        }
+    } else {
+        stage_load(areg[0], 0);
+        if (NST > 1) stage_load(areg[1], 1);
+    }
     int tile = a.tile0 + blockIdx.x, par = 0;
     const int tile_end = a.tile0 + a.ntiles;
     const int my_tiles = (tile_end - tile + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -1326,7 +1341,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
         load_pre(pre, tile);
     }
     __builtin_amdgcn_sched_barrier(0);
-    f16x8 af[UB][4];
+    if constexpr (!XP)
 #pragma unroll
     for (int st_ = 0; st_ < NST; st_++) {
         stage_store(areg[st_ & 1], st_);
@@ -2046,6 +2061,15 @@ static int launch_stream16_inst(const StreamArgs& a, hipStream_t st) {
             grid = (a.ntiles + per - 1) / per;
         }
     }
+    static const int xp_timing = QS_DEV_KNOB("QSPEC_W4A16_XP_TIMING", 0);   // (timing probe: the plain buffer read as if permuted)
+    if constexpr ((NW == 8 && (UB == 4 || UB == 5)) || (NW == 4 && (UB == 7 || UB == 9))) {   // the Llama-3-8B / Llama-2-13B shapes
+        if (a.xperm || xp_timing) {
+            hipLaunchKernelGGL((gemm_w4a16_stream_kernel<EPI, NW, UB, true>), dim3(grid, slices), dim3(NW * 64),
+                               (size_t)2 * NW * 1024 + 1024, st, a);
+            return 0;
+        }
+    }
+    if (a.xperm) return -1;
     hipLaunchKernelGGL((gemm_w4a16_stream_kernel<EPI, NW, UB>), dim3(grid, slices), dim3(NW * 64), lds, st, a);
     return 0;
 }
@@ -2082,11 +2106,19 @@ static int launch_stream16(const StreamArgs& a, hipStream_t st) {
     return -1;
 }
 
+// xperm (every entry below): x is the 16-row activation tile in fragment-major layout (common.cuh: w4a16_xperm_offset; the
+// producers write it: norm_quant.hip ln_kernel, hadamard.hip spread forms) -- built for the shapes gemm_w4a16_xperm_supported names
+bool gemm_w4a16_xperm_supported(int M, int K) {
+    int NW, UB;
+    if (M < 1 || M > 16 || !stream16_shape(K, &NW, &UB)) return false;
+    return (NW == 8 && (UB == 4 || UB == 5)) || (NW == 4 && (UB == 7 || UB == 9));   // K = 4096 / 5120 / 3584 / 4608
+}
 int gemm_w4a16_stream(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, const f16* ws, f16* out, int M, int N,
-                      int K, hipStream_t st) {
+                      int K, hipStream_t st, int xperm) {
     if (!gemm_w4a16_stream_supported(M, N, K) || (ldx && ldx % 8) || (ldw && ldw % 16)) return -1;
+    if (xperm && (ldx || !gemm_w4a16_xperm_supported(M, K))) return -1;
     StreamArgs a{};
-    a.x = x; a.ldx = ldx; a.ldw = ldw; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = out;
+    a.x = x; a.ldx = ldx; a.ldw = ldw; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = out; a.xperm = xperm;
     a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
     return launch_stream16<SEPI_PLAIN>(a, st);
 }
@@ -2108,9 +2140,11 @@ int gemm_w4a16_stream_partial_slices(int M, int N, int K) {
     return 0;
 }
 int gemm_w4a16_stream_partial(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, float* part, int M, int N, int K,
-                              int S, hipStream_t st) {
+                              int S, hipStream_t st, int xperm) {
     if (S < 1 || K % S || !gemm_w4a16_stream_supported(M, N, K / S) || !part) return -1;
+    if (xperm && (ldx || (K / S) % 128 || !gemm_w4a16_xperm_supported(M, K / S))) return -1;
     StreamArgs a{};
+    a.xperm = xperm;
     a.x = x; a.ldx = ldx ? ldx : K; a.ldw = ldw ? ldw : K / 2; a.wq = reinterpret_cast<const uint8_t*>(wq);
     a.M = M; a.N = N; a.K = K / S; a.ntiles = N / 16; a.part = part; a.nq = S;
     return launch_stream16<SEPI_PARTIAL>(a, st);
@@ -2137,9 +2171,11 @@ static int qkv_level_workgroups(int nq, int nkv, int N) {
 
 int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                                const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
-                               const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st) {
+                               const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st, int xperm) {
     if (d != 128 || rot_dim != 128 || N != (nq + 2 * nkv) * 128 || !gemm_w4a16_stream_supported(M, N, K)) return -1;
+    if (xperm && !gemm_w4a16_xperm_supported(M, K)) return -1;
     StreamArgs a{};
+    a.xperm = xperm;
     a.x = x; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = qkv; a.M = M; a.N = N; a.K = K;
     a.ntiles = N / 16; a.positions = positions; a.cos_sin_cache = cos_sin_cache; a.key_cache = key_cache;
     a.value_cache = value_cache; a.slot_mapping = slot_mapping; a.nq = nq; a.nkv = nkv;
@@ -2153,9 +2189,11 @@ int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f1
 }
 
 int gemm_w4a16_stream_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K, int ch0,
-                                   int nch, hipStream_t st) {
+                                   int nch, hipStream_t st, int xperm) {
     if (I % 8 || ch0 % 8 || nch % 8 || ch0 + nch > I || !gemm_w4a16_stream_supported(M, 2 * I, K)) return -1;
+    if (xperm && !gemm_w4a16_xperm_supported(M, K)) return -1;
     StreamArgs a{};
+    a.xperm = xperm;
     a.x = x; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = act; a.M = M; a.N = 2 * I; a.K = K;
     a.I = I; a.tile0 = ch0 / 8; a.ntiles = nch / 8;
     return launch_stream16<SEPI_GATEUP>(a, st);

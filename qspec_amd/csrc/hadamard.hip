@@ -487,7 +487,7 @@ template <bool AMAX>
 __global__ __launch_bounds__(512) void heads_hadamard_merge_spread32_kernel(const float* __restrict__ ws_o,
                                                                              const float* __restrict__ ws_ml, int S,
                                                                              f16* __restrict__ out16, float had_scale,
-                                                                             float* __restrict__ part_amax) {
+                                                                             float* __restrict__ part_amax, int xp = 0) {
     constexpr int NH = 32, D = 128, SMAX = 8;
     __shared__ float xl[NH][16];
     __shared__ float red8[8];
@@ -546,7 +546,12 @@ __global__ __launch_bounds__(512) void heads_hadamard_merge_spread32_kernel(cons
 #pragma unroll
     for (int j = 1; j < 8; j++) r = w == j ? x[j] : r;
     const f16 y = f2h(r * had_scale);
-    out16[(size_t)t * NH * D + (size_t)head * D + d] = y;
+    if (xp) {   // verify pass: the o_proj launch's fragment-major layout (T <= 16): k and k + 4 are neighbours there
+        const f16 y4 = f2h(dpp_xor<4>(h2f(y)));
+        if (!(col & 4)) *reinterpret_cast<f16x2*>(out16 + w4a16_xperm_offset(t, head * D + d)) = f16x2{y, y4};
+    } else {
+        out16[(size_t)t * NH * D + (size_t)head * D + d] = y;
+    }
     if (AMAX) {
         const float am = wave_max_uniform(__builtin_fabsf(h2f(y)));
         if (lane == 0) red8[w] = am;
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(1024) void heads_hadamard_mix_merge_spread_kernel(c
                                                                                 const f16* __restrict__ hadK,
                                                                                 f16* __restrict__ out16, float had_scale,
                                                                                 float* __restrict__ part_amax, int heads,
-                                                                                int K) {
+                                                                                int K, int xp = 0) {
     constexpr int D = 128, SMAX = 8;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* yl = reinterpret_cast<float*>(smem_raw);          // [heads][16]
@@ -630,7 +635,12 @@ __global__ __launch_bounds__(1024) void heads_hadamard_mix_merge_spread_kernel(c
     float acc = 0.0f;
     for (int k = 0; k < K; k++) acc = __builtin_fmaf(hrow[k], yl[(k * P + pp) * 16 + col], acc);   // = heads_hadamard_mix_kernel
     const f16 y = f2h(acc);
-    if (act) out16[(size_t)t * heads * D + (size_t)head * D + d] = y;
+    if (xp) {   // (k, k + 4) pairs, as in heads_hadamard_merge_spread32_kernel; heads in whole 16-lane groups
+        const f16 y4 = f2h(dpp_xor<4>(h2f(y)));
+        if (act && !(col & 4)) *reinterpret_cast<f16x2*>(out16 + w4a16_xperm_offset(t, head * D + d)) = f16x2{y, y4};
+    } else if (act) {
+        out16[(size_t)t * heads * D + (size_t)head * D + d] = y;
+    }
     if (AMAX) {
         const float am = wave_max_f(act ? __builtin_fabsf(h2f(y)) : 0.0f);
         if (lane == 0) red[w] = am;
@@ -651,8 +661,9 @@ bool heads_hadamard_mix_merge_spread_supported(int T, int heads, int d, int K) {
 }
 // fp16 rows + (part_amax != nullptr) 8 partial row maxima per token
 int heads_hadamard_mix_merge_spread(const float* ws, int max_tokens, int n_splits, const f16* hadK, f16* out_f16,
-                                    float* part_amax, float had_scale, int T, int heads, int d, int K, hipStream_t st) {
+                                    float* part_amax, float had_scale, int T, int heads, int d, int K, hipStream_t st, int xp) {
     if (T == 0) return 0;
+    if (xp && (part_amax != nullptr || T > 16)) return -1;
     if (!heads_hadamard_mix_merge_spread_supported(T, heads, d, K) || n_splits < 1 || T > max_tokens) return -1;
     const float* ws_o = ws + paged_attention_ws_o_offset();
     const float* ws_ml = ws + paged_attention_ws_ml_offset(max_tokens, heads, d, n_splits);
@@ -660,17 +671,18 @@ int heads_hadamard_mix_merge_spread(const float* ws, int max_tokens, int n_split
     const size_t lds = ((size_t)heads * 16 + (size_t)K * K + 16) * sizeof(float);
     if (part_amax)
         hipLaunchKernelGGL(heads_hadamard_mix_merge_spread_kernel<true>, dim3(T, 8), dim3(threads), lds, st, ws_o, ws_ml,
-                           n_splits, hadK, out_f16, had_scale, part_amax, heads, K);
+                           n_splits, hadK, out_f16, had_scale, part_amax, heads, K, 0);
     else
         hipLaunchKernelGGL(heads_hadamard_mix_merge_spread_kernel<false>, dim3(T, 8), dim3(threads), lds, st, ws_o, ws_ml,
-                           n_splits, hadK, out_f16, had_scale, part_amax, heads, K);
+                           n_splits, hadK, out_f16, had_scale, part_amax, heads, K, xp);
     return 0;
 }
 
 // partials: the workspace of paged_attention(..., out = nullptr) called for `max_tokens` = n_seqs * max_q_len tokens
 int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out_f16, int8_t* q, f16* scale,
-                         float had_scale, float clip, int T, int heads, int d, hipStream_t st) {
+                         float had_scale, float clip, int T, int heads, int d, hipStream_t st, int xp) {
     if (T == 0) return 0;
+    if (xp && (q != nullptr || heads != 32 || T > 16)) return -1;   // fragment-major fp16 rows: the spread 32-head form only
     if (d != 128 || !(heads == 32 || heads == 64) || n_splits < 1 || T > max_tokens) return -1;
     const float* ws_o = ws + paged_attention_ws_o_offset();
     const float* ws_ml = ws + paged_attention_ws_ml_offset(max_tokens, heads, d, n_splits);
@@ -678,9 +690,10 @@ int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out
     static const int spread = QS_DEV_KNOB("QSPEC_HHM_SPREAD", 1);   // (0: one workgroup per token also for the fp16 form)
     if (!quant && heads == 32 && spread && T * 8 <= 1024) {
         hipLaunchKernelGGL(heads_hadamard_merge_spread32_kernel<false>, dim3(T, 8), dim3(512), 0, st, ws_o, ws_ml, n_splits,
-                           out_f16, had_scale, (float*)nullptr);
+                           out_f16, had_scale, (float*)nullptr, xp);
         return 0;
     }
+    if (xp) return -1;
 #define QS_HHM(NHV)                                                                                                \
     if (heads == NHV) {                                                                                             \
         if (quant)                                                                                                  \
@@ -838,7 +851,7 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
                                                                             f16* __restrict__ out16,
                                                                             int8_t* __restrict__ q,
                                                                             f16* __restrict__ scale, float had_scale,
-                                                                            float clip, int I, int K, uint32_t* xws) {
+                                                                            float clip, int I, int K, uint32_t* xws, int xp = 0) {
     constexpr bool pre_activated = PREACT;   // the input is already g = silu(gate)*up, [T, I] (gate_up GEMM epilogue)
     constexpr int P = PW, CHUNK = EPL * 64;   // row length of the transform; elements per wave trip of phase A
     static_assert(CHUNK % P == 0 && P >= EPL, "a wave trip covers whole rows");
@@ -971,7 +984,7 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         constexpr int CB = P / NB, PAIRS = CB / 2;            // this workgroup's columns of every row
         constexpr int ITEMS = KH * PAIRS;                     // (row, column pair) items, one per thread
-        static_assert(ITEMS <= NT, "one item per thread");
+        static_assert(ITEMS <= NT && PAIRS % 4 == 0, "one item per thread; four lanes = one 8-element group (xp stores)");
         const int b = blockIdx.x % NB;
         const int row = tid / PAIRS, jp = tid % PAIRS;
         const bool active = tid < ITEMS;
@@ -997,7 +1010,18 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
         const f16x2 zz = {f2h(a[0]), f2h(a[1])};
         const size_t e0 = (size_t)row * P + b * CB + 2 * jp;  // element index inside the token's row of I
         if (q == nullptr) {
-            if (active) *reinterpret_cast<f16x2*>(out16 + (size_t)t * I + e0) = zz;
+            if (xp) {
+                // verify pass: down_proj's fragment-major layout (T <= 16).  Four lanes hold the 8 elements of one 16-byte
+                // group as (0,1) (2,3) (4,5) (6,7); the layout wants (0,4) (1,5) (2,6) (3,7): lane j takes element j from
+                // lane j / 2 and element j + 4 from lane 2 + j / 2 (quad permutes), then stores one dword
+                const int mine = __builtin_bit_cast(int, zz), j = lane & 3;
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, mine, 0x50, 0xF, 0xF, false);   // quad_perm:[0,0,1,1]
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, mine, 0xFA, 0xF, 0xF, false);   // quad_perm:[2,2,3,3]
+                const uint32_t pair = (j & 1) ? ((lo >> 16) | (hi & 0xFFFF0000u)) : ((lo & 0xFFFFu) | (hi << 16));
+                if (active) *reinterpret_cast<uint32_t*>(out16 + w4a16_xperm_offset(t, (int)e0 - 2 * j) + 2 * j) = pair;
+            } else if (active) {
+                *reinterpret_cast<f16x2*>(out16 + (size_t)t * I + e0) = zz;
+            }
             return;
         }
         float amax = active ? fmaxf(__builtin_fabsf(h2f(zz[0])), __builtin_fabsf(h2f(zz[1]))) : 0.0f;
@@ -1191,8 +1215,15 @@ static int smh_spread(int T, int P, int K, int pre_activated, const void* xws) {
     return T * nb <= 256 ? nb : 1;     // every workgroup of a token resident: at most one workgroup per CU
 }
 
+// the forms that can write the fragment-major tile: the spread ones (a workspace is given), at most 16 tokens
+bool mlp_hadamard_xperm_supported(int T, int I, int K) {
+    if (T < 1 || T > 16 || K < 1 || I % K) return false;
+    static const int dummy = 0;
+    return smh_spread(T, I / K, K, 1, &dummy) > 1;
+}
+
 int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,
-                      float clip, int T, int I, int K, int pre_activated, void* xws, hipStream_t st) {
+                      float clip, int T, int I, int K, int pre_activated, void* xws, hipStream_t st, int xp) {
     if (T == 0) return 0;
     if (K < 1 || K > 172 || I % K) return -1;
     const int P = I / K;
@@ -1206,7 +1237,7 @@ int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t*
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&silu_mul_hadamard_kernel<EPLV, 28, true, NBV>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
         hipLaunchKernelGGL((silu_mul_hadamard_kernel<EPLV, 28, true, NBV>), dim3(T * NBV), dim3(QS_SMH_THREADS), lds, st, \
-                           gate_up, hadK, out_f16, q, scale, had_scale, clip, I, K, reinterpret_cast<uint32_t*>(xws)); \
+                           gate_up, hadK, out_f16, q, scale, had_scale, clip, I, K, reinterpret_cast<uint32_t*>(xws), xp); \
         return 0;                                                                                                \
     }
     QS_SMH_SPREAD(8, 8) QS_SMH_SPREAD(16, 16)
@@ -1217,11 +1248,12 @@ int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t*
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&silu_mul_hadamard_kernel<8, 108, true, NBV, 128>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
         hipLaunchKernelGGL((silu_mul_hadamard_kernel<8, 108, true, NBV, 128>), dim3(T * NBV), dim3(QS_SMH_THREADS), lds, st, \
-                           gate_up, hadK, out_f16, q, scale, had_scale, clip, I, K, reinterpret_cast<uint32_t*>(xws)); \
+                           gate_up, hadK, out_f16, q, scale, had_scale, clip, I, K, reinterpret_cast<uint32_t*>(xws), xp); \
         return 0;                                                                                                \
     }
     QS_SMH_108(8) QS_SMH_108(16)
 #undef QS_SMH_108
+    if (xp) return -1;   // the fragment-major fp16 output exists in the spread forms only
 #define QS_SMH2(EPLV, KHV)                                                                                      \
     {                                                                                                            \
         if (pre_activated) QS_SMH3(EPLV, KHV, true)                                                              \

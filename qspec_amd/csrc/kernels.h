@@ -20,12 +20,12 @@ typedef _Float16 f16;
 // norm_quant.hip
 int ln_quant_i4(const f16* x, const f16* delta, f16* hidden_out, int8_t* q, f16* scale, f16* isum, float eps, int T,
                 int H, hipStream_t st);
-int ln_fp16(const f16* x, const f16* delta, f16* hidden_out, f16* out, float eps, int T, int H, hipStream_t st);
+int ln_fp16(const f16* x, const f16* delta, f16* hidden_out, f16* out, float eps, int T, int H, hipStream_t st, int xp = 0);
 // delta = h((part[0] + ... + part[S-1])[t, :] * f(ws[:])): the K-sliced W4A16 projection finished inside the norm
 int ln_ipartial(const f16* x, const int* ipart, const f16* xs, const f16* ws, int S, f16* hidden_out, f16* out, int8_t* q,
                 f16* scale, float eps, int T, int H, hipStream_t st);
 int ln_fp16_partial(const f16* x, const float* part, const f16* ws, int S, f16* hidden_out, f16* out, float eps, int T,
-                    int H, hipStream_t st);
+                    int H, hipStream_t st, int xp = 0);
 int rowabsmax_quant(const f16* x, f16* scale, int8_t* q, float clip, int T, int K, hipStream_t st);
 
 // hadamard.hip
@@ -36,10 +36,11 @@ int heads_hadamard(const f16* attn, f16* out_f16, int8_t* q, f16* scale, float h
 int heads_hadamard_mix(const f16* attn, const f16* hadK, f16* out, float had_scale, int T, int heads, int d, int K,
                        hipStream_t st);
 int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out_f16, int8_t* q, f16* scale,
-                         float had_scale, float clip, int T, int heads, int d, hipStream_t st);
+                         float had_scale, float clip, int T, int heads, int d, hipStream_t st, int xp = 0);
 int silu_mul(const f16* gate_up, f16* out, int T, int I, hipStream_t st);
+bool mlp_hadamard_xperm_supported(int T, int I, int K);
 int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,
-                      float clip, int T, int I, int K, int pre_activated, void* xws, hipStream_t st);
+                      float clip, int T, int I, int K, int pre_activated, void* xws, hipStream_t st, int xp = 0);
 size_t xwg_workspace_bytes();
 
 // gemm.hip
@@ -91,7 +92,7 @@ bool gemm_w4a4_stream_residual_hq_supported(int M, int N, int K, int nparts);
 int gemm_w4a4_stream_partial_slices(int M, int N, int K);
 int gemm_w4a4_stream_partial(const int8_t* xq, const int8_t* wq, int* ipart, int M, int N, int K, int S, hipStream_t st);
 int heads_hadamard_mix_merge_spread(const float* ws, int max_tokens, int n_splits, const f16* hadK, f16* out_f16,
-                                    float* part_amax, float had_scale, int T, int heads, int d, int K, hipStream_t st);
+                                    float* part_amax, float had_scale, int T, int heads, int d, int K, hipStream_t st, int xp = 0);
 bool heads_hadamard_mix_merge_spread_supported(int T, int heads, int d, int K);
 int heads_hadamard_merge_spread(const float* ws, int max_tokens, int n_splits, f16* out_f16, float* part_amax, float had_scale,
                                 int T, int heads, int d, hipStream_t st);
@@ -103,17 +104,18 @@ int gemm_w4a4_stream_gate_up_silu(const StreamActs& x, const int8_t* wq, const f
 
 // W4A16 on the same streaming skeleton (M <= 16, K = 128 * NW * UB for a built (NW, UB))
 bool gemm_w4a16_stream_supported(int M, int N, int K);
+bool gemm_w4a16_xperm_supported(int M, int K);
 int gemm_w4a16_stream(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, const f16* ws, f16* out, int M, int N,
-                      int K, hipStream_t st);
+                      int K, hipStream_t st, int xperm = 0);
 int gemm_w4a16_stream_partial_slices(int M, int N, int K);
 int gemm_w4a16_stream_partial(const f16* x, int64_t ldx, const int8_t* wq, int64_t ldw, float* part, int M, int N, int K,
-                              int S, hipStream_t st);
+                              int S, hipStream_t st, int xperm = 0);
 int gemm_w4a16_partial_finish(const float* part, const f16* ws, f16* out, int M, int N, int S, hipStream_t st);
 int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                                const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
-                               const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st);
+                               const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st, int xperm = 0);
 int gemm_w4a16_stream_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K, int ch0,
-                                   int nch, hipStream_t st);
+                                   int nch, hipStream_t st, int xperm = 0);
 
 // gemm_tiled.hip: W4A16 for prefill-sized M (tiles of 32..128 tokens x 128 weight rows, 32x32x16 MFMA)
 bool gemm_w4a16_tiled_supported(int M, int N, int K);

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
                                                  f16* __restrict__ input_sum, float eps, int H,
                                                  const float* __restrict__ part = nullptr,
                                                  const f16* __restrict__ pws = nullptr, int S = 0, size_t pstride = 0,
-                                                 const int* __restrict__ ipart = nullptr, const f16* __restrict__ pxs = nullptr) {
+                                                 const int* __restrict__ ipart = nullptr, const f16* __restrict__ pxs = nullptr,
+                                                 int xp = 0 /* MODE 1: `out` in the W4A16 fragment-major layout (T <= 16) */) {
     __shared__ __attribute__((aligned(16))) float red_all[4][32];   // one region per reduction: no barrier in front
     float* red = red_all[0];
     const int row = blockIdx.x, j = threadIdx.x;
@@ -181,7 +182,20 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
             f16x4 o;
 #pragma unroll
             for (int c = 0; c < 4; c++) o[c] = f2h((v[it][c] - mean) * rstd);
-            *reinterpret_cast<f16x4*>(out + (size_t)row * H + it * 1024 + 4 * j) = o;
+            if (xp) {
+                // thread j holds elements e = 4 (j & 1) .. + 3 of the 8-half group j / 2 of this trip; the group is stored in
+                // the order e0 e4 e1 e5 | e2 e6 e3 e7: the even thread writes the first four, the odd one the last four,
+                // after swapping two halves each with its neighbour (lane ^ 1)
+                const u32 lo = __builtin_bit_cast(u32, f16x2{o[0], o[1]}), hi = __builtin_bit_cast(u32, f16x2{o[2], o[3]});
+                const bool odd = j & 1;
+                const u32 got = (u32)__shfl_xor((int)(odd ? lo : hi), 1, 64);       // even gets the partner's (e4, e5); odd (e2, e3)
+                const f16x2 mine = __builtin_bit_cast(f16x2, odd ? hi : lo), other = __builtin_bit_cast(f16x2, got);
+                const f16x4 w4 = odd ? f16x4{other[0], mine[0], other[1], mine[1]} : f16x4{mine[0], other[0], mine[1], other[1]};
+                const int k0 = it * 1024 + 8 * (j >> 1);
+                *reinterpret_cast<f16x4*>(out + w4a16_xperm_offset(row, k0) + 4 * (j & 1)) = w4;
+            } else {
+                *reinterpret_cast<f16x4*>(out + (size_t)row * H + it * 1024 + 4 * j) = o;
+            }
         }
         return;
     }
@@ -227,12 +241,14 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
 
 template <int MODE>
 static int launch_ln(const f16* x, const f16* delta, f16* hidden_out, f16* out, int8_t* q, f16* scale, f16* isum,
-                     float eps, int T, int H, hipStream_t st) {
+                     float eps, int T, int H, hipStream_t st, int xp = 0) {
     if (T == 0) return 0;
+    if (xp && (MODE != 1 || T > 16 || H % 128)) return -1;
 #define QS_LN_CASE(NI)                                                                                        \
     case NI:                                                                                                  \
         hipLaunchKernelGGL((ln_kernel<NI, MODE>), dim3(T), dim3(256), 0, st, x, delta, hidden_out, out, q, scale, \
-                           isum, eps, H);                                                                     \
+                           isum, eps, H, (const float*)nullptr, (const f16*)nullptr, 0, (size_t)0, (const int*)nullptr, \
+                           (const f16*)nullptr, xp);                                                          \
         break;
     switch (H / 1024) {
         QS_LN_CASE(1) QS_LN_CASE(2) QS_LN_CASE(3) QS_LN_CASE(4) QS_LN_CASE(5) QS_LN_CASE(6) QS_LN_CASE(7) QS_LN_CASE(8)
@@ -246,8 +262,8 @@ int ln_quant_i4(const f16* x, const f16* delta, f16* hidden_out, int8_t* q, f16*
                 int H, hipStream_t st) {
     return launch_ln<0>(x, delta, hidden_out, nullptr, q, scale, isum, eps, T, H, st);
 }
-int ln_fp16(const f16* x, const f16* delta, f16* hidden_out, f16* out, float eps, int T, int H, hipStream_t st) {
-    return launch_ln<1>(x, delta, hidden_out, out, nullptr, nullptr, nullptr, eps, T, H, st);
+int ln_fp16(const f16* x, const f16* delta, f16* hidden_out, f16* out, float eps, int T, int H, hipStream_t st, int xp) {
+    return launch_ln<1>(x, delta, hidden_out, out, nullptr, nullptr, nullptr, eps, T, H, st, xp);
 }
 // delta = the W4A4 projection whose S int32 K-slice sums are ipart [S][T][H] (activation scales xs [T], channel scales ws [H]);
 // q != nullptr: int4 output (the draft pass's next norm), else fp16 `out` (the final norm)
@@ -274,13 +290,15 @@ int ln_ipartial(const f16* x, const int* ipart, const f16* xs, const f16* ws, in
     return 0;
 }
 int ln_fp16_partial(const f16* x, const float* part, const f16* ws, int S, f16* hidden_out, f16* out, float eps, int T,
-                    int H, hipStream_t st) {
+                    int H, hipStream_t st, int xp) {
     if (T == 0) return 0;
     if (S < 1 || !part || !ws) return -1;
+    if (xp && (T > 16 || H % 128)) return -1;
 #define QS_LNP_CASE(NI)                                                                                              \
     case NI:                                                                                                         \
         hipLaunchKernelGGL((ln_kernel<NI, 1>), dim3(T), dim3(256), 0, st, x, (const f16*)nullptr, hidden_out, out,   \
-                           (int8_t*)nullptr, (f16*)nullptr, (f16*)nullptr, eps, H, part, ws, S, (size_t)T * H);     \
+                           (int8_t*)nullptr, (f16*)nullptr, (f16*)nullptr, eps, H, part, ws, S, (size_t)T * H,      \
+                           (const int*)nullptr, (const f16*)nullptr, xp);                                            \
         break;
     switch (H / 1024) {
         QS_LNP_CASE(1) QS_LNP_CASE(2) QS_LNP_CASE(3) QS_LNP_CASE(4) QS_LNP_CASE(5) QS_LNP_CASE(6) QS_LNP_CASE(7) QS_LNP_CASE(8)

@@ -100,6 +100,10 @@ class Scratch:
         self.logits = e(T if logits_rows is None else logits_rows, cfg.vocab_size)
         # verify pass: raw fp32 K-slice sums of down_proj, finished inside the next norm (ops.w4a16_linear_partial)
         self.down_part = e(4, T, H, dtype=torch.float32) if T <= 16 else None
+        # verify pass at <= 16 tokens: fragment-major 16-row activation tiles between the producers and the W4A16 GEMMs
+        # (ops.w4a16_act_layout_supported); rows past T are never read back into a result
+        z = lambda k: torch.zeros(16, k, dtype=f16, device=device)  # noqa: E731
+        self.xp_normed, self.xp_had, self.xp_had_mlp = (z(H), z(cfg.q_size), z(I)) if T <= 16 else (None, None, None)
         self.tp_part = e(1, min(T, 32), H, dtype=torch.float32)   # TP verify pass (T <= 32): fp32 row-parallel partials
         self.had_part_amax = e(min(T, 16), 8, dtype=torch.float32)  # draft pass (T <= 4): partial row maxima of the spread head Hadamard
         # draft pass at 17..32 tokens: int32 K-slice sums of down_proj + the activation scales they were computed with
@@ -176,26 +180,46 @@ class QuarotLlamaForCausalLM:
     # draft pass, T <= 4, 32 heads of 128: head Hadamard spread over 8 workgroups per token + the quantiser in o_proj's prologue
     HADAMARD_QUANT_IN_OPROJ = __import__("os").environ.get("QSPEC_HQ_OPROJ", "1") != "0"
 
-    def _w4a16(self, x, lin, out):
-        # every M reads the packed int4 buffer: streaming kernel (M <= 16), M-tiled kernel (prefill-sized M)
-        return ops.w4a16_linear(x, lin.weight, lin._scales(), out)
+    # verify pass at <= 16 tokens (one GPU): the norm / head transform / MLP transform store their fp16 rows as the
+    # FRAGMENT-MAJOR tile the W4A16 GEMMs' MFMA operands are loaded from (include/qspec_hip.h "activation layout"), which
+    # removes the LDS regrouping pass from the head of four launches per layer.  Same bits either way.
+    ACT_FRAGMENT_MAJOR = __import__("os").environ.get("QSPEC_ACT_FRAGMENT_MAJOR", "1") != "0"
 
-    def _add_norm_fp16(self, normed, hidden, delta, eps):
+    def _w4a16(self, x, lin, out, xp=False, tokens=None):
+        # every M reads the packed int4 buffer: streaming kernel (M <= 16), M-tiled kernel (prefill-sized M)
+        return ops.w4a16_linear(x, lin.weight, lin._scales(), out, xp=xp, tokens=tokens)
+
+    def _add_norm_fp16(self, normed, hidden, delta, eps, xp=False):
         """hidden += delta; normed = LN(hidden).  delta: fp16 tensor, None, or ("partial", part, w_scale, S) = the raw
-        K-slice sums of a long-K W4A16 down_proj, finished inside the norm kernel."""
+        K-slice sums of a long-K W4A16 down_proj, finished inside the norm kernel.  xp: normed is a fragment-major tile."""
         if isinstance(delta, tuple) and delta[0] == "ipartial":
             _, ipart, xs, w_scale, S = delta
             ops.add_rms_norm_ipartial(hidden, hidden, ipart, xs, w_scale, S, eps, out_f16=normed)
         elif isinstance(delta, tuple):
             _, part, w_scale, S = delta
-            ops.add_rms_norm_fp16_partial(normed, hidden, hidden, part, w_scale, S, eps)
+            ops.add_rms_norm_fp16_partial(normed, hidden, hidden, part, w_scale, S, eps, xp=xp)
         else:
-            ops.add_rms_norm_fp16(normed, hidden, hidden, delta, eps)
+            ops.add_rms_norm_fp16(normed, hidden, hidden, delta, eps, xp=xp)
+
+    def _fragment_major_ok(self, T, md, s):
+        """Every producer and consumer of the verify pass has its fragment-major form at this shape."""
+        cfg = self.config
+        H, I, nh, hd = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim
+        if not (self.ACT_FRAGMENT_MAJOR and s.xp_normed is not None and T <= 16 and self.MERGE_IN_HADAMARD
+                and self.VERIFY_O_SLICES <= 1 and hd == 128 and md.n_splits <= 64):
+            return False
+        S = ops.w4a16_linear_partial_slices(T, H, I) if s.down_part is not None else 0
+        down_k = I // S if 0 < S <= 4 else (I if S == 0 else 0)
+        heads_ok = (nh == 32 if self.head_had_K == 1 else
+                    ops.heads_hadamard_mix_merged_spread_supported(T, nh, hd, self.head_had_K))
+        return bool(down_k and heads_ok and ops.w4a16_act_layout_supported(T, H)
+                    and ops.w4a16_act_layout_supported(T, cfg.q_size) and ops.w4a16_act_layout_supported(T, down_k)
+                    and ops.mlp_hadamard_act_layout_supported(T, I, self.had_K))
 
     MERGE_IN_HADAMARD = True   # False: the attention kernel merges its context splits itself (ticket + fences)
     DOWN_K_SLICES = __import__("os").environ.get("QSPEC_DOWN_K_SLICES", "1") != "0"   # draft down_proj at 17..32 tokens as K slices
 
-    def _attention_hadamard(self, qkv, row, kc, vc, md, T, s, attn, q1, sc, had):
+    def _attention_hadamard(self, qkv, row, kc, vc, md, T, s, attn, q1, sc, had, xp=False):
         """Attention + head Hadamard (+ quant when q1 is given, else fp16 into `had`) (quarot_llama.py:213-238).
         For 32 / 64 heads of 128 the split merge of the attention kernel runs at the head of the Hadamard launch."""
         cfg = self.config
@@ -212,14 +236,14 @@ class QuarotLlamaForCausalLM:
             buf = had if had is not None else s.act_buffer_had[:T]
             if mix_merged:
                 ops.heads_hadamard_mix_merged_spread(s.attn_ws, B * md.max_q_len, md.n_splits, T, nh, cfg.head_dim, self.head_had,
-                                                     self.head_had_K, self.head_had_scale, buf)
+                                                     self.head_had_K, self.head_had_scale, buf, xp=xp)
             else:   # generic kernels: one workgroup per token
                 ops.heads_hadamard_mix(attn.view(T, nh, cfg.head_dim), self.head_had, self.head_had_K, self.head_had_scale, buf)
             if q1 is not None:
                 ops.fuse_sym_quant(buf, sc, q1)
         elif merged:
             ops.heads_hadamard_merged(s.attn_ws, B * md.max_q_len, md.n_splits, T, nh, cfg.head_dim,
-                                      self.head_had_scale, out_f16=had, q=q1, scale=sc)
+                                      self.head_had_scale, out_f16=had, q=q1, scale=sc, xp=xp)
         elif q1 is not None:
             ops.heads_hadamard(attn, self.head_had_scale, q=q1, scale=sc, heads=nh)
         else:
@@ -262,6 +286,9 @@ class QuarotLlamaForCausalLM:
                    ops.heads_hadamard_mix_merged_spread_supported(T, nh, hd, self.head_had_K))
               and ops.rowwise_scaled_linear_s4s4_residual_hq_supported(T, cfg.hidden_size, cfg.q_size))
         had16 = s.act_buffer_had[:T]
+        xp = not w4a4 and fuse and not tp_on and self._fragment_major_ok(T, md, s)
+        if xp:
+            normed_x, had_x = s.xp_normed, s.xp_had
         # draft pass at 17..32 tokens: down_proj as K slices (0 / 1 = the plain launch)
         S_down = (ops.rowwise_scaled_linear_s4s4_partial_slices(T, cfg.hidden_size, cfg.intermediate_size)
                   if (w4a4 and fuse and not ln_fused and s.down_ipart is not None and self.DOWN_K_SLICES) else 0)
@@ -304,12 +331,15 @@ class QuarotLlamaForCausalLM:
                 else:
                     ops.add_rms_norm_i4(q1, sc, hidden, hidden, delta, eps)
                 x, xs = q1, sc
+            elif xp:
+                self._add_norm_fp16(normed_x, hidden, delta, eps, xp=True)
+                x, xs = normed_x, None
             else:
                 self._add_norm_fp16(normed, hidden, delta, eps)
                 x, xs = normed, None
             if fuse:
                 ops.qkv_rope_linear(x, xs, qkv_w, qkv_s, qkv, positions, self.cos_sin_cache, kc, vc, md.slot_mapping,
-                                    nh, nkv, hd)
+                                    nh, nkv, hd, xp=xp, tokens=T)
             else:
                 if w4a4:
                     ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, qkv_w, qkv_s, None, qkv)
@@ -322,6 +352,11 @@ class QuarotLlamaForCausalLM:
                 ops.rowwise_scaled_linear_cutlass_s4s4_unified(q1, sc, layer.o_proj.weight, layer.o_proj._scales(), None, o)
                 ops.add_rms_norm_i4(q1, sc, hidden, hidden, o, eps)
                 x, xs = q1, sc
+            elif xp:
+                self._attention_hadamard(qkv, row, kc, vc, md, T, s, attn, None, None, had_x, xp=True)
+                self._w4a16(had_x, layer.o_proj, o, xp=True, tokens=T)
+                ops.add_rms_norm_fp16(normed_x, hidden, hidden, o, eps, xp=True)
+                x, xs = normed_x, None
             else:
                 self._attention_hadamard(qkv, row, kc, vc, md, T, s, attn, None, None, had)
                 if tp_on:   # row-parallel o_proj over this rank's K range of the shared buffer: raw fp32 sums,
@@ -350,10 +385,13 @@ class QuarotLlamaForCausalLM:
                     ops.gate_up_silu_linear_shard(x, gu_w, gu_s, act, c0, c1 - c0)
                     self.tp.all_gather_channels(act, cfg.intermediate_size)
                 else:
-                    ops.gate_up_silu_linear(x, xs, gu_w, gu_s, act)
+                    ops.gate_up_silu_linear(x, xs, gu_w, gu_s, act, xp=xp, tokens=T)
                 if w4a4:   # (K-sliced down_proj: its activation scales outlive the next norm's, so they get their own buffer)
                     ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, q=q3,
                                      scale=s.down_xs[:T] if S_down > 1 else sc)
+                elif xp:
+                    had_mlp_in = s.xp_had_mlp
+                    ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, out_f16=had_mlp_in, xp=True)
                 else:
                     had_mlp_in = s.act_buffer_gate_up.view(-1)[:T * cfg.intermediate_size].view(T, cfg.intermediate_size)
                     ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, out_f16=had_mlp_in)
@@ -385,10 +423,10 @@ class QuarotLlamaForCausalLM:
                     S = ops.w4a16_linear_partial_slices(T, cfg.hidden_size, cfg.intermediate_size)
                 if 0 < S <= 4:
                     part = s.down_part.view(-1)[:S * T * cfg.hidden_size].view(S, T, cfg.hidden_size)
-                    ops.w4a16_linear_partial(had_mlp_in, layer.down_proj.weight, part, S)
+                    ops.w4a16_linear_partial(had_mlp_in, layer.down_proj.weight, part, S, xp=xp, tokens=T)
                     delta = ("partial", part, layer.down_proj._scales(), S)
                     continue
-                self._w4a16(had_mlp_in, layer.down_proj, o)
+                self._w4a16(had_mlp_in, layer.down_proj, o, xp=xp, tokens=T)
             delta = o
         # final norm is always fp16, in both passes (self.norm(hidden_states) without kwargs, :533)
         self._add_norm_fp16(normed, hidden, delta, eps)

@@ -79,10 +79,30 @@ def add_rms_norm_i4(out_q, scaling, hidden_out, x, delta, eps: float):
           _stream())
 
 
-def add_rms_norm_fp16(out, hidden_out, x, delta, eps: float):
+def _xp_tile(t, name, K):
+    """A fragment-major activation tile always holds 16 rows (w4a16_act_layout_supported)."""
+    if t.numel() < 16 * K:
+        raise RuntimeError(f"{name}: a fragment-major tile is 16 x {K} halves, got {tuple(t.shape)}")
+    return t
+
+
+def w4a16_act_layout_supported(M: int, K: int) -> bool:
+    """True when the W4A16 GEMMs at (M <= 16 tokens, K) read the FRAGMENT-MAJOR activation tile the `xp=True` producers
+    write (norm, head transform, MLP transform): [K/128][4][4 k-groups][16 rows][8 halves], the order the MFMA operand
+    registers hold them, so the GEMM loads them straight from global memory with no LDS staging pass."""
+    return bool(_lib.load().qspec_w4a16_act_layout_supported(M, K))
+
+
+def mlp_hadamard_act_layout_supported(T: int, I: int, K: int) -> bool:
+    return XWG_SPREAD and bool(_lib.load().qspec_mlp_hadamard_act_layout_supported(T, I, K))
+
+
+def add_rms_norm_fp16(out, hidden_out, x, delta, eps: float, xp: bool = False):
     H = x.shape[-1]
     T = x.numel() // H
-    _call("qspec_add_rms_norm_fp16", _chk(out, "out", _F16), _opt(hidden_out, "hidden_out", _F16),
+    if xp:
+        _xp_tile(out, "out", H)
+    _call("qspec_add_rms_norm_fp16" + ("_xp" if xp else ""), _chk(out, "out", _F16), _opt(hidden_out, "hidden_out", _F16),
           _chk(x, "x", _F16), _opt(delta, "delta", _F16), float(eps), T, H, _stream())
 
 
@@ -182,11 +202,13 @@ def xwg_error_word(device):
 
 
 def mlp_hadamard(act, hadK, K: int, had_scale: float, out_f16=None, q=None, scale=None, clip_ratio: float = 1.0,
-                 workspace="auto"):
+                 workspace="auto", xp: bool = False):
     """Hadamard (+ quantiser) tail of silu_mul_hadamard on act = silu(gate)*up, [T, I]."""
     T, I = act.shape
     ws = xwg_workspace(act.device) if isinstance(workspace, str) else workspace
-    _call("qspec_mlp_hadamard", _chk(act, "act", _F16), _opt(hadK, "hadK", _F16), _opt(out_f16, "out_f16", _F16),
+    if xp:
+        _xp_tile(out_f16, "out_f16", I)
+    _call("qspec_mlp_hadamard" + ("_xp" if xp else ""), _chk(act, "act", _F16), _opt(hadK, "hadK", _F16), _opt(out_f16, "out_f16", _F16),
           _opt(q, "q", _I8), _opt(scale, "scale", _F16), float(had_scale), float(clip_ratio), T, I, K,
           None if ws is None else ws.data_ptr(), _stream())
 
@@ -194,12 +216,14 @@ def mlp_hadamard(act, hadK, K: int, had_scale: float, out_f16=None, q=None, scal
 # ------------------------------------------------------------------ linear
 
 def qkv_rope_linear(x, x_scale, wq, w_scale, qkv, positions, cos_sin_cache, key_cache, value_cache, slot_mapping,
-                    num_heads, num_kv_heads, head_size):
+                    num_heads, num_kv_heads, head_size, xp: bool = False, tokens=None):
     """qkv GEMM + rotary_embedding + reshape_and_cache_flash in one launch (quarot_llama.py:183-226).
     x_scale is None -> W4A16 (x fp16 [M,K]); else W4A4 (x packed int4 [M,K/2])."""
     N = wq.shape[0]
     K = wq.shape[1] * 2
-    M = x.shape[0]
+    M = x.shape[0] if tokens is None else tokens    # xp: x is the 16-row tile, tokens the rows in use
+    if xp:
+        _xp_tile(x, "x", K)
     common = (_chk(positions, "positions", _I64), _chk(cos_sin_cache, "cos_sin_cache", _F16),
               _chk(key_cache, "key_cache", _F16), _chk(value_cache, "value_cache", _F16),
               _chk(slot_mapping, "slot_mapping", _I64), num_heads, num_kv_heads, head_size, cos_sin_cache.shape[-1])
@@ -208,22 +232,24 @@ def qkv_rope_linear(x, x_scale, wq, w_scale, qkv, positions, cos_sin_cache, key_
               _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16), _chk(qkv, "qkv", _F16), M, N, K, *common,
               _stream())
     else:
-        _call("qspec_qkv_rope_linear_w4a16", _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)),
+        _call("qspec_qkv_rope_linear_w4a16" + ("_xp" if xp else ""), _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)),
               _chk(w_scale, "w_scale", _F16), _chk(qkv, "qkv", _F16), M, N, K, *common,
               w4a16_workspace(x.device).data_ptr(), _stream())
     return qkv
 
 
-def gate_up_silu_linear(x, x_scale, wq, w_scale, act):
+def gate_up_silu_linear(x, x_scale, wq, w_scale, act, xp: bool = False, tokens=None):
     """gate_up GEMM + silu(gate)*up in one launch (quarot_llama.py:276-284); act [M, I]."""
-    M = x.shape[0]
+    M = x.shape[0] if tokens is None else tokens
     I = wq.shape[0] // 2
     K = wq.shape[1] * 2
+    if xp:
+        _xp_tile(x, "x", K)
     if x_scale is not None:
         _call("qspec_gate_up_silu_linear_s4s4", _chk(x, "xq", (_I8, _U8)), _chk(x_scale, "x_scale", _F16),
               _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16), _chk(act, "act", _F16), M, I, K, _stream())
     else:
-        _call("qspec_gate_up_silu_linear_w4a16", _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)),
+        _call("qspec_gate_up_silu_linear_w4a16" + ("_xp" if xp else ""), _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)),
               _chk(w_scale, "w_scale", _F16), _chk(act, "act", _F16), M, I, K, w4a16_workspace(x.device).data_ptr(),
               _stream())
     return act
@@ -352,14 +378,17 @@ def w4a16_workspace(device):
     return _w16_ws[key]
 
 
-def w4a16_linear(x, wq, w_scale, out, bias=None):
+def w4a16_linear(x, wq, w_scale, out, bias=None, xp: bool = False, tokens=None):
     """bitblas.Matmul(x, w ^ 0x88, output=out, scale=w_scale, bias=bias) on the SAME packed buffer
     (quarot_nn/linear.py:122)."""
     M, K = x.shape
     N = wq.shape[0]
     if wq.shape[1] * 2 != K:
         raise RuntimeError(f"x and wq disagree on K: {x.shape} vs {wq.shape}")
-    _call("qspec_w4a16_linear", _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
+    if xp:
+        M = M if tokens is None else tokens
+        _xp_tile(x, "x", K)
+    _call("qspec_w4a16_linear" + ("_xp" if xp else ""), _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
           _opt(bias, "bias", _F16), _chk(out, "out", _F16), M, N, K, w4a16_workspace(x.device).data_ptr(), _stream())
     return out
 
@@ -369,20 +398,25 @@ def w4a16_linear_partial_slices(M: int, N: int, K: int) -> int:
     return int(_lib.load().qspec_w4a16_linear_partial_slices(M, N, K))
 
 
-def w4a16_linear_partial(x, wq, part, slices: int):
+def w4a16_linear_partial(x, wq, part, slices: int, xp: bool = False, tokens=None):
     """Raw fp32 K-slice sums of x @ dequant(wq)^T into part [slices, M, N] (finished by add_rms_norm_fp16_partial)."""
     M, K = x.shape
     N = wq.shape[0]
-    _call("qspec_w4a16_linear_partial", _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)), _chk(part, "part", _F32), M, N, K,
+    if xp:
+        M = M if tokens is None else tokens
+        _xp_tile(x, "x", K)
+    _call("qspec_w4a16_linear_partial" + ("_xp" if xp else ""), _chk(x, "x", _F16), _chk(wq, "wq", (_I8, _U8)), _chk(part, "part", _F32), M, N, K,
           slices, _stream())
     return part
 
 
-def add_rms_norm_fp16_partial(out, hidden_out, x, part, w_scale, slices: int, eps: float):
+def add_rms_norm_fp16_partial(out, hidden_out, x, part, w_scale, slices: int, eps: float, xp: bool = False):
     """hidden_out = x + h(sum_s part[s] * w_scale); out = LN(hidden_out) -- the finish of w4a16_linear_partial fused in."""
     H = x.shape[-1]
     T = x.numel() // H
-    _call("qspec_add_rms_norm_fp16_partial", _chk(out, "out", _F16), _chk(hidden_out, "hidden_out", _F16),
+    if xp:
+        _xp_tile(out, "out", H)
+    _call("qspec_add_rms_norm_fp16_partial" + ("_xp" if xp else ""), _chk(out, "out", _F16), _chk(hidden_out, "hidden_out", _F16),
           _chk(x, "x", _F16), _chk(part, "part", _F32), _chk(w_scale, "w_scale", _F16), slices, float(eps), T, H, _stream())
 
 
@@ -506,9 +540,11 @@ def paged_attention(q, q_stride, key_cache, value_cache, block_tables, ctx_lens,
 
 
 def heads_hadamard_merged(workspace, max_tokens, n_splits, tokens, heads, head_dim, had_scale: float, out_f16=None,
-                          q=None, scale=None, clip_ratio: float = 1.0):
+                          q=None, scale=None, clip_ratio: float = 1.0, xp: bool = False):
     """Split merge of paged_attention(..., out=None) + heads_hadamard in one launch."""
-    _call("qspec_heads_hadamard_merged", workspace.data_ptr(), max_tokens, n_splits, _opt(out_f16, "out_f16", _F16),
+    if xp:
+        _xp_tile(out_f16, "out_f16", heads * head_dim)
+    _call("qspec_heads_hadamard_merged" + ("_xp" if xp else ""), workspace.data_ptr(), max_tokens, n_splits, _opt(out_f16, "out_f16", _F16),
           _opt(q, "q", _I8), _opt(scale, "scale", _F16), float(had_scale), float(clip_ratio), tokens, heads, head_dim,
           _stream())
 
@@ -525,10 +561,12 @@ def heads_hadamard_merged_spread_supported(tokens: int, heads: int, head_dim: in
 
 
 def heads_hadamard_mix_merged_spread(workspace, max_tokens, n_splits, tokens, heads, head_dim, hadK, K: int, had_scale: float,
-                                     out_f16, part_amax=None):
+                                     out_f16, part_amax=None, xp: bool = False):
     """The spread merge + head transform for head counts with a table factor (40 heads = had40): fp16 rows, and with
     part_amax [tokens, 8] the partial row maxima for rowwise_scaled_linear_s4s4_residual_hq."""
-    _call("qspec_heads_hadamard_mix_merged_spread", workspace.data_ptr(), max_tokens, n_splits, _chk(hadK, "hadK", _F16), K,
+    if xp:
+        _xp_tile(out_f16, "out_f16", heads * head_dim)
+    _call("qspec_heads_hadamard_mix_merged_spread" + ("_xp" if xp else ""), workspace.data_ptr(), max_tokens, n_splits, _chk(hadK, "hadK", _F16), K,
           _chk(out_f16, "out_f16", _F16), _opt(part_amax, "part_amax", _F32), float(had_scale), tokens, heads, head_dim,
           _stream())
 

@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_load_binds_prototypes_and_reports_errors():
     lib = _lib.load()
-    assert lib.qspec_abi_version() == 5
+    assert lib.qspec_abi_version() == 6
     # argument validation happens before any HIP call, so it is testable without a GPU
     rc = lib.qspec_rms_norm_general_fuse_sum_fp16(None, None, 1e-5, 4, 4096, None)
     assert rc != 0 and b"NULL" in lib.qspec_last_error()

@@ -680,6 +680,33 @@ def test_model_family_layer_matches_oracle(oracle, family, w4a4):
         assert (out.float() - b.float()).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("family,ctx_lens,q_len", [("llama-3-8b", [40, 130, 9, 260], 4), ("llama-3-8b", [77], 4),
+                                                   ("llama-2-13b", [33, 150, 20], 4), ("llama-3-70b", [33, 150], 4)])
+def test_fragment_major_activation_tiles_change_no_bit(family, ctx_lens, q_len, monkeypatch):
+    """Verify pass at <= 16 tokens: norm / head transform / MLP transform storing fragment-major tiles and the W4A16 GEMMs
+    loading their operands straight from them (model.ACT_FRAGMENT_MAJOR) against the row-major buffers + LDS regrouping:
+    the normed hidden state and every KV slot bit for bit, two layers deep (the second norm takes the K-slice finish).
+    Llama-3-70B's K = 8192 has no tile form: the switch must then be inert."""
+    from qspec_amd.model import QuarotLlamaConfig, QuarotLlamaForCausalLM, Scratch
+    H, I, nh, nkv, theta = FAMILIES[family]
+    cfg = QuarotLlamaConfig(H, I, nh, nkv, 2, 1024, 1e-5, theta, 512, family + "-2layer")
+    model = QuarotLlamaForCausalLM(cfg, DEV).init_synthetic(seed=5, lm_head_std=0.05)
+    rng = np.random.default_rng(6)
+    inp = make_inputs(model, rng, ctx_lens, q_len)
+    s = Scratch(cfg, inp["T"], len(ctx_lens), q_len, inp["n_splits"], DEV)
+    assert model._fragment_major_ok(inp["T"], inp["md"], s) == (family != "llama-3-70b")
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(model, "ACT_FRAGMENT_MAJOR", on)
+        kv = [(k.clone(), v.clone()) for k, v in inp["kv_t"]]
+        outs.append((model.forward(inp["ids_t"], inp["pos_t"], kv, inp["md"], s, w4a4=False).clone(), kv))
+    torch.cuda.synchronize()
+    (a, kva), (b, kvb) = outs
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    for (ka, va), (kb, vb) in zip(kva, kvb):
+        assert torch.equal(ka, kb) and torch.equal(va, vb)
+
+
 def test_verify_o_proj_k_sliced_dev_knob_meets_the_same_bar(oracle, monkeypatch):
     """QSPEC_VERIFY_O_SLICES (model.py, dev knob; measured in rounds 1 and 3 and left off: DESIGN.md section 4): the verify pass's
     o_proj as K slices whose raw fp32 sums the following norm finishes, as down_proj's are.  Same comparison and bars as
