@@ -1798,6 +1798,122 @@ __global__ __launch_bounds__(12 * 64) void gemm_f16_sdma_kernel(const f16* __res
         par ^= 1;
     }
 }
+// ---- 17..32 tokens (config 3's draft steps): two token tiles over ONE pass of the weight stream.
+// The 12-wave form above has no room for a second tile's 64 fragment registers (three waves per SIMD: 170 VGPRs; it was built
+// and spilled: 240 us against the M-tiled kernel's 230).  Here ALL eight waves stream -- two per SIMD, 256 VGPRs, 128 of them
+// activation fragments -- with the same ring (four 4-KiB groups per wave in flight, 128 KB per CU), and the epilogue is theirs
+// too: 8 x 64 lanes = the tile's 32 x 16 outputs, one per lane, summed over the waves' partials in wave order.  The partials
+// are single-buffered (16 KB: ring + partials = 144 KB): barrier B in front of the post, barrier A behind it; the LDS-DMA
+// window keeps filling across both (raw s_barrier, no vmcnt drain).
+__global__ __launch_bounds__(8 * 64) void gemm_f16_sdma2_kernel(const f16* __restrict__ x, const f16* __restrict__ wt,
+                                                                f16* __restrict__ out, int M, int N, int ntiles,
+                                                                HeadMax* __restrict__ part_max) {
+    constexpr int NW = 8, K = 4096, WIN = 4, MT = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = reinterpret_cast<float*>(smem);                 // [NW][MT][256]
+    unsigned char* ring = smem + (size_t)NW * MT * 1024;         // [NW][WIN][4 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // epilogue role of this lane: output (token em, tile column ec); its partial sits at index eidx of tile emt of every wave
+    const int ec = tid & 15, em = tid >> 4, emt = em >> 4;
+    const int eidx = (em & 3) * 64 + ((em >> 2) & 3) * 16 + ec;
+    float best_v = -__builtin_inff();
+    int best_i = 0x7fffffff;
+
+    const int r = lane & 15, g = lane >> 4;
+    f16x8 af[MT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int row = r + 16 * mt;
+        const f16* xrow = x + (size_t)(row < M ? row : 0) * K + wave * 512 + g * 8;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; s2++) af[mt][s2] = *reinterpret_cast<const f16x8*>(xrow + s2 * 32);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // before the first LDS-DMA load: hipcc's own waits do not know them
+    const u32 my0 = (u32)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)ring + (u32)wave * (WIN * 4096);
+    const int lrow = lane >> 4;
+    auto issue_group = [&](int gi) {   // as in gemm_f16_sdma_kernel
+        const int t = blockIdx.x + (gi >> 2) * (int)gridDim.x;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(wt + (size_t)t * 16 * K) + wave * 1024 + (gi & 3) * 256;
+        const u32 dst = my0 + (u32)(gi & (WIN - 1)) * 4096u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int row = 4 * q + lrow;
+            glds16<1>(base + (size_t)row * (K * 2) + (((lane & 15) ^ row) << 4), dst + (u32)q * 1024u);
+        }
+    };
+    const int n_groups = my_tiles * 4;
+#pragma unroll
+    for (int gi = 0; gi < WIN; gi++)
+        if (gi < n_groups) issue_group(gi);
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
+    const __attribute__((address_space(3))) unsigned char* my3 =
+        (const __attribute__((address_space(3))) unsigned char*)ring + (size_t)wave * (WIN * 4096);
+    u32 foff[4];
+#pragma unroll
+    for (int q2 = 0; q2 < 4; q2++) foff[q2] = (u32)(r >> 2) * 1024u + (u32)((((r & 3) << 4) | ((q2 * 4 + g) ^ r)) << 4);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int gi = 0, tile = blockIdx.x;
+    for (int ti = 0; ti < my_tiles; ti++) {
+        const bool last = ti == my_tiles - 1;   // (wave-uniform) the window runs empty behind the last tile
+#pragma unroll
+        for (int seg = 0; seg < 4; seg++, gi++) {
+            if (!last) vmcnt_le<12>();
+            else if (seg == 0) vmcnt_le<12>();
+            else if (seg == 1) vmcnt_le<8>();
+            else if (seg == 2) vmcnt_le<4>();
+            else vmcnt_le<0>();
+            u32x4 wv[4];
+#pragma unroll
+            for (int q2 = 0; q2 < 4; q2++)
+                wv[q2] = *reinterpret_cast<const volatile lds_u32x4_t*>(my3 + (size_t)seg * 4096 + foff[q2]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (gi + WIN < n_groups) issue_group(gi + WIN);   // into the slot just read
+#pragma unroll
+            for (int q2 = 0; q2 < 4; q2++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][seg * 4 + q2], __builtin_bit_cast(f16x8, wv[q2]), acc[mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_barrier();   // B: every lane has read the previous tile's partials
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) red[(wave * MT + mt) * 256 + i * 64 + lane] = acc[mt][i];
+            acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // A: the tile's partials are posted
+        if (em < M) {
+            float sum = red[emt * 256 + eidx];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; w2++) sum = sum + red[(w2 * MT + emt) * 256 + eidx];
+            const f16 hv = f2h(sum);
+            out[(size_t)em * N + tile * 16 + ec] = hv;
+            const float fv = h2f(hv);
+            if (fv > best_v) {          // tiles come in increasing column order: a tie keeps the first column
+                best_v = fv;
+                best_i = tile * 16 + ec;
+            }
+        }
+        tile += gridDim.x;
+    }
+    if (part_max) {   // the 16 columns of a row sit in 16 consecutive lanes: larger value, then smaller column, wins
+#pragma unroll
+        for (int mk = 1; mk < 16; mk <<= 1) {
+            const float ov = __shfl_xor(best_v, mk, 64);
+            const int oi = __shfl_xor(best_i, mk, 64);
+            if (ov > best_v || (ov == best_v && oi < best_i)) {
+                best_v = ov;
+                best_i = oi;
+            }
+        }
+        if (em < M && ec == 0) part_max[(size_t)em * gridDim.x + blockIdx.x] = HeadMax{best_v, best_i};
+    }
+}
 // (dev knob QSPEC_HEAD_SDMA=0: the register-streaming lm_head)
 static bool head_sdma_on() {
     static const int v = QS_DEV_KNOB("QSPEC_HEAD_SDMA", 1);
@@ -1818,14 +1934,33 @@ static int gemm_f16_sdma_launch_inst(const f16* x, const f16* w, f16* out, int M
     hipLaunchKernelGGL(gemm_f16_sdma_kernel<MT>, dim3(grid), dim3(12 * 64), lds, st, x, w, out, M, N, ntiles, pm);
     return 0;
 }
-// (MT = 2 -- 17..32 tokens as two token tiles over one weight pass -- was built and measured: 240 us against 245 for the M-tiled
-// kernel at M = 32: the second tile's 64 fragment registers push the kernel to 168 VGPRs + scratch at 12 waves, and scratch
-// traffic shares the vmcnt queue with the LDS-DMA window.  Only MT = 1 is launched.)
+// (MT = 2 of THIS kernel -- 17..32 tokens as two token tiles over one weight pass -- was built and measured in round 3: 240 us
+// against 245 for the M-tiled kernel at M = 32: the second tile's 64 fragment registers push the kernel to 168 VGPRs + scratch
+// at 12 waves, and scratch traffic shares the vmcnt queue with the LDS-DMA window.  gemm_f16_sdma2_kernel -- eight waves, all
+// streaming, 184 VGPRs -- is what 17..32 tokens launch: 183 us.)
 static int gemm_f16_sdma_launch(const f16* x, const f16* w, f16* out, int M, int N, int ntiles, int grid, HeadMax* pm,
                                 hipStream_t st) {
+    if (M > 16) {   // two token tiles: gemm_f16_sdma2_kernel
+        const size_t lds = (size_t)8 * 2 * 1024 + (size_t)8 * 4 * 4096;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_sdma2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
+                return -8;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_f16_sdma2_kernel, dim3(grid), dim3(8 * 64), lds, st, x, w, out, M, N, ntiles, pm);
+        return 0;
+    }
     return gemm_f16_sdma_launch_inst<1>(x, w, out, M, N, ntiles, grid, pm, st);
 }
+int gemm_f16_stream_grid(int N);
+// 17..32 tokens: the two-token-tile LDS-DMA form, for a long stream only (the lm_head: >= 4 tiles per workgroup)
+static bool gemm_f16_stream2_supported(int M, int N, int K) {
+    return M > 16 && M <= 32 && K == 4096 && N % 16 == 0 && N / 16 >= 4 * gemm_f16_stream_grid(N) && head_sdma_on();
+}
 bool gemm_f16_stream_supported(int M, int N, int K) {
+    if (gemm_f16_stream2_supported(M, N, K)) return true;
     return M >= 1 && M <= 16 && N % 16 == 0 && (K == 1024 || K == 2048 || K == 4096 || K == 5120 || K == 8192);
 }
 int gemm_f16_stream_grid(int N) {
@@ -1844,7 +1979,7 @@ int gemm_f16_stream(const f16* x, const f16* w, f16* out, int M, int N, int K, v
     static const int cap_knob = QS_DEV_KNOB("QSPEC_HEAD_CAP", 256);   // one workgroup per CU: 6.3 TB/s measured (512: 6.1, 1024: 5.9)
     const int cap = cap_knob < 1 ? 256 : cap_knob;
     int grid = ntiles;
-    if (part_max) {
+    if (part_max || M > 16) {
         grid = gemm_f16_stream_grid(N);
     } else if (grid > cap) {
         const int per = (ntiles + cap - 1) / cap;
@@ -2061,9 +2196,8 @@ static int launch_stream16_inst(const StreamArgs& a, hipStream_t st) {
             grid = (a.ntiles + per - 1) / per;
         }
     }
-    static const int xp_timing = QS_DEV_KNOB("QSPEC_W4A16_XP_TIMING", 0);   // (timing probe: the plain buffer read as if permuted)
     if constexpr ((NW == 8 && (UB == 4 || UB == 5)) || (NW == 4 && (UB == 7 || UB == 9))) {   // the Llama-3-8B / Llama-2-13B shapes
-        if (a.xperm || xp_timing) {
+        if (a.xperm) {
             hipLaunchKernelGGL((gemm_w4a16_stream_kernel<EPI, NW, UB, true>), dim3(grid, slices), dim3(NW * 64),
                                (size_t)2 * NW * 1024 + 1024, st, a);
             return 0;

@@ -890,7 +890,8 @@ def test_softmax_argmax(ops, oracle, T, V):
     assert np.array_equal(host(probs).view(np.uint32), p0.view(np.uint32))
 
 
-@pytest.mark.parametrize("T,V,K", [(4, 128256, 4096), (16, 128256, 4096), (1, 128256, 4096), (3, 32000, 2048), (16, 2048, 1024), (8, 16384, 8192)])
+@pytest.mark.parametrize("T,V,K", [(4, 128256, 4096), (16, 128256, 4096), (1, 128256, 4096), (3, 32000, 2048), (16, 2048, 1024), (8, 16384, 8192),
+                                   (32, 128256, 4096), (17, 20000, 4096)])
 def test_lm_head_softmax_argmax_fused_front_end(ops, oracle, T, V, K):
     """lm_head launch (row maxima from its epilogue) + denominator + write-once probabilities == the two-step path
     (qspec_linear_f16 + qspec_softmax_argmax) bit for bit, and == the oracle's softmax of the GPU's own logits
@@ -1235,8 +1236,9 @@ def test_linear_f16_tiled_within_1e3(ops, oracle, M, N, K):
 
 @pytest.mark.parametrize("M,N", [(1, 16384), (4, 16400), (16, 32768), (3, 128256), (17, 16384), (32, 32768), (24, 20000)])
 def test_linear_f16_lds_dma_stream_within_1e3(ops, oracle, M, N):
-    """The long-stream lm_head (K = 4096, >= 4 tiles per workgroup) through self-service LDS-DMA (`gemm_f16_sdma_kernel`):
-    one and two 16-token tiles, a vocabulary whose tile count is not a multiple of the grid, rows beyond M untouched.
+    """The long-stream lm_head (K = 4096, >= 4 tiles per workgroup) through self-service LDS-DMA (`gemm_f16_sdma_kernel`, and
+    `gemm_f16_sdma2_kernel` = two 16-token tiles over one weight pass from 17 tokens on): a vocabulary whose tile count is not
+    a multiple of the grid, rows beyond M untouched.
     (N = 20000: 1250 tiles on 250 workgroups x 5.)"""
     K = 4096
     rng = np.random.default_rng(M + N)
