@@ -163,7 +163,9 @@ int qspec_add_rms_norm_fp16_partial(qspec_half* out, qspec_half* hidden_out, con
  * (s4s4: linear.py:82 / w4a16: linear.py:122) -> ops.rotary_embedding on q,k (csrc/pos_encoding_kernels.cu:71-122)
  * -> reshape_and_cache_flash of k,v (csrc/cache_kernels.cu:207-303).  wq rows are [q; k; v] (fuse_qkv,
  * quarot_llama.py:152-173).  qkv [M, (num_heads + 2 num_kv_heads) * 128] receives rotated q,k and v;
- * head_size = rot_dim = 128 only.  Bit-identical to running the three ops one after the other. */
+ * head_size = rot_dim = 128, or 64 (TinyLlama) where the streaming kernels take the shape: qspec_qkv_rope_linear_supported
+ * (w4a4 != 0: the s4s4 form) answers that.  Bit-identical to running the three ops one after the other. */
+int qspec_qkv_rope_linear_supported(int w4a4, int M, int N, int K, int head_size);
 int qspec_qkv_rope_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int8_t* wq, const qspec_half* ws,
                                qspec_half* qkv, int M, int N, int K, const int64_t* positions,
                                const qspec_half* cos_sin_cache, qspec_half* key_cache, qspec_half* value_cache,

@@ -37,6 +37,7 @@ SIGNATURES = {
     "qspec_qkv_rope_linear_s4s4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "qspec_qkv_rope_linear_w4a16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp,
                                          _vp]),
+    "qspec_qkv_rope_linear_supported": (_i, [_i, _i, _i, _i, _i]),
     "qspec_gate_up_silu_linear_s4s4": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "qspec_gate_up_silu_linear_w4a16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "qspec_ln_qkv_rope_linear_s4s4": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i,

@@ -1176,34 +1176,67 @@ __global__ __launch_bounds__(256) void paged_attention_generic_vec_kernel(
     const int kvh = h / (nq / nkv);
     const int32_t* bt = block_tables + (size_t)seq * max_blocks;
     const int pieces = d >> 3;                         // 16-byte pieces per row
-    const int KC = 256 / pieces;                       // V rows per chunk
+    const int RG = 256 / pieces;                       // row groups of the P.V pass (threads beyond RG * pieces idle there)
     float* sc = reinterpret_cast<float*>(smem_raw);   // [nvis rounded up to 4]
-    f16* vt = reinterpret_cast<f16*>(smem_raw + (((size_t)nvis * 4 + 15) & ~(size_t)15));   // [KC][d]
+    float* pvr = reinterpret_cast<float*>(smem_raw + (((size_t)nvis * 4 + 15) & ~(size_t)15));   // [RG][d] partial output rows
     if (tid < pieces)
         *reinterpret_cast<u32x4*>(qrow + tid * 8) = *reinterpret_cast<const u32x4*>(q + (size_t)t * q_stride + (size_t)h * d + tid * 8);
-    __syncthreads();
-    float mx = -__builtin_inff();
-    for (int k = tid; k < nvis; k += 256) {
-        const int64_t slot = (int64_t)bt[k / block_size] * block_size + k % block_size;
-        const f16* kp = key_cache + (slot * nkv + kvh) * d;
-        float acc = 0.0f;
-        for (int p0 = 0; p0 < pieces; p0 += 8) {      // up to 8 pieces of the row in flight
-            u32x4 kr[8];
+    // the V rows do not depend on the scores: this thread's first PRE of them are requested here, in front of the K rows
+    constexpr int PRE = 8;
+    const int rg = tid / pieces, vp = tid - rg * pieces;
+    const bool pv_on = rg < RG;
+    auto vaddr = [&](int k) -> const f16* {
+        const int kc = min(k, nvis - 1);               // clamped: no branch around a load (rows past the end are not used)
+        const int64_t slot = (int64_t)bt[kc / block_size] * block_size + kc % block_size;
+        return value_cache + (slot * nkv + kvh) * d + vp * 8;
+    };
+    u32x4 vpre[PRE];
 #pragma unroll
-            for (int j = 0; j < 8; j++) kr[j] = *reinterpret_cast<const u32x4*>(kp + min(p0 + j, pieces - 1) * 8);
+    for (int j = 0; j < PRE; j++) vpre[j] = *reinterpret_cast<const u32x4*>(vaddr(rg + RG * j));
+    __syncthreads();
+    // scores: NK keys per thread and trip -- their table entries first, then every K piece in flight, then the dot products
+    // (one key per trip was two dependent round trips per key: 512 keys = four of them per thread)
+    constexpr int NK = 4;
+    float mx = -__builtin_inff();
+    for (int kb = tid; kb < nvis; kb += 256 * NK) {
+        const f16* kp[NK];
+#pragma unroll
+        for (int i = 0; i < NK; i++) {
+            const int kc = min(kb + 256 * i, nvis - 1);   // clamped: rows past the end are loaded, not used
+            const int64_t slot = (int64_t)bt[kc / block_size] * block_size + kc % block_size;
+            kp[i] = key_cache + (slot * nkv + kvh) * d;
+        }
+        float acc[NK];
+#pragma unroll
+        for (int i = 0; i < NK; i++) acc[i] = 0.0f;
+        for (int p0 = 0; p0 < pieces; p0 += 8) {      // up to 8 pieces of each row in flight
+            u32x4 kr[NK][8];
+#pragma unroll
+            for (int i = 0; i < NK; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) kr[i][j] = *reinterpret_cast<const u32x4*>(kp[i] + min(p0 + j, pieces - 1) * 8);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 if (p0 + j < pieces) {
-                    const f16x8 k8 = __builtin_bit_cast(f16x8, kr[j]);
                     const f16x8 q8 = *reinterpret_cast<const f16x8*>(qrow + (p0 + j) * 8);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) acc = __builtin_fmaf(h2f(q8[e]), h2f(k8[e]), acc);
+                    for (int i = 0; i < NK; i++) {
+                        const f16x8 k8 = __builtin_bit_cast(f16x8, kr[i][j]);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) acc[i] = __builtin_fmaf(h2f(q8[e]), h2f(k8[e]), acc[i]);
+                    }
                 }
             }
         }
-        acc *= sm_scale;
-        sc[k] = acc;
-        mx = fmaxf(mx, acc);
+#pragma unroll
+        for (int i = 0; i < NK; i++) {
+            const int k = kb + 256 * i;
+            if (k < nvis) {
+                const float a = acc[i] * sm_scale;
+                sc[k] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
     }
     mx = wave_max_f(mx);
     if ((tid & 63) == 0) red[tid >> 6] = mx;
@@ -1220,28 +1253,41 @@ __global__ __launch_bounds__(256) void paged_attention_generic_vec_kernel(
     if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
     __syncthreads();
     const float den = (red[4] + red[5]) + (red[6] + red[7]);
-    // ---- P.V
-    const int vrow = tid / pieces, vpiece = tid - vrow * pieces;   // this thread's (row of the chunk, piece)
-    const bool loader = vrow < KC;
-    auto load_piece = [&](int k0) -> u32x4 {
-        const int k = min(k0 + vrow, nvis - 1);        // clamped: no branch around a load (rows past the end are not used)
-        const int64_t slot = (int64_t)bt[k / block_size] * block_size + k % block_size;
-        return *reinterpret_cast<const u32x4*>(value_cache + (slot * nkv + kvh) * d + vpiece * 8);
+    // ---- P.V: thread (row group rg, 16-byte piece vp) sums p_k * V[k][8 vp .. 8 vp + 8) over the keys rg, rg + RG, ...
+    // (the first eight of its rows were requested in front of the scores), then the RG partial rows are added in order.
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = 0.0f;
+    auto fma8 = [&](float pk, u32x4 raw) {
+        const f16x8 v8 = __builtin_bit_cast(f16x8, raw);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = __builtin_fmaf(pk, h2f(v8[e]), acc[e]);
     };
-    u32x4 nxt = u32x4{0, 0, 0, 0};
-    if (loader) nxt = load_piece(0);
-    float acc = 0.0f;
-    for (int k0 = 0; k0 < nvis; k0 += KC) {
-        __syncthreads();                               // the previous chunk has been consumed
-        if (loader) *reinterpret_cast<u32x4*>(vt + (size_t)vrow * d + vpiece * 8) = nxt;
-        __syncthreads();
-        if (loader && k0 + KC < nvis) nxt = load_piece(k0 + KC);
-        if (tid < d) {
-            const int kn = min(KC, nvis - k0);
-            for (int kk = 0; kk < kn; kk++) acc = __builtin_fmaf(sc[k0 + kk], h2f(vt[(size_t)kk * d + tid]), acc);
+    if (pv_on) {
+#pragma unroll
+        for (int j = 0; j < PRE; j++) {
+            const int k = rg + RG * j;
+            if (k < nvis) fma8(sc[k], vpre[j]);
         }
+        for (int k0 = rg + RG * PRE; k0 < nvis; k0 += RG * PRE) {   // long contexts: eight more rows in flight per trip
+            u32x4 vb[PRE];
+#pragma unroll
+            for (int j = 0; j < PRE; j++) vb[j] = *reinterpret_cast<const u32x4*>(vaddr(k0 + RG * j));
+#pragma unroll
+            for (int j = 0; j < PRE; j++) {
+                const int k = k0 + RG * j;
+                if (k < nvis) fma8(sc[k], vb[j]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) pvr[(size_t)rg * d + vp * 8 + e] = acc[e];
     }
-    if (tid < d) out[((size_t)t * nq + h) * d + tid] = f2h(acc / den);
+    __syncthreads();
+    if (tid < d) {
+        float o = pvr[tid];
+        for (int r2 = 1; r2 < RG; r2++) o += pvr[(size_t)r2 * d + tid];
+        out[((size_t)t * nq + h) * d + tid] = f2h(o / den);
+    }
 }
 
 // float offsets of the partials inside the workspace (shared with hadamard.hip:heads_hadamard_merge)
@@ -1274,11 +1320,11 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
             static bool attr_set = false;
             if (!attr_set) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_generic_vec_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, max_ctx_bytes + 4096 + 16) != hipSuccess)
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, max_ctx_bytes + 32768 + 16) != hipSuccess)
                     return -8;
                 attr_set = true;
             }
-            hipLaunchKernelGGL(paged_attention_generic_vec_kernel, dim3(n_seqs * max_q_len, nq), dim3(256), max_ctx_bytes + 4096 + 16,
+            hipLaunchKernelGGL(paged_attention_generic_vec_kernel, dim3(n_seqs * max_q_len, nq), dim3(256), max_ctx_bytes + 32768 + 16,
                                st, q, q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, n_seqs, nq,
                                nkv, d, block_size, sm_scale, out);
             return 0;

@@ -537,13 +537,20 @@ int qspec_qkv_rope_linear_s4s4(const int8_t* xq, const qspec_half* xs, const int
     if (M == 0) return 0;
     NONNULL(op, xq); NONNULL(op, xs); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, qkv); NONNULL(op, positions);
     NONNULL(op, cos_sin_cache); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
-    if (head_size != 128 || rot_dim != 128) return fail("%s: head_size and rot_dim must be 128", op);
+    if ((head_size != 128 && head_size != 64) || rot_dim != head_size) return fail("%s: head_size = rot_dim = 128 or 64 only", op);
+    if (head_size == 64 && !(use_stream() && qspec::gemm_w4a4_stream_supported(M, N, K, false)))
+        return fail("%s: head_size 64 exists on the streaming kernel only (M=%d N=%d K=%d): ask qspec_qkv_rope_linear_supported", op, M, N, K);
     if (use_stream() && qspec::gemm_w4a4_stream_supported(M, N, K, false)) {
         qspec::StreamActs x;
         x.xq = xq; x.xs = CH(xs);
         return finish(op, qspec::gemm_w4a4_stream_qkv_rope(x, wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST));
     }
     return finish(op, qspec::gemm_w4a4_qkv_rope(xq, CH(xs), wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST));
+}
+int qspec_qkv_rope_linear_supported(int w4a4, int M, int N, int K, int head_size) {
+    if (head_size == 128) return 1;   // every shape: the streaming kernels, else the first-generation fused kernels
+    if (head_size != 64 || !use_stream()) return 0;
+    return (w4a4 ? qspec::gemm_w4a4_stream_supported(M, N, K, false) : qspec::gemm_w4a16_stream_supported(M, N, K)) ? 1 : 0;
 }
 int qspec_qkv_rope_linear_w4a16(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M,
                                 int N, int K, const int64_t* positions, const qspec_half* cos_sin_cache,
@@ -554,7 +561,9 @@ int qspec_qkv_rope_linear_w4a16(const qspec_half* x, const int8_t* wq, const qsp
     if (M == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, qkv); NONNULL(op, positions);
     NONNULL(op, cos_sin_cache); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
-    if (head_size != 128 || rot_dim != 128) return fail("%s: head_size and rot_dim must be 128", op);
+    if ((head_size != 128 && head_size != 64) || rot_dim != head_size) return fail("%s: head_size = rot_dim = 128 or 64 only", op);
+    if (head_size == 64 && !(use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K)))
+        return fail("%s: head_size 64 exists on the streaming kernel only (M=%d N=%d K=%d): ask qspec_qkv_rope_linear_supported", op, M, N, K);
     if (g_xp && !(use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K) && qspec::gemm_w4a16_xperm_supported(M, K)))
         return fail("%s: no fragment-major form for (M=%d N=%d K=%d)", op, M, N, K);
     if (use_stream() && qspec::gemm_w4a16_stream_supported(M, N, K))
@@ -652,7 +661,7 @@ int qspec_ln_qkv_rope_linear_s4s4(const qspec_half* hidden_in, const qspec_half*
     NONNULL(op, hidden_in); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, qkv); NONNULL(op, positions);
     NONNULL(op, cos_sin_cache); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
     if (hidden_out == hidden_in) return fail("%s: hidden_out must not alias hidden_in (every workgroup reads it)", op);
-    if (head_size != 128 || rot_dim != 128) return fail("%s: head_size and rot_dim must be 128", op);
+    if ((head_size != 128 && head_size != 64) || rot_dim != head_size) return fail("%s: head_size = rot_dim = 128 or 64 only", op);
     if (!qspec::gemm_w4a4_stream_supported(M, N, K, true))
         return fail("%s: need M <= 16, N %% 16 == 0, K in {1024, 2048, 4096, 5120, 8192} (M=%d N=%d K=%d)", op, M, N, K);
     qspec::StreamActs x;

@@ -88,6 +88,7 @@ struct StreamArgs {
     f16* value_cache;
     const int64_t* slot_mapping;
     int nq, nkv, I;
+    int hdl = 7;   // SEPI_QKV: log2(head size), 7 or 6
 };
 
 __device__ __forceinline__ i32x4 widen16(u32 p0, u32 p1) {
@@ -115,17 +116,18 @@ struct QkvPair {
     int head, i;
     bool valid;
 };
-__device__ __forceinline__ QkvPair qkv_pair(int tb, int j, int L) {   // j = 0..7: pair slot of the tile
-    if (L == 0) return QkvPair{tb >> 3, (tb & 7) * 8 + j, true};
+// hdl = log2(head size): 7 (128: 64 pairs = 8 tiles per head) or 6 (64, e.g. TinyLlama: 32 pairs = 4 tiles per head)
+__device__ __forceinline__ QkvPair qkv_pair(int tb, int j, int L, int hdl) {   // j = 0..7: pair slot of the tile
+    if (L == 0) return QkvPair{tb >> (hdl - 4), (tb & ((1 << (hdl - 4)) - 1)) * 8 + j, true};
     const bool half = tb >= L;
     const int p = 12 * (half ? tb - L : tb) + (half ? 8 + (j & 3) : j);
     return QkvPair{p >> 6, p & 63, !half || j < 4};
 }
 template <int EPI>
-__device__ __forceinline__ int stile_row(int tb, int r, int I) {
+__device__ __forceinline__ int stile_row(int tb, int r, int I, int hdl) {
     if (EPI == SEPI_QKV) {
-        const QkvPair q = qkv_pair(tb, r & 7, I);
-        return q.head * 128 + (r >> 3) * 64 + q.i;
+        const QkvPair q = qkv_pair(tb, r & 7, I, hdl);
+        return (q.head << hdl) + ((r >> 3) << (hdl - 1)) + q.i;
     }
     if (EPI == SEPI_GATEUP) return (r >> 3) * I + tb * 8 + (r & 7);
     return tb * 16 + r;
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
             __builtin_amdgcn_s_barrier();   // #0 (the norm waves' row requests are out)
             for (int d = 1; d <= nd; d++) {
                 const int td = blockIdx.x + d * (int)gridDim.x;
-                const uint8_t* wp = a.wq + (size_t)stile_row<EPI>(td, lane & 15, a.I) * Kb + (lane >> 4) * 16;
+                const uint8_t* wp = a.wq + (size_t)stile_row<EPI>(td, lane & 15, a.I, a.hdl) * Kb + (lane >> 4) * 16;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const int j = lw + 4 * i;   // load j of the tile = (stream wave j / UB, step j % UB)
@@ -631,17 +633,17 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
         f16 swn, cf, sf;
     };
     auto load_pre = [&](Pre& pre, int tile) {  // epilogue operands of (token m, column c) of `tile`
-        if (EPI != SEPI_IPART) pre.swn = a.ws[stile_row<EPI>(tile, c, a.I)];
+        if (EPI != SEPI_IPART) pre.swn = a.ws[stile_row<EPI>(tile, c, a.I, a.hdl)];
         if (EPI == SEPI_RESID) pre.cf = a.resid_in[(size_t)mc * a.N + tile * 16 + c];   // the residual element
         if (EPI == SEPI_QKV) {
-            const int o = qkv_pair(tile, c & 7, a.I).i;
-            const f16* cs = a.cos_sin_cache + pos_m * 128;
+            const int o = qkv_pair(tile, c & 7, a.I, a.hdl).i;
+            const f16* cs = a.cos_sin_cache + (pos_m << a.hdl);   // rot_dim = head size
             pre.cf = cs[o];
-            pre.sf = cs[64 + o];
+            pre.sf = cs[(1 << (a.hdl - 1)) + o];
         }
     };
     auto wptr = [&](int tile, int b) -> const uint8_t* {
-        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I) * ldwb + kofs + (size_t)(b * UB * NW) * 64 + g * 16;
+        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I, a.hdl) * ldwb + kofs + (size_t)(b * UB * NW) * 64 + g * 16;
     };
     // A wave owns the same K steps of every tile (one batch per tile: NB == 1, checked on the host), so its
     // activation fragments are widened ONCE and stay in registers: no per-step LDS read, and with (xq, xs) given
@@ -716,10 +718,10 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
             return;
         }
         // SEPI_QKV
-        const QkvPair qp = qkv_pair(tile, c & 7, a.I);
+        const QkvPair qp = qkv_pair(tile, c & 7, a.I, a.hdl);
         if (!qp.valid) return;   // a half tile's repeated slots
         const int head = qp.head, o = qp.i;
-        const int n = head * 128 + (c >> 3) * 64 + o;
+        const int n = (head << a.hdl) + ((c >> 3) << (a.hdl - 1)) + o;
         f16 res = hv;
         if (head < a.nq + a.nkv) {
             const float cff = h2f(pre.cf), sff = h2f(pre.sf);
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(NW * 64 + (pro_split<PRO>() ? 256 : 0) + (DMA > 0 ?
             const bool is_k = head < a.nq + a.nkv;
             const int kvh = is_k ? head - a.nq : head - a.nq - a.nkv;
             f16* cache = is_k ? a.key_cache : a.value_cache;
-            cache[(slot_m * a.nkv + kvh) * 128 + (c >> 3) * 64 + o] = res;
+            cache[((slot_m * a.nkv + kvh) << a.hdl) + ((c >> 3) << (a.hdl - 1)) + o] = res;
         }
     };
 
@@ -1270,16 +1272,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
         f16 swn, cf, sf;
     };
     auto load_pre = [&](Pre& pre, int tile) {
-        pre.swn = a.ws[stile_row<EPI>(tile, c, a.I)];
+        pre.swn = a.ws[stile_row<EPI>(tile, c, a.I, a.hdl)];
         if (EPI == SEPI_QKV) {
-            const int o = qkv_pair(tile, c & 7, a.I).i;
-            const f16* cs = a.cos_sin_cache + pos_m * 128;
+            const int o = qkv_pair(tile, c & 7, a.I, a.hdl).i;
+            const f16* cs = a.cos_sin_cache + (pos_m << a.hdl);   // rot_dim = head size
             pre.cf = cs[o];
-            pre.sf = cs[64 + o];
+            pre.sf = cs[(1 << (a.hdl - 1)) + o];
         }
     };
     auto wptr = [&](int tile) -> const uint8_t* {
-        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I) * ldw + (kofs >> 1) + g * 16;
+        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I, a.hdl) * ldw + (kofs >> 1) + g * 16;
     };
     // Activation fragments of this wave's K slice (rows >= M repeat row 0: their outputs are never stored).
     // As MFMA fragments they are 16 rows x 64-byte pieces per load instruction (measured: the 128 KB per workgroup cost
@@ -1400,10 +1402,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
             }
             return;
         }
-        const QkvPair qp = qkv_pair(tile, c & 7, a.I);
+        const QkvPair qp = qkv_pair(tile, c & 7, a.I, a.hdl);
         if (!qp.valid) return;   // a half tile's repeated slots
         const int head = qp.head, o = qp.i;
-        const int n = head * 128 + (c >> 3) * 64 + o;
+        const int n = (head << a.hdl) + ((c >> 3) << (a.hdl - 1)) + o;
         f16 res = hv;
         if (head < a.nq + a.nkv) {
             const float cff = h2f(pre.cf), sff = h2f(pre.sf);
@@ -1415,7 +1417,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream_kernel(StreamArgs a
             const bool is_k = head < a.nq + a.nkv;
             const int kvh = is_k ? head - a.nq : head - a.nq - a.nkv;
             f16* cache = is_k ? a.key_cache : a.value_cache;
-            cache[(slot_m * a.nkv + kvh) * 128 + (c >> 3) * 64 + o] = res;
+            cache[((slot_m * a.nkv + kvh) << a.hdl) + ((c >> 3) << (a.hdl - 1)) + o] = res;
         }
     };
     for (int q = 0; q < my_tiles - 1; q++) {
@@ -2306,15 +2308,16 @@ static int qkv_level_workgroups(int nq, int nkv, int N) {
 int gemm_w4a16_stream_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                                const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
                                const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st, int xperm) {
-    if (d != 128 || rot_dim != 128 || N != (nq + 2 * nkv) * 128 || !gemm_w4a16_stream_supported(M, N, K)) return -1;
+    if ((d != 128 && d != 64) || rot_dim != d || N != (nq + 2 * nkv) * d || !gemm_w4a16_stream_supported(M, N, K)) return -1;
     if (xperm && !gemm_w4a16_xperm_supported(M, K)) return -1;
     StreamArgs a{};
     a.xperm = xperm;
+    a.hdl = d == 64 ? 6 : 7;
     a.x = x; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = qkv; a.M = M; a.N = N; a.K = K;
     a.ntiles = N / 16; a.positions = positions; a.cos_sin_cache = cos_sin_cache; a.key_cache = key_cache;
     a.value_cache = value_cache; a.slot_mapping = slot_mapping; a.nq = nq; a.nkv = nkv;
 #ifdef QS_EXPERIMENTAL
-    if (const int L = qkv_level_workgroups(nq, nkv, N)) {   // twelve RoPE pairs per workgroup: a full + a half tile
+    if (const int L = d == 128 ? qkv_level_workgroups(nq, nkv, N) : 0) {   // twelve RoPE pairs per workgroup: a full + a half tile
         a.I = L;
         a.ntiles = 2 * L;
     }
@@ -2398,16 +2401,17 @@ int gemm_w4a4_stream_residual_hq(const f16* x16, const float* part_amax, int npa
 int gemm_w4a4_stream_qkv_rope(const StreamActs& x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                               const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
                               const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st) {
-    if (d != 128 || rot_dim != 128 || N != (nq + 2 * nkv) * 128) return -1;
+    if ((d != 128 && d != 64) || rot_dim != d || N != (nq + 2 * nkv) * d) return -1;
     if (!gemm_w4a4_stream_supported(M, N, K, x.hidden_in != nullptr)) return -1;
     StreamArgs a{};
+    a.hdl = d == 64 ? 6 : 7;
     a.xq = x.xq; a.xs = x.xs; a.hidden_in = x.hidden_in; a.delta = x.delta; a.hidden_out = x.hidden_out; a.eps = x.eps; a.sync = x.sync;
     a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = qkv; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
     a.positions = positions; a.cos_sin_cache = cos_sin_cache; a.key_cache = key_cache; a.value_cache = value_cache;
     a.slot_mapping = slot_mapping; a.nq = nq; a.nkv = nkv;
 #ifdef QS_EXPERIMENTAL
     if (!sdma_on<SEPI_QKV>()) {   // (the LDS-DMA forms keep the classic tiles)
-        if (const int L = qkv_level_workgroups(nq, nkv, N)) {
+        if (const int L = d == 128 ? qkv_level_workgroups(nq, nkv, N) : 0) {
             a.I = L;
             a.ntiles = 2 * L;
         }

@@ -269,7 +269,10 @@ class QuarotLlamaForCausalLM:
         row = cfg.q_size + 2 * cfg.kv_size
         tp_sharded = self.tp is not None and self.tp.world > 1 and getattr(self.tp, "shard_layers", True) and not w4a4
         # fused GEMM epilogues (decode-sized M)
-        fuse = cfg.head_dim == 128 and (w4a4 or T <= (min(self.BIG_M, 32) if tp_sharded else self.VERIFY_FUSE_MAX_M))
+        # (head size 64 -- TinyLlama -- has the fused qkv + RoPE + KV-write epilogue on the streaming kernels only)
+        fuse_hd = cfg.head_dim == 128 or (cfg.head_dim == 64 and T <= 32 and
+                                          ops.qkv_rope_linear_supported(w4a4, T, cfg.q_size + 2 * cfg.kv_size, cfg.hidden_size, 64))
+        fuse = fuse_hd and (w4a4 or T <= (min(self.BIG_M, 32) if tp_sharded else self.VERIFY_FUSE_MAX_M))
         # tensor parallelism only on the verify pass at decode-sized M; the draft pass and prefill run replicated
         tp_on = tp_sharded and fuse and T <= 32
         act = s.act_buffer_had_mlp[:T]                            # silu(gate)*up, [T, I]

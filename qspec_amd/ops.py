@@ -215,6 +215,11 @@ def mlp_hadamard(act, hadK, K: int, had_scale: float, out_f16=None, q=None, scal
 
 # ------------------------------------------------------------------ linear
 
+def qkv_rope_linear_supported(w4a4: bool, M: int, N: int, K: int, head_size: int) -> bool:
+    """The fused qkv GEMM + RoPE + KV write exists for head size 128 (every shape) and 64 (streaming shapes)."""
+    return bool(_lib.load().qspec_qkv_rope_linear_supported(int(bool(w4a4)), M, N, K, head_size))
+
+
 def qkv_rope_linear(x, x_scale, wq, w_scale, qkv, positions, cos_sin_cache, key_cache, value_cache, slot_mapping,
                     num_heads, num_kv_heads, head_size, xp: bool = False, tokens=None):
     """qkv GEMM + rotary_embedding + reshape_and_cache_flash in one launch (quarot_llama.py:183-226).

@@ -301,12 +301,23 @@ def test_both_views_read_the_same_buffer(ops, oracle):
     assert torch.equal(w, before)
 
 
-@pytest.mark.parametrize("M,w4a4", [(4, True), (16, True), (33, True), (16, False), (24, False)])
-def test_qkv_rope_linear_equals_gemm_then_rope_then_cache(ops, oracle, M, w4a4):
-    """Fused epilogue == the three reference ops one after the other, bit for bit (same kernels' arithmetic)."""
+@pytest.mark.parametrize("M,w4a4,d", [(4, True, 128), (16, True, 128), (33, True, 128), (16, False, 128), (24, False, 128),
+                                      (1, True, 64), (4, True, 64), (16, True, 64), (24, True, 64), (4, False, 64), (16, False, 64)])
+def test_qkv_rope_linear_equals_gemm_then_rope_then_cache(ops, oracle, M, w4a4, d):
+    """Fused epilogue == the three reference ops one after the other, bit for bit (same kernels' arithmetic).  Head size 64
+    (TinyLlama: 32 + 2 x 4 heads, K = 2048) runs on the streaming kernels only (RoPE pairs (i, i + 32), four tiles per head)."""
     rng = np.random.default_rng(M)
-    nq, nkv, d, K, bs = 8, 2, 128, 1024, 16
+    nq, nkv, K, bs = (8, 2, 1024, 16) if d == 128 else (32, 4, 2048, 16)
     N = (nq + 2 * nkv) * d
+    if not ops.qkv_rope_linear_supported(w4a4, M, N, K, d):   # head size 64 beyond the streaming shapes: refused, not mis-computed
+        assert d == 64 and M > 16
+        with pytest.raises(RuntimeError):
+            ops.qkv_rope_linear(dev(oracle.pack_i4(rand_w4(rng, M, K))), dev(np.ones(M, np.float16)), dev(oracle.pack_i4(rand_w4(rng, N, K))),
+                                dev(np.ones(N, np.float16)), torch.empty(M, N, dtype=torch.float16, device=DEV),
+                                dev(np.zeros(M, np.int64)), dev(oracle.make_cos_sin_cache(d, 64, 10000.0)),
+                                torch.zeros(8, bs, nkv, d, dtype=torch.float16, device=DEV), torch.zeros(8, bs, nkv, d, dtype=torch.float16, device=DEV),
+                                dev(np.zeros(M, np.int64)), nq, nkv, d)
+        return
     wq = dev(oracle.pack_i4(rand_w4(rng, N, K)))
     ws = dev((rng.random(N) * 0.01 + 0.001).astype(np.float16))
     cs = dev(oracle.make_cos_sin_cache(d, 2048, 10000.0))
@@ -661,9 +672,12 @@ def test_paged_attention_within_1e3(ops, oracle, ctx_lens, q_len, few_splits):
 
 # ------------------------------------------------------------------ token side
 
-@pytest.mark.parametrize("ctx_lens,q_len,d,nq,nkv", [([37, 200], 1, 64, 32, 4), ([70, 9, 300], 4, 64, 8, 8), ([50], 3, 96, 4, 2)])
+@pytest.mark.parametrize("ctx_lens,q_len,d,nq,nkv", [([37, 200], 1, 64, 32, 4), ([70, 9, 300], 4, 64, 8, 8), ([50], 3, 96, 4, 2),
+                                                     ([1, 600, 1300], 2, 64, 32, 4), ([2100], 1, 64, 8, 4), ([700, 3], 1, 256, 2, 1),
+                                                     ([300], 4, 8, 4, 4)])
 def test_paged_attention_generic_head_size_within_1e3(ops, oracle, ctx_lens, q_len, d, nq, nkv):
-    """Head sizes other than 128 (TinyLlama: 64) take the generic kernel (no context split, no matrix cores)."""
+    """Head sizes other than 128 (TinyLlama: 64) take the generic kernel (no context split, no matrix cores): contexts inside
+    and beyond the P.V pass's prefetch window (8 rows per thread), one-key contexts, 1..32 pieces per row."""
     rng = np.random.default_rng(sum(ctx_lens) + d)
     bs = 16
     n_seqs = len(ctx_lens)
