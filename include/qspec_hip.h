@@ -292,8 +292,10 @@ int qspec_rope_kv_write(const int64_t* positions, qspec_half* qkv, const qspec_h
  * with the keys over the waves of a workgroup (out == NULL and block_tables wide enough for splits longer than 128
  * keys); 64-row flash-style workgroups for prompt-sized queries (n_splits == 1, max_q_len * num_heads / num_kv_heads
  * >= 128).  Every block_tables entry must be a valid block number (unused tail entries: 0, as vLLM pads them): rows
- * past a sequence's context are read (clamped prefetch) and masked, never used.  head_size != 128 (<= 256): a generic
- * kernel, out != NULL only. */
+ * past a sequence's context are read (clamped prefetch) and masked, never used.  head_size != 128 (even, <= 256; TinyLlama:
+ * 64): a generic kernel without matrix cores, one workgroup per (token, head, split) over min(n_splits, 4) context splits of
+ * whole 16-key groups; out != NULL merges them with a second small launch, out == NULL (head_size % 8 == 0) leaves the
+ * partials to qspec_heads_hadamard_merged -- the same merge expression, so the same bits either way. */
 size_t qspec_paged_attention_workspace_bytes(int max_tokens, int num_heads, int head_size, int n_splits);
 int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_half* key_cache,
                           const qspec_half* value_cache, const int32_t* block_tables, int max_blocks_per_seq,
@@ -304,7 +306,8 @@ int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_hal
 /* qspec_heads_hadamard on the un-merged output of qspec_paged_attention(..., out = NULL): split merge (same
  * expression as the attention kernel's own merge, rounded to fp16 where flash-attn returns fp16) + head Hadamard
  * (+ row-absmax int4 quant when q != NULL).  attn_workspace / max_tokens (= n_seqs * max_q_len) / n_splits are
- * those of the attention call.  head_dim 128, 32 or 64 heads.  The merge itself is the attention kernel's expression;
+ * those of the attention call.  head_dim 128 with 32 or 64 heads; 32 heads of another size % 8 == 0 (64).  The merge itself
+ * is the attention kernel's expression;
  * with splits of at most 128 keys the result is bit-identical to qspec_paged_attention(out != NULL) followed by
  * qspec_heads_hadamard (longer splits take a kernel with another summation order inside a split: equal within 1e-3). */
 int qspec_heads_hadamard_merged(const void* attn_workspace, int max_tokens, int n_splits, qspec_half* out_f16, int8_t* q,

@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(256) void paged_attention_generic_vec_kernel(
     const f16* __restrict__ q, int64_t q_stride, const f16* __restrict__ key_cache, const f16* __restrict__ value_cache,
     const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ ctx_lens,
     const int32_t* __restrict__ q_start, int n_seqs, int nq, int nkv, int d, int block_size, float sm_scale,
-    f16* __restrict__ out) {
+    f16* __restrict__ out, float* __restrict__ ws_o, float* __restrict__ ws_ml) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ float red[8];
     __shared__ __attribute__((aligned(16))) f16 qrow[256];
@@ -1172,7 +1172,13 @@ __global__ __launch_bounds__(256) void paged_attention_generic_vec_kernel(
     const int qs = q_start[seq], qlen = q_start[seq + 1] - qs, ctx = ctx_lens[seq];
     if (t - qs >= qlen) return;   // (uniform)
     const int pos = ctx - qlen + (t - qs);            // absolute position of this query token
-    const int nvis = pos + 1;                          // causal: keys 0..pos
+    const int nall = pos + 1;                          // causal: keys 0..pos
+    // context splits (gridDim.z = S > 1, or partials wanted): split sp takes keys [kbase, kbase + nvis) -- whole 16-key groups,
+    // the same length for every split of a token; an empty split leaves (m, l, o) = (-inf, 0, 0)
+    const int S = gridDim.z, sp = blockIdx.z;
+    const int per = S > 1 ? ((((nall + S - 1) / S) + 15) & ~15) : nall;
+    const int kbase = min(nall, sp * per);
+    const int nvis = min(nall - kbase, per);           // keys of this workgroup (0: an empty split)
     const int kvh = h / (nq / nkv);
     const int32_t* bt = block_tables + (size_t)seq * max_blocks;
     const int pieces = d >> 3;                         // 16-byte pieces per row
@@ -1186,7 +1192,7 @@ __global__ __launch_bounds__(256) void paged_attention_generic_vec_kernel(
     const int rg = tid / pieces, vp = tid - rg * pieces;
     const bool pv_on = rg < RG;
     auto vaddr = [&](int k) -> const f16* {
-        const int kc = min(k, nvis - 1);               // clamped: no branch around a load (rows past the end are not used)
+        const int kc = min(kbase + min(k, nvis - 1), nall - 1);   // clamped: no branch around a load (rows past the end are not used)
         const int64_t slot = (int64_t)bt[kc / block_size] * block_size + kc % block_size;
         return value_cache + (slot * nkv + kvh) * d + vp * 8;
     };
@@ -1202,7 +1208,7 @@ __global__ __launch_bounds__(256) void paged_attention_generic_vec_kernel(
         const f16* kp[NK];
 #pragma unroll
         for (int i = 0; i < NK; i++) {
-            const int kc = min(kb + 256 * i, nvis - 1);   // clamped: rows past the end are loaded, not used
+            const int kc = min(kbase + min(kb + 256 * i, nvis - 1), nall - 1);   // clamped: rows past the end are loaded, not used
             const int64_t slot = (int64_t)bt[kc / block_size] * block_size + kc % block_size;
             kp[i] = key_cache + (slot * nkv + kvh) * d;
         }
@@ -1263,7 +1269,8 @@ __global__ __launch_bounds__(256) void paged_attention_generic_vec_kernel(
 #pragma unroll
         for (int e = 0; e < 8; e++) acc[e] = __builtin_fmaf(pk, h2f(v8[e]), acc[e]);
     };
-    if (pv_on) {
+    const int pv_rows = min(RG, nvis);   // row groups that saw a key (the others wrote nothing)
+    if (pv_on && rg < nvis) {
 #pragma unroll
         for (int j = 0; j < PRE; j++) {
             const int k = rg + RG * j;
@@ -1284,13 +1291,45 @@ __global__ __launch_bounds__(256) void paged_attention_generic_vec_kernel(
     }
     __syncthreads();
     if (tid < d) {
-        float o = pvr[tid];
-        for (int r2 = 1; r2 < RG; r2++) o += pvr[(size_t)r2 * d + tid];
-        out[((size_t)t * nq + h) * d + tid] = f2h(o / den);
+        float o = pv_rows > 0 ? pvr[tid] : 0.0f;
+        for (int r2 = 1; r2 < pv_rows; r2++) o += pvr[(size_t)r2 * d + tid];
+        if (ws_o) {   // partials of split sp: unnormalised output, (row maximum, sum of exponentials)
+            const size_t ths = ((size_t)t * nq + h) * S + sp;
+            ws_o[ths * d + tid] = o;
+            if (tid == 0) *reinterpret_cast<float2*>(ws_ml + ths * 2) = float2{mx, den};
+        } else {
+            out[((size_t)t * nq + h) * d + tid] = f2h(o / den);
+        }
     }
 }
 
 // float offsets of the partials inside the workspace (shared with hadamard.hip:heads_hadamard_merge)
+// Split merge for the generic head sizes when the caller wants fp16 rows (the reference-order path; the engine merges in
+// the head-transform launch, hadamard.hip: heads_hadamard_merge_cols_kernel -- same expression, same bits):
+// out = h( sum_s w_s o_s / sum_s w_s l_s ), w_s = e^(m_s - M), splits in order.
+__global__ __launch_bounds__(256) void paged_attention_generic_merge_kernel(const float* __restrict__ ws_o,
+                                                                            const float* __restrict__ ws_ml, int S, int d,
+                                                                            f16* __restrict__ out, const int32_t* __restrict__ q_start,
+                                                                            int n_seqs, int nq) {
+    const size_t th = blockIdx.x;   // token * nq + head
+    if ((int)(th / nq) >= q_start[n_seqs]) return;   // the grid covers n_seqs * max_q_len tokens, `out` the real ones
+    const float* mlb = ws_ml + th * S * 2;
+    float M = -__builtin_inff();
+    for (int s2 = 0; s2 < S; s2++) M = fmaxf(M, mlb[s2 * 2]);
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float num = 0.0f, den = 0.0f;
+        for (int s2 = 0; s2 < S; s2++) {
+            const float m = mlb[s2 * 2];
+            const float w = m == -__builtin_inff() ? 0.0f : aexp(m - M);
+            den = __builtin_fmaf(w, mlb[s2 * 2 + 1], den);
+            num = __builtin_fmaf(w, ws_o[(th * S + s2) * d + c], num);
+        }
+        out[th * d + c] = f2h(num / den);
+    }
+}
+// context splits the generic-head-size kernel uses for a caller's n_splits (shared with the merge in hadamard.hip)
+int paged_attention_generic_splits(int n_splits) { return n_splits < 1 ? 1 : (n_splits > 4 ? 4 : n_splits); }   // (TinyLlama bs = 1, 512 / 1900 keys: 1: 4.61 / 6.27 ms per cycle, 2: 4.30 / 5.08, 4: 4.25 / 4.77, 8: 4.46 / 4.78)
+
 size_t paged_attention_ws_o_offset() { return QS_ATT_CNT_SLOTS; }
 size_t paged_attention_ws_ml_offset(int Tmax, int nq, int d, int n_splits) {
     return QS_ATT_CNT_SLOTS + (size_t)Tmax * nq * n_splits * d;
@@ -1313,10 +1352,13 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
     // out == nullptr: leave the per-split partials (o, m, l) in the workspace for heads_hadamard_merge
     if (n_seqs == 0) return 0;
     if (nq % nkv) return -1;
-    if (d != 128) {   // plumbing path (e.g. TinyLlama's 64): no split, no partials -> needs `out`
-        if (!out || d > 256 || d % 2) return -1;
-        int max_ctx_bytes = 64 * 1024;   // scores of one row in LDS: contexts up to 16 K keys
-        if (d % 8 == 0 && d >= 8) {       // vector loads; + one chunk of V rows (<= 256 x 16 B)
+    if (d != 128) {   // other head sizes (TinyLlama's 64): no matrix cores; context splits + a merge (here or in the head transform)
+        if (d > 256 || d % 2) return -1;
+        const int max_ctx_bytes = 64 * 1024;   // scores of one row in LDS: contexts up to 16 K keys
+        if (d % 8 == 0 && d >= 8) {             // vector loads
+            if (n_splits < 1 || n_splits > QS_ATT_MAXSPLIT) return -3;
+            const int S = paged_attention_generic_splits(n_splits);
+            if (!out && !ws) return -1;
             static bool attr_set = false;
             if (!attr_set) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_generic_vec_kernel),
@@ -1324,11 +1366,19 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
                     return -8;
                 attr_set = true;
             }
-            hipLaunchKernelGGL(paged_attention_generic_vec_kernel, dim3(n_seqs * max_q_len, nq), dim3(256), max_ctx_bytes + 32768 + 16,
+            const size_t Tm = (size_t)n_seqs * max_q_len;
+            const bool partials = !out || S > 1;
+            float* ws_o = partials ? ws + paged_attention_ws_o_offset() : nullptr;
+            float* ws_ml = partials ? ws + paged_attention_ws_ml_offset((int)Tm, nq, d, S) : nullptr;
+            hipLaunchKernelGGL(paged_attention_generic_vec_kernel, dim3(n_seqs * max_q_len, nq, S), dim3(256), max_ctx_bytes + 32768 + 16,
                                st, q, q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, n_seqs, nq,
-                               nkv, d, block_size, sm_scale, out);
+                               nkv, d, block_size, sm_scale, out, ws_o, ws_ml);
+            if (out && partials)
+                hipLaunchKernelGGL(paged_attention_generic_merge_kernel, dim3((unsigned)(Tm * nq)), dim3(256), 0, st, ws_o, ws_ml, S, d,
+                                   out, q_start, n_seqs, nq);
             return 0;
         }
+        if (!out) return -1;
         hipLaunchKernelGGL(paged_attention_generic_kernel, dim3(n_seqs * max_q_len, nq), dim3(128), max_ctx_bytes, st, q,
                            q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, n_seqs, nq, nkv,
                            d, block_size, sm_scale, out);

@@ -298,8 +298,8 @@ int qspec_paged_attention(const qspec_half* q, int64_t q_stride, const qspec_hal
     if (n_seqs == 0 || tokens == 0) return 0;
     NONNULL(op, q); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, block_tables); NONNULL(op, ctx_lens);
     NONNULL(op, q_start); NONNULL(op, workspace);   /* out == NULL: partials only, see qspec_heads_hadamard_merged */
-    if (head_size != 128 && (!out || head_size > 256 || head_size % 2))
-        return fail("%s: head_size=%d: the matrix-core kernel is built for 128; other sizes <= 256 run the generic kernel, which needs `out`", op, head_size);
+    if (head_size != 128 && (head_size > 256 || head_size % 2 || (!out && head_size % 8)))
+        return fail("%s: head_size=%d: the matrix-core kernel is built for 128; other even sizes <= 256 run the generic kernel (partials, out = NULL: multiples of 8)", op, head_size);
     if (tokens > n_seqs * max_q_len) return fail("%s: tokens=%d > n_seqs*max_q_len=%d", op, tokens, n_seqs * max_q_len);
     int rc = qspec::paged_attention(CH(q), q_stride, CH(key_cache), CH(value_cache), block_tables, max_blocks_per_seq, ctx_lens, q_start, n_seqs, max_q_len, num_heads, num_kv_heads, head_size, block_size, sm_scale, n_splits, (float*)workspace, H(out), ST);
     return finish(op, rc);
@@ -312,9 +312,9 @@ int qspec_heads_hadamard_merged(const void* attn_workspace, int max_tokens, int 
     if (tokens == 0) return 0;
     NONNULL(op, attn_workspace);
     if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
-    if (head_dim != 128 || !(heads == 32 || heads == 64))
-        return fail("%s: built for head_dim 128 and 32 / 64 heads (got %d x %d)", op, heads, head_dim);
-    if (g_xp && (q || heads != 32 || tokens > 16))
+    if (!((head_dim == 128 && (heads == 32 || heads == 64)) || (heads == 32 && head_dim % 8 == 0 && head_dim >= 8 && head_dim <= 256)))
+        return fail("%s: built for 32 / 64 heads of 128 and 32 heads of another size %% 8 == 0 (got %d x %d)", op, heads, head_dim);
+    if (g_xp && (q || heads != 32 || tokens > 16 || head_dim != 128))
         return fail("%s: the fragment-major fp16 output exists for 32 heads, <= 16 tokens, no quantiser", op);
     return finish(op, qspec::heads_hadamard_merge((const float*)attn_workspace, max_tokens, n_splits, H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, heads, head_dim, ST, g_xp));
 }

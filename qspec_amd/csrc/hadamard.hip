@@ -678,12 +678,143 @@ int heads_hadamard_mix_merge_spread(const float* ws, int max_tokens, int n_split
     return 0;
 }
 
+// heads_hadamard_kernel with the split merge of the generic-head-size attention kernel (attention.hip:
+// paged_attention_generic_vec_kernel, head sizes other than 128 -- TinyLlama's 64) in front of it: 512 threads merge
+// (head, four columns) items -- out = h(sum_s w_s o_s / sum_s w_s l_s), w_s = e^(m_s - M), splits in order: the expression of
+// paged_attention_generic_merge_kernel, so the same fp16 rows -- into LDS, then the first d / 2 lanes run
+// heads_hadamard_kernel's transform on them (same arithmetic: same bits as merge -> heads_hadamard).
+template <int NH, bool QUANT>
+__global__ __launch_bounds__(512) void heads_hadamard_merge_cols_kernel(const float* __restrict__ ws_o,
+                                                                        const float* __restrict__ ws_ml, int S,
+                                                                        f16* __restrict__ out16, int8_t* __restrict__ q,
+                                                                        f16* __restrict__ scale, float had_scale, float clip,
+                                                                        int d) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f16* al = reinterpret_cast<f16*>(smem_raw);   // [NH][d]
+    __shared__ float red[4];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int per_head = d >> 2;
+    for (int it = tid; it < NH * per_head; it += 512) {
+        const int head = it / per_head, c0 = (it - head * per_head) * 4;
+        const size_t th = (size_t)t * NH + head;
+        const float* mlb = ws_ml + th * S * 2;
+        const float* ob = ws_o + th * S * d + c0;
+        // S <= 4 (paged_attention_generic_splits; 8 slots): every load of the item in flight before the first use
+        constexpr int SMAX = 8;
+        float2 ml[SMAX];
+        f32x4 o[SMAX];
+#pragma unroll
+        for (int s2 = 0; s2 < SMAX; s2++) {
+            const int sc = min(s2, S - 1);
+            ml[s2] = *reinterpret_cast<const float2*>(mlb + sc * 2);
+            o[s2] = *reinterpret_cast<const f32x4*>(ob + (size_t)sc * d);
+        }
+        float M = -__builtin_inff();
+#pragma unroll
+        for (int s2 = 0; s2 < SMAX; s2++) M = fmaxf(M, s2 < S ? ml[s2].x : -__builtin_inff());
+        f32x4 num = f32x4{0.f, 0.f, 0.f, 0.f};
+        float den = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < SMAX; s2++) {
+            if (s2 < S) {
+                const float w = ml[s2].x == -__builtin_inff() ? 0.0f : aexp(ml[s2].x - M);
+                den = __builtin_fmaf(w, ml[s2].y, den);
+#pragma unroll
+                for (int e = 0; e < 4; e++) num[e] = __builtin_fmaf(w, o[s2][e], num[e]);
+            }
+        }
+        f16x4 h4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) h4[e] = f2h(num[e] / den);
+        *reinterpret_cast<f16x4*>(al + (size_t)head * d + c0) = h4;
+    }
+    __syncthreads();
+    const int TT = ((d / 2 + 63) / 64) * 64;       // transform threads (whole waves), as heads_hadamard's launch
+    if (tid >= TT) return;
+    const int j = tid;
+    const bool act = 2 * j < d;
+    float v0[NH], v1[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        f16x2 a = {(f16)0.0f, (f16)0.0f};
+        if (act) a = *reinterpret_cast<const f16x2*>(al + (size_t)h * d + 2 * j);
+        v0[h] = h2f(a[0]);
+        v1[h] = h2f(a[1]);
+    }
+#pragma unroll
+    for (int stride = 1; stride < NH; stride <<= 1) {
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            if (!(h & stride)) {
+                float a = v0[h], b = v0[h + stride];
+                v0[h] = a + b;
+                v0[h + stride] = a - b;
+                a = v1[h];
+                b = v1[h + stride];
+                v1[h] = a + b;
+                v1[h + stride] = a - b;
+            }
+        }
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        v0[h] = h2f(f2h(v0[h] * had_scale));
+        v1[h] = h2f(f2h(v1[h] * had_scale));
+        if (QUANT) {
+            float a0 = __builtin_fabsf(v0[h]), a1 = __builtin_fabsf(v1[h]);
+            amax = a0 > amax ? a0 : amax;
+            amax = a1 > amax ? a1 : amax;
+        }
+    }
+    if (!QUANT) {
+        if (!act) return;
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            f16x2 o = {f2h(v0[h]), f2h(v1[h])};
+            *reinterpret_cast<f16x2*>(out16 + (size_t)t * NH * d + (size_t)h * d + 2 * j) = o;
+        }
+        return;
+    }
+    amax = wave_max_f(amax);
+    if (TT > 64) {   // (the retired waves take no part in this barrier)
+        if ((j & 63) == 0) red[j >> 6] = amax;
+        __syncthreads();
+        amax = fmaxf(red[0], red[1]);
+    }
+    const f16 sc = f2h(h2f(f2h(amax / 7.0f)) * h2f(f2h(clip)));
+    const float scf = h2f(sc);
+    const float rcf = 1.0f / scf;
+    if (j == 0) scale[t] = sc;
+    if (!act) return;
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        int q0 = rni_sat(h2f(f2h(div3_h(v0[h], rcf, scf))), -8, 7);
+        int q1 = rni_sat(h2f(f2h(div3_h(v1[h], rcf, scf))), -8, 7);
+        q[((size_t)t * NH * d + (size_t)h * d + 2 * j) / 2] = (int8_t)pack_nib(q0, q1);
+    }
+}
+
 // partials: the workspace of paged_attention(..., out = nullptr) called for `max_tokens` = n_seqs * max_q_len tokens
 int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out_f16, int8_t* q, f16* scale,
                          float had_scale, float clip, int T, int heads, int d, hipStream_t st, int xp) {
     if (T == 0) return 0;
-    if (xp && (q != nullptr || heads != 32 || T > 16)) return -1;   // fragment-major fp16 rows: the spread 32-head form only
-    if (d != 128 || !(heads == 32 || heads == 64) || n_splits < 1 || T > max_tokens) return -1;
+    if (xp && (q != nullptr || heads != 32 || T > 16 || d != 128)) return -1;   // fragment-major fp16 rows: the spread 32-head form only
+    if (d != 128) {   // generic head sizes (TinyLlama: 32 heads of 64): partials of paged_attention_generic_vec_kernel
+        if (heads != 32 || d % 8 || d < 8 || d > 256 || n_splits < 1 || T > max_tokens) return -1;
+        const int S = paged_attention_generic_splits(n_splits);
+        const float* go = ws + paged_attention_ws_o_offset();
+        const float* gml = ws + paged_attention_ws_ml_offset(max_tokens, heads, d, S);
+        const size_t lds = (size_t)heads * d * sizeof(f16);
+        if (q)
+            hipLaunchKernelGGL((heads_hadamard_merge_cols_kernel<32, true>), dim3(T), dim3(512), lds, st, go, gml, S, out_f16, q, scale,
+                               had_scale, clip, d);
+        else
+            hipLaunchKernelGGL((heads_hadamard_merge_cols_kernel<32, false>), dim3(T), dim3(512), lds, st, go, gml, S, out_f16, q, scale,
+                               had_scale, clip, d);
+        return 0;
+    }
+    if (!(heads == 32 || heads == 64) || n_splits < 1 || T > max_tokens) return -1;
     const float* ws_o = ws + paged_attention_ws_o_offset();
     const float* ws_ml = ws + paged_attention_ws_ml_offset(max_tokens, heads, d, n_splits);
     const bool quant = q != nullptr;

@@ -148,6 +148,7 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
                     float* ws, f16* out, hipStream_t st);
 size_t paged_attention_ws_bytes(int T, int nq, int d, int n_splits);
 size_t paged_attention_ws_o_offset();
+int paged_attention_generic_splits(int n_splits);   // head sizes other than 128: the splits actually used for a caller's n_splits
 size_t paged_attention_ws_ml_offset(int Tmax, int nq, int d, int n_splits);
 
 // sampler.hip

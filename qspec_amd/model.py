@@ -225,8 +225,9 @@ class QuarotLlamaForCausalLM:
         cfg = self.config
         nh = cfg.num_attention_heads
         B = md.ctx_lens.numel()
-        merged = (self.MERGE_IN_HADAMARD and cfg.head_dim == 128 and nh in (32, 64) and md.n_splits <= 64
-                  and self.head_had_K == 1)
+        # (other head sizes -- TinyLlama's 64 -- leave their split partials to the same launch when there are 32 heads)
+        merged = (self.MERGE_IN_HADAMARD and md.n_splits <= 64 and self.head_had_K == 1
+                  and ((cfg.head_dim == 128 and nh in (32, 64)) or (cfg.head_dim != 128 and cfg.head_dim % 8 == 0 and nh == 32)))
         # head count with a table factor (40 heads = had40): the split merge + transform spread over 8 workgroups per token
         mix_merged = (self.MERGE_IN_HADAMARD and self.head_had_K > 1 and md.n_splits <= 64
                       and ops.heads_hadamard_mix_merged_spread_supported(T, nh, cfg.head_dim, self.head_had_K))

@@ -693,6 +693,27 @@ def test_paged_attention_generic_head_size_within_1e3(ops, oracle, ctx_lens, q_l
     out = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
     ops.paged_attention(dev(qkv), row, dev(kc), dev(vc), dev(bt), dev(ctx), dev(q_start), T, q_len, nq, scale, 1, ws, out)
     assert_close_1e3(host(out), ref)
+    # context splits (min(n_splits, 4) of whole 16-key groups; some of them empty for the short sequences) + the merge launch
+    for n_splits in (3, 16):
+        ws = torch.zeros(ops.paged_attention_workspace_bytes(T, nq, d, n_splits), dtype=torch.uint8, device=DEV)
+        out_s = torch.full((T + 1, nq * d), 7.0, dtype=torch.float16, device=DEV)
+        ops.paged_attention(dev(qkv), row, dev(kc), dev(vc), dev(bt), dev(ctx), dev(q_start), T, q_len, nq, scale, n_splits, ws, out_s[:T])
+        assert_close_1e3(host(out_s[:T]), ref)
+        assert torch.all(out_s[T] == 7.0)
+        if nq == 32 and d % 8 == 0:   # partials left to the head transform: the bits of merge launch -> heads_hadamard
+            had_scale = oracle.rsqrt_scale(nq)
+            o0 = torch.empty(T, nq * d, dtype=torch.float16, device=DEV); o1 = torch.empty_like(o0)
+            q0 = torch.empty(T, nq * d // 2, dtype=torch.int8, device=DEV); s0 = torch.empty(T, dtype=torch.float16, device=DEV)
+            q1 = torch.empty_like(q0); s1 = torch.empty_like(s0)
+            ops.heads_hadamard(out_s[:T].contiguous(), had_scale, out_f16=o0, heads=nq)
+            ops.heads_hadamard(out_s[:T].contiguous(), had_scale, q=q0, scale=s0, heads=nq)
+            ws2 = torch.zeros_like(ws)
+            ops.paged_attention(dev(qkv), row, dev(kc), dev(vc), dev(bt), dev(ctx), dev(q_start), T, q_len, nq, scale, n_splits, ws2, None)
+            ops.heads_hadamard_merged(ws2, T, n_splits, T, nq, d, had_scale, out_f16=o1)
+            ops.heads_hadamard_merged(ws2, T, n_splits, T, nq, d, had_scale, q=q1, scale=s1)
+            torch.cuda.synchronize()
+            assert torch.equal(o0.view(torch.int16), o1.view(torch.int16))
+            assert torch.equal(q0, q1) and torch.equal(s0.view(torch.int16), s1.view(torch.int16))
 
 
 @pytest.mark.parametrize("ctx_lens,q_len,n_splits", [([37, 128, 129, 500], 1, 8), ([37, 130, 260, 515], 4, 5),
@@ -1571,8 +1592,6 @@ def test_paged_attention_reference_fixture_within_1e3(ops, golden_dir, idx, n_sp
     T = c["q"].shape[0]
     nq = c["q"].shape[1] // d
     q_lens = np.diff(c["q_start"])
-    if d != 128:
-        n_splits = 1                              # the generic head-size kernel has no context split
     ws = torch.zeros(ops.paged_attention_workspace_bytes(len(q_lens) * int(q_lens.max()), nq, d, n_splits),
                      dtype=torch.uint8, device=DEV)
     out = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
