@@ -2216,7 +2216,7 @@ static bool stream16_shape(int K, int* NW, int* UB) {
     // (16 waves x 112 VGPRs would leave nothing else); that layer stays on gemm.hip's 2-D kernel
     // (4, 9) = K 4608: a third of Llama-2-13B's down_proj (13824 = 3 x 4608, gemm_w4a16_stream_partial_slices); the
     // activation staging buffer is 2 x 16 rows x NW x 512 B, so NW stays <= 8 (12 waves x 3 steps would need 222 KB of LDS)
-    static const int cand[][2] = {{8, 4}, {8, 8}, {8, 5}, {4, 4}, {4, 2}, {8, 7}, {4, 7}, {4, 1}, {4, 9}};
+    static const int cand[][2] = {{8, 4}, {8, 8}, {8, 5}, {4, 4}, {4, 2}, {8, 7}, {4, 7}, {4, 1}, {4, 9}, {4, 11}};   // (4, 11) = K 5632: TinyLlama's down_proj
     if (K % 128) return false;
     for (const auto& c : cand)
         if (K / 128 == c[0] * c[1]) {
@@ -2237,7 +2237,7 @@ static int launch_stream16(const StreamArgs& a, hipStream_t st) {
     int NW, UB;
     if (a.M < 1 || a.M > 16 || !stream16_shape(a.K, &NW, &UB)) return -1;
 #define QS_S16(NWV, UBV) if (NW == NWV && UB == UBV) return launch_stream16_inst<EPI, NWV, UBV>(a, st);
-    QS_S16(8, 4) QS_S16(8, 8) QS_S16(8, 5) QS_S16(4, 4) QS_S16(4, 2) QS_S16(8, 7) QS_S16(4, 7) QS_S16(4, 1) QS_S16(4, 9)
+    QS_S16(8, 4) QS_S16(8, 8) QS_S16(8, 5) QS_S16(4, 4) QS_S16(4, 2) QS_S16(8, 7) QS_S16(4, 7) QS_S16(4, 1) QS_S16(4, 9) QS_S16(4, 11)
 #undef QS_S16
     return -1;
 }

@@ -263,7 +263,7 @@ def assert_close_1e3(got, ref):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 64, 128), (16, 6144, 4096), (16, 4096, 14336), (4, 4096, 4096), (24, 512, 4096),
-                                   (40, 128, 4096)])
+                                   (40, 128, 4096), (4, 2048, 5632), (16, 2048, 5632)])
 def test_w4a16_gemm_within_1e3(ops, oracle, M, N, K):
     rng = np.random.default_rng(M + N + K)
     x = rand_hidden(rng, M, K)
