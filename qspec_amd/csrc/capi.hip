@@ -684,12 +684,23 @@ int qspec_ln_gate_up_silu_linear_s4s4(const qspec_half* hidden_in, const qspec_h
     return finish(op, qspec::gemm_w4a4_stream_gate_up_silu(x, wq, CH(ws), H(act), M, intermediate, K, ST));
 }
 size_t qspec_ln_linear_workspace_bytes(void) { return qspec::gemm_w4a4_stream_sync_bytes(); }
-int qspec_w4a16_linear_partial_slices(int M, int N, int K) { return use_stream() ? qspec::gemm_w4a16_stream_partial_slices(M, N, K) : 0; }
+int qspec_w4a16_linear_partial_slices(int M, int N, int K) {
+    if (M > 16)   // the M-tiled kernel's launch plan (narrow layers at a few dozen to a few hundred tokens)
+        return M >= tiled_min_m() ? qspec::gemm_w4a16_tiled_partial_slices(M, N, K) : 0;
+    return use_stream() ? qspec::gemm_w4a16_stream_partial_slices(M, N, K) : 0;
+}
 int qspec_w4a16_linear_partial(const qspec_half* x, const int8_t* wq, float* part, int M, int N, int K, int slices,
                                void* stream) {
     const char* op = "qspec_w4a16_linear_partial";
     if (M == 0 || N == 0) return 0;
     NONNULL(op, x); NONNULL(op, wq); NONNULL(op, part);
+    if (M > 16) {
+        if (g_xp) return fail("%s: the fragment-major layout is a 16-row tile (M=%d)", op, M);
+        if (slices < 2 || slices != qspec_w4a16_linear_partial_slices(M, N, K))
+            return fail("%s: (M=%d N=%d K=%d) takes %d slices (qspec_w4a16_linear_partial_slices), got %d", op, M, N, K,
+                        qspec_w4a16_linear_partial_slices(M, N, K), slices);
+        return finish(op, qspec::gemm_w4a16_tiled_partial(CH(x), wq, part, M, N, K, slices, ST));
+    }
     // the planned count (qspec_w4a16_linear_partial_slices), or -- for shapes that also run unsliced -- any count whose
     // slices the streaming kernel takes (the verify pass's o_proj experiment)
     const int planned = qspec::gemm_w4a16_stream_partial_slices(M, N, K);

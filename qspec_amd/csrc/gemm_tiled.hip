@@ -241,11 +241,33 @@ void gemm_w4a16_tiled_plan(int M, int N, int K, size_t part_bytes, int* MT_out, 
     *S_out = bs;
 }
 
+static int tiled_launch(const f16* x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K, float* part, int MT, int S,
+                        bool finish, hipStream_t st);
 int gemm_w4a16_tiled(const f16* x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K, float* part,
                      size_t part_bytes, hipStream_t st) {
     if (!gemm_w4a16_tiled_supported(M, N, K)) return -1;
     int MT, S;
     gemm_w4a16_tiled_plan(M, N, K, part ? part_bytes : 0, &MT, &S);
+    return tiled_launch(x, wq, ws, out, M, N, K, part, MT, S, true, st);
+}
+// The plan's K slices for a caller that finishes the raw sums itself (the verify pass: inside the norm that follows o_proj /
+// down_proj, norm_quant.hip ln_fp16_partial -- the expression of gemm_w4a16_partial_finish, so the same bits, one launch less):
+// slice count for (M, N, K), 0 = the plan does not slice this shape; then the launch that leaves part [S][M][N].
+int gemm_w4a16_tiled_partial_slices(int M, int N, int K) {
+    if (!gemm_w4a16_tiled_supported(M, N, K)) return 0;
+    int MT, S;
+    gemm_w4a16_tiled_plan(M, N, K, gemm_w4a16_ws_bytes() - 8192, &MT, &S);   // the cap of qspec_w4a16_linear's own workspace: the same plan
+    return S > 1 ? S : 0;
+}
+int gemm_w4a16_tiled_partial(const f16* x, const int8_t* wq, float* part, int M, int N, int K, int S, hipStream_t st) {
+    if (!gemm_w4a16_tiled_supported(M, N, K) || !part) return -1;
+    int MT, PS;
+    gemm_w4a16_tiled_plan(M, N, K, gemm_w4a16_ws_bytes() - 8192, &MT, &PS);
+    if (PS != S || S < 2) return -1;
+    return tiled_launch(x, wq, nullptr, nullptr, M, N, K, part, MT, S, false, st);
+}
+static int tiled_launch(const f16* x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K, float* part, int MT, int S,
+                        bool finish, hipStream_t st) {
     // two weight tiles per wave when that still leaves two workgroups per CU (large M): halves the LDS reads per MFMA
     static const int force_nt = env_int("QSPEC_TILED_NT", 0);
     const int mblocks = (M + 32 * MT - 1) / (32 * MT);
@@ -276,7 +298,7 @@ int gemm_w4a16_tiled(const f16* x, const int8_t* wq, const f16* ws, f16* out, in
         default: return -1;
     }
 #undef QS_TILED
-    if (S > 1) return gemm_w4a16_partial_finish(part, ws, out, M, N, S, st);
+    if (S > 1 && finish) return gemm_w4a16_partial_finish(part, ws, out, M, N, S, st);
     return 0;
 }
 

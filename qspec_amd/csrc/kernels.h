@@ -120,6 +120,8 @@ int gemm_w4a16_stream_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws
 // gemm_tiled.hip: W4A16 for prefill-sized M (tiles of 32..128 tokens x 128 weight rows, 32x32x16 MFMA)
 bool gemm_w4a16_tiled_supported(int M, int N, int K);
 // part (may be NULL): part_bytes of fp32 scratch for the K-sliced plan of narrow layers
+int gemm_w4a16_tiled_partial_slices(int M, int N, int K);
+int gemm_w4a16_tiled_partial(const f16* x, const int8_t* wq, float* part, int M, int N, int K, int S, hipStream_t st);
 int gemm_w4a16_tiled(const f16* x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K, float* part,
                      size_t part_bytes, hipStream_t st);
 

@@ -99,7 +99,8 @@ class Scratch:
         self.act_buffer_had_mlp = e(T, I)
         self.logits = e(T if logits_rows is None else logits_rows, cfg.vocab_size)
         # verify pass: raw fp32 K-slice sums of down_proj, finished inside the next norm (ops.w4a16_linear_partial)
-        self.down_part = e(4, T, H, dtype=torch.float32) if T <= 16 else None
+        # (17..256 tokens: the M-tiled kernel's plan slices narrow layers up to eight ways)
+        self.down_part = e(4 if T <= 16 else 8, T, H, dtype=torch.float32) if T <= 256 else None
         # verify pass at <= 16 tokens: fragment-major 16-row activation tiles between the producers and the W4A16 GEMMs
         # (ops.w4a16_act_layout_supported); rows past T are never read back into a result
         z = lambda k: torch.zeros(16, k, dtype=f16, device=device)  # noqa: E731
@@ -216,6 +217,7 @@ class QuarotLlamaForCausalLM:
                     and ops.w4a16_act_layout_supported(T, cfg.q_size) and ops.w4a16_act_layout_supported(T, down_k)
                     and ops.mlp_hadamard_act_layout_supported(T, I, self.had_K))
 
+    TILED_PARTIAL_IN_NORM = __import__("os").environ.get("QSPEC_TILED_PARTIAL_IN_NORM", "1") != "0"
     MERGE_IN_HADAMARD = True   # False: the attention kernel merges its context splits itself (ticket + fences)
     DOWN_K_SLICES = __import__("os").environ.get("QSPEC_DOWN_K_SLICES", "1") != "0"   # draft down_proj at 17..32 tokens as K slices
 
@@ -379,8 +381,17 @@ class QuarotLlamaForCausalLM:
                     ops.w4a16_linear_partial(had, layer.o_proj.weight, part, S)
                     ops.add_rms_norm_fp16_partial(normed, hidden, hidden, part, layer.o_proj._scales(), S, eps)
                 else:
-                    self._w4a16(had, layer.o_proj, o)
-                    ops.add_rms_norm_fp16(normed, hidden, hidden, o, eps)
+                    # 17+ tokens: where the M-tiled kernel's plan slices K (narrow layers), the raw sums are finished inside
+                    # the norm instead of by a finishing launch of their own (same expression, same bits)
+                    S_o = (ops.w4a16_linear_partial_slices(T, cfg.hidden_size, cfg.q_size)
+                           if (T > 16 and s.down_part is not None and self.TILED_PARTIAL_IN_NORM) else 0)
+                    if 1 < S_o <= 8:
+                        part = s.down_part.view(-1)[:S_o * T * cfg.hidden_size].view(S_o, T, cfg.hidden_size)
+                        ops.w4a16_linear_partial(had, layer.o_proj.weight, part, S_o)
+                        ops.add_rms_norm_fp16_partial(normed, hidden, hidden, part, layer.o_proj._scales(), S_o, eps)
+                    else:
+                        self._w4a16(had, layer.o_proj, o)
+                        ops.add_rms_norm_fp16(normed, hidden, hidden, o, eps)
                 x, xs = normed, None
             # gate_up -> silu*up -> online hadamard (+ quant) -> down_proj                              :266-299
             if fuse:
@@ -423,9 +434,11 @@ class QuarotLlamaForCausalLM:
                 continue
             else:
                 S = 0
-                if fuse and s.down_part is not None:   # long K at decode-sized M: K slices, finished by the next norm
+                if s.down_part is not None and (fuse or (T > 16 and self.TILED_PARTIAL_IN_NORM)):
+                    # long K at decode-sized M (streaming kernel) / narrow layer at 17+ tokens (M-tiled kernel's plan):
+                    # K slices, finished by the next norm
                     S = ops.w4a16_linear_partial_slices(T, cfg.hidden_size, cfg.intermediate_size)
-                if 0 < S <= 4:
+                if 0 < S <= (4 if T <= 16 else 8):
                     part = s.down_part.view(-1)[:S * T * cfg.hidden_size].view(S, T, cfg.hidden_size)
                     ops.w4a16_linear_partial(had_mlp_in, layer.down_proj.weight, part, S, xp=xp, tokens=T)
                     delta = ("partial", part, layer.down_proj._scales(), S)

@@ -1063,6 +1063,41 @@ def test_w4a16_long_k_slices_and_norm_finish(ops, oracle, M, N, K):
         assert torch.equal(n0.view(torch.int16), n1.view(torch.int16))
 
 
+@pytest.mark.parametrize("M,N,K", [(32, 4096, 4096), (32, 8192, 8192), (192, 4096, 14336), (32, 4096, 14336), (64, 5120, 13824),
+                                   (192, 4096, 4096), (100, 1024, 4096)])
+def test_w4a16_tiled_plan_slices_finished_in_the_norm(ops, oracle, M, N, K):
+    """17+ tokens: where the M-tiled kernel's launch plan cuts K into slices, the verify pass leaves their raw fp32 sums to the
+    norm that follows (hidden = x + h(sum * ws), LN) instead of a finishing launch: the same bits as w4a16_linear followed by
+    add_rms_norm_fp16, and the GEMM within 1e-3 of the oracle.  A shape the plan does not slice answers 0."""
+    rng = np.random.default_rng(M + N + K)
+    x = rand_hidden(rng, M, K)
+    wq = dev(oracle.pack_i4(rand_w4(rng, N, K)))
+    ws_np = (rng.random(N) * 0.002 + 0.0005).astype(np.float16)
+    ws = dev(ws_np)
+    S = ops.w4a16_linear_partial_slices(M, N, K)
+    assert S == 0 or 2 <= S <= 8
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.w4a16_linear(dev(x), wq, ws, out)
+    if M <= 64:
+        assert_close_1e3(host(out), oracle.gemm_w4a16(x, host(wq), ws_np))
+    if S == 0:
+        with pytest.raises(RuntimeError):
+            ops.w4a16_linear_partial(dev(x), wq, torch.empty(2, M, N, dtype=torch.float32, device=DEV), 2)
+        return
+    part = torch.empty(S, M, N, dtype=torch.float32, device=DEV)
+    ops.w4a16_linear_partial(dev(x), wq, part, S)
+    hidden = dev(rand_hidden(rng, M, N))
+    n0 = torch.empty_like(hidden); h0 = torch.empty_like(hidden)
+    ops.add_rms_norm_fp16(n0, h0, hidden, out, 1e-5)
+    n1 = torch.empty_like(hidden); h1 = torch.empty_like(hidden)
+    ops.add_rms_norm_fp16_partial(n1, h1, hidden, part, ws, S, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(h0.view(torch.int16), h1.view(torch.int16))
+    assert torch.equal(n0.view(torch.int16), n1.view(torch.int16))
+    with pytest.raises(RuntimeError):   # another count than the plan's
+        ops.w4a16_linear_partial(dev(x), wq, torch.empty(S + 1, M, N, dtype=torch.float32, device=DEV), S + 1)
+
+
 @pytest.mark.parametrize("M,N,K,world", [(16, 4096, 4096, 8), (16, 4096, 14336, 8), (4, 1024, 3584, 2)])
 def test_w4a16_ksliced_partials_sum_to_full(ops, oracle, M, N, K, world):
     from qspec_amd.parallel import shard_range
