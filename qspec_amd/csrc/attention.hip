@@ -1370,7 +1370,13 @@ int paged_attention(const f16* q, int64_t q_stride, const f16* key_cache, const 
             const bool partials = !out || S > 1;
             float* ws_o = partials ? ws + paged_attention_ws_o_offset() : nullptr;
             float* ws_ml = partials ? ws + paged_attention_ws_ml_offset((int)Tm, nq, d, S) : nullptr;
-            hipLaunchKernelGGL(paged_attention_generic_vec_kernel, dim3(n_seqs * max_q_len, nq, S), dim3(256), max_ctx_bytes + 32768 + 16,
+            // LDS: the scores of one split (the block table bounds a context: max_blocks * block_size keys) + the [RG][d] fp32
+            // partial rows of the P.V pass (<= 8 KiB) -- sized to the launch, so that several workgroups share a CU (with the
+            // 96 KB of a 16 K-key context every launch ran one workgroup per CU: the verify pass's 512 in two rounds)
+            const size_t per = (((size_t)max_blocks * block_size + S - 1) / S + 15) & ~(size_t)15;
+            if (per * 4 > (size_t)max_ctx_bytes) return -2;
+            const size_t lds = ((per * 4 + 15) & ~(size_t)15) + 8192 + 16;
+            hipLaunchKernelGGL(paged_attention_generic_vec_kernel, dim3(n_seqs * max_q_len, nq, S), dim3(256), lds,
                                st, q, q_stride, key_cache, value_cache, block_tables, max_blocks, ctx_lens, q_start, n_seqs, nq,
                                nkv, d, block_size, sm_scale, out, ws_o, ws_ml);
             if (out && partials)
