@@ -467,15 +467,39 @@ struct TkRow {      // what pass 3 needs of a row
     int greedy;
     int pad[3];
 };
-__global__ __launch_bounds__(256) void topk_hist_kernel(const f16* __restrict__ logits, uint32_t* __restrict__ hist, int V) {
-    const int c = blockIdx.x, t = blockIdx.y;
-    int lo, hi;
-    sm_chunk_range(V, c, lo, hi);
+// One workgroup per (row, eighth of the vocabulary): a PRIVATE histogram of all 65536 keys in LDS -- 16-bit counters packed two
+// to a dword (an eighth of a 128 K vocabulary cannot overflow one; larger vocabularies take more chunks) -- then only the non-zero
+// counters go to the row's histogram in memory: a few thousand integer atomics per workgroup instead of one per logit (the first
+// form: 38.6 us per launch at 4 rows, 79 at 16).  Integer adds: the histogram does not depend on the order.
+#define QS_TK_HCHUNK 16384   // logits per workgroup (< 65536)
+__global__ __launch_bounds__(1024) void topk_hist_kernel(const f16* __restrict__ logits, uint32_t* __restrict__ hist, int V) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lh[];   // [32768] = 65536 16-bit counters
+    const int c = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    uint4* lz = reinterpret_cast<uint4*>(lh);
+#pragma unroll
+    for (int i = 0; i < 8; i++) lz[tid + 1024 * i] = uint4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    const int lo = c * QS_TK_HCHUNK, hi = min(V, lo + QS_TK_HCHUNK);
     const f16* l = logits + (size_t)t * V;
-    uint32_t* h = hist + (size_t)t * QS_TK_KEYS;
-    for (int v = lo + threadIdx.x; v < hi; v += 256) {
+    for (int v = lo + tid; v < hi; v += 1024) {
         const f16 x = l[v];
-        if (x == x) atomicAdd(h + tk_key(x), 1u);   // (a NaN logit takes no part)
+        if (x == x) {   // (a NaN logit takes no part)
+            const uint32_t key = tk_key(x);
+            atomicAdd(lh + (key >> 1), (key & 1u) ? 65536u : 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* h = hist + (size_t)t * QS_TK_KEYS;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int q = tid + 1024 * i;
+        const uint4 v = lz[q];
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (w4[e] & 0xFFFFu) atomicAdd(h + 8 * q + 2 * e, w4[e] & 0xFFFFu);
+            if (w4[e] >> 16) atomicAdd(h + 8 * q + 2 * e + 1, w4[e] >> 16);
+        }
     }
 }
 __global__ __launch_bounds__(1024) void topk_select_kernel(uint32_t* __restrict__ hist, const float* __restrict__ temperature,
@@ -705,7 +729,14 @@ int sample_top_k_top_p(const f16* logits, const float* temperature, const int32_
     uint32_t* hist = reinterpret_cast<uint32_t*>(ws);
     TkRow* rows = reinterpret_cast<TkRow*>(reinterpret_cast<char*>(ws) + (size_t)T * QS_TK_KEYS * 4);
     SmPartA* part_a = reinterpret_cast<SmPartA*>(reinterpret_cast<char*>(rows) + (size_t)T * sizeof(TkRow));
-    hipLaunchKernelGGL(topk_hist_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, logits, hist, V);
+    static bool hist_attr = false;
+    if (!hist_attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                QS_TK_KEYS * 2) != hipSuccess)
+            return -8;
+        hist_attr = true;
+    }
+    hipLaunchKernelGGL(topk_hist_kernel, dim3((V + QS_TK_HCHUNK - 1) / QS_TK_HCHUNK, T), dim3(1024), QS_TK_KEYS * 2, st, logits, hist, V);
     hipLaunchKernelGGL(topk_select_kernel, dim3(T), dim3(1024), 0, st, hist, temperature, top_k, top_p, rows, V);
     hipLaunchKernelGGL(topk_write_kernel, dim3(QS_SM_CHUNKS, T), dim3(256), 0, st, logits, rows, exponential, seed, offset,
                        rng_state, probs, part_a, V);
