@@ -459,6 +459,26 @@ int qspec_spec_prepare_verify(int batch, int k, int block_size, int max_blocks_p
                               int64_t block_tables_stride, int64_t* tokens, int64_t* positions, int64_t* slot_mapping,
                               int32_t* ctx_lens, void* stream);
 
+/* The three steps above with the embedding lookup of the forward that follows them (nn.Embedding, quarot_llama.py:484-500:
+ * hidden_out[row] = embed_tokens[token of the row]; a padded row takes row 0) in the same launch: one workgroup per row, the
+ * bookkeeping on its first thread.  Same outputs as the step followed by qspec_embedding.  prepare_draft additionally takes
+ * step_mask (may be NULL): eff_lens[b] = seq_lens[b] * step_mask[b] is written and used in place of seq_lens (slots that sit a
+ * step out count as empty). */
+int qspec_spec_prepare_draft_embed(int batch, int block_size, int max_blocks_per_seq, const int64_t* last_token,
+                                   const int32_t* seq_lens, const int32_t* step_mask, int32_t* eff_lens,
+                                   const int32_t* block_tables, int64_t block_tables_stride, int64_t* input_tokens,
+                                   int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens, const qspec_half* embed_tokens,
+                                   qspec_half* hidden_out, int hidden, int vocab, void* stream);
+int qspec_spec_advance_draft_embed(int batch, int block_size, int max_blocks_per_seq, int64_t* input_tokens,
+                                   const int64_t* sampled_token_ids, int64_t* positions, int32_t* ctx_lens,
+                                   int64_t* slot_mapping, const int32_t* block_tables, int64_t block_tables_stride,
+                                   const qspec_half* embed_tokens, qspec_half* hidden_out, int hidden, int vocab, void* stream);
+int qspec_spec_prepare_verify_embed(int batch, int k, int block_size, int max_blocks_per_seq, const int64_t* last_token,
+                                    const int64_t* draft_token_ids, int64_t ids_stride_b, int64_t ids_stride_k,
+                                    const int32_t* seq_lens, const int32_t* block_tables, int64_t block_tables_stride,
+                                    int64_t* tokens, int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens,
+                                    const qspec_half* embed_tokens, qspec_half* hidden_out, int hidden, int vocab, void* stream);
+
 /* SpecDecodeWorker._create_output_sampler_list bookkeeping (vllm/spec_decode/spec_decode_worker.py:972-1063):
  * append the emitted prefix of out_tokens[b] (-1 = nothing) to gen_tokens[b] (may be NULL), advance seq_lens,
  * last_token = last emitted token. */

@@ -97,6 +97,9 @@ SIGNATURES = {
     "qspec_spec_prepare_draft": (_i, [_i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "qspec_spec_advance_draft": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "qspec_spec_prepare_verify": (_i, [_i, _i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "qspec_spec_prepare_draft_embed": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "qspec_spec_advance_draft_embed": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp]),
+    "qspec_spec_prepare_verify_embed": (_i, [_i, _i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "qspec_spec_commit": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "qspec_spec_snapshot": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "qspec_collect_error_words": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),

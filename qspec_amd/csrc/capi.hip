@@ -484,6 +484,43 @@ int qspec_spec_prepare_verify(int batch, int k, int block_size, int max_blocks_p
     NONNULL(op, tokens); NONNULL(op, positions); NONNULL(op, slot_mapping); NONNULL(op, ctx_lens);
     return finish(op, qspec::spec_prepare_verify(batch, k, block_size, max_blocks_per_seq, last_token, draft_token_ids, ids_stride_b, ids_stride_k, seq_lens, block_tables, block_tables_stride, tokens, positions, slot_mapping, ctx_lens, ST));
 }
+int qspec_spec_prepare_draft_embed(int batch, int block_size, int max_blocks_per_seq, const int64_t* last_token,
+                                   const int32_t* seq_lens, const int32_t* step_mask, int32_t* eff_lens,
+                                   const int32_t* block_tables, int64_t block_tables_stride, int64_t* input_tokens,
+                                   int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens, const qspec_half* embed_tokens,
+                                   qspec_half* hidden_out, int hidden, int vocab, void* stream) {
+    const char* op = "qspec_spec_prepare_draft_embed";
+    if (batch == 0) return 0;
+    NONNULL(op, last_token); NONNULL(op, seq_lens); NONNULL(op, block_tables); NONNULL(op, input_tokens);
+    NONNULL(op, positions); NONNULL(op, slot_mapping); NONNULL(op, ctx_lens); NONNULL(op, embed_tokens); NONNULL(op, hidden_out);
+    if (step_mask && !eff_lens) return fail("%s: step_mask needs eff_lens", op);
+    if (hidden % 8 || hidden <= 0) return fail("%s: hidden=%d must be a positive multiple of 8", op, hidden);
+    return finish(op, qspec::spec_prepare_draft_embed(batch, block_size, max_blocks_per_seq, last_token, seq_lens, step_mask, eff_lens, block_tables, block_tables_stride, input_tokens, positions, slot_mapping, ctx_lens, CH(embed_tokens), H(hidden_out), hidden, vocab, ST));
+}
+int qspec_spec_advance_draft_embed(int batch, int block_size, int max_blocks_per_seq, int64_t* input_tokens,
+                                   const int64_t* sampled_token_ids, int64_t* positions, int32_t* ctx_lens,
+                                   int64_t* slot_mapping, const int32_t* block_tables, int64_t block_tables_stride,
+                                   const qspec_half* embed_tokens, qspec_half* hidden_out, int hidden, int vocab, void* stream) {
+    const char* op = "qspec_spec_advance_draft_embed";
+    if (batch == 0) return 0;
+    NONNULL(op, input_tokens); NONNULL(op, sampled_token_ids); NONNULL(op, positions); NONNULL(op, ctx_lens);
+    NONNULL(op, slot_mapping); NONNULL(op, block_tables); NONNULL(op, embed_tokens); NONNULL(op, hidden_out);
+    if (hidden % 8 || hidden <= 0) return fail("%s: hidden=%d must be a positive multiple of 8", op, hidden);
+    return finish(op, qspec::spec_advance_draft_embed(batch, block_size, max_blocks_per_seq, input_tokens, sampled_token_ids, positions, ctx_lens, slot_mapping, block_tables, block_tables_stride, CH(embed_tokens), H(hidden_out), hidden, vocab, ST));
+}
+int qspec_spec_prepare_verify_embed(int batch, int k, int block_size, int max_blocks_per_seq, const int64_t* last_token,
+                                    const int64_t* draft_token_ids, int64_t ids_stride_b, int64_t ids_stride_k,
+                                    const int32_t* seq_lens, const int32_t* block_tables, int64_t block_tables_stride,
+                                    int64_t* tokens, int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens,
+                                    const qspec_half* embed_tokens, qspec_half* hidden_out, int hidden, int vocab, void* stream) {
+    const char* op = "qspec_spec_prepare_verify_embed";
+    if (batch == 0) return 0;
+    NONNULL(op, last_token); NONNULL(op, draft_token_ids); NONNULL(op, seq_lens); NONNULL(op, block_tables);
+    NONNULL(op, tokens); NONNULL(op, positions); NONNULL(op, slot_mapping); NONNULL(op, ctx_lens); NONNULL(op, embed_tokens);
+    NONNULL(op, hidden_out);
+    if (hidden % 8 || hidden <= 0) return fail("%s: hidden=%d must be a positive multiple of 8", op, hidden);
+    return finish(op, qspec::spec_prepare_verify_embed(batch, k, block_size, max_blocks_per_seq, last_token, draft_token_ids, ids_stride_b, ids_stride_k, seq_lens, block_tables, block_tables_stride, tokens, positions, slot_mapping, ctx_lens, CH(embed_tokens), H(hidden_out), hidden, vocab, ST));
+}
 int qspec_spec_commit(int batch, int k, const int64_t* out_tokens, int32_t* seq_lens, int64_t* last_token,
                       int64_t* gen_tokens, int32_t* gen_lens, int gen_capacity, void* stream) {
     const char* op = "qspec_spec_commit";

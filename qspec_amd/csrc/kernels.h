@@ -180,6 +180,17 @@ int advance_step(int n, int block_size, int64_t* input_tokens, const int64_t* sa
 int spec_advance_draft(int n, int block_size, int max_blocks, int64_t* input_tokens, const int64_t* sampled,
                        int64_t* positions, int32_t* ctx_lens, int64_t* slot_mapping, const int32_t* block_tables,
                        int64_t bt_stride, hipStream_t st);
+int spec_prepare_draft_embed(int B, int block_size, int max_blocks, const int64_t* last_token, const int32_t* seq_lens,
+                             const int32_t* step_mask, int32_t* eff_lens, const int32_t* block_tables, int64_t bt_stride,
+                             int64_t* input_tokens, int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens, const f16* table,
+                             f16* hidden_out, int H, int V, hipStream_t st);
+int spec_advance_draft_embed(int n, int block_size, int max_blocks, int64_t* input_tokens, const int64_t* sampled, int64_t* positions,
+                             int32_t* ctx_lens, int64_t* slot_mapping, const int32_t* block_tables, int64_t bt_stride, const f16* table,
+                             f16* hidden_out, int H, int V, hipStream_t st);
+int spec_prepare_verify_embed(int B, int k, int block_size, int max_blocks, const int64_t* last_token, const int64_t* draft_ids,
+                              int64_t di_sb, int64_t di_sk, const int32_t* seq_lens, const int32_t* block_tables, int64_t bt_stride,
+                              int64_t* v_tokens, int64_t* v_positions, int64_t* v_slots, int32_t* v_ctx_lens, const f16* table,
+                              f16* hidden_out, int H, int V, hipStream_t st);
 int spec_prepare_draft(int B, int block_size, int max_blocks, const int64_t* last_token, const int32_t* seq_lens,
                        const int32_t* block_tables, int64_t bt_stride, int64_t* input_tokens, int64_t* positions,
                        int64_t* slot_mapping, int32_t* ctx_lens, hipStream_t st);

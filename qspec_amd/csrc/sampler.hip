@@ -785,6 +785,33 @@ __device__ __forceinline__ int64_t spec_slot(const int32_t* block_tables, int64_
     if (pos < 0 || (max_blocks > 0 && blk >= max_blocks)) return -1;
     return (int64_t)block_tables[bt_stride * b + blk] * block_size + pos % block_size;
 }
+// (each bookkeeping step below is a per-row device function returning the row's input token: the plain kernels run one row per
+// thread; the `_embed` kernels run one row per WORKGROUP -- thread 0 does the bookkeeping, then all 256 copy the token's embedding
+// row into the forward's hidden buffer (embedding_kernel's copy): one launch of the cycle's chain less per forward)
+__device__ __forceinline__ int64_t spec_prepare_draft_row(int b, int block_size, int max_blocks, const int64_t* last_token,
+                                                          const int32_t* seq_lens, const int32_t* step_mask, int32_t* eff_lens,
+                                                          const int32_t* block_tables, int64_t bt_stride, int64_t* input_tokens,
+                                                          int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens) {
+    int L = seq_lens[b];
+    if (step_mask) {   // eff_lens = seq_lens * step_mask (slots that sit this step out count as empty)
+        L *= step_mask[b];
+        eff_lens[b] = L;
+    }
+    const int pos = L - 1;
+    if (L <= 0) {
+        input_tokens[b] = 0;
+        positions[b] = 0;
+        ctx_lens[b] = 1;
+        slot_mapping[b] = -1;
+        return 0;
+    }
+    const int64_t tok = last_token[b];
+    input_tokens[b] = tok;
+    positions[b] = pos;
+    ctx_lens[b] = L;
+    slot_mapping[b] = spec_slot(block_tables, bt_stride, b, pos, block_size, max_blocks);
+    return tok;
+}
 __global__ void spec_prepare_draft_kernel(int B, int block_size, int max_blocks, const int64_t* __restrict__ last_token,
                                           const int32_t* __restrict__ seq_lens,
                                           const int32_t* __restrict__ block_tables, int64_t bt_stride,
@@ -792,41 +819,97 @@ __global__ void spec_prepare_draft_kernel(int B, int block_size, int max_blocks,
                                           int64_t* __restrict__ slot_mapping, int32_t* __restrict__ ctx_lens) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const int L = seq_lens[b], pos = L - 1;
-    if (L <= 0) {
-        input_tokens[b] = 0;
-        positions[b] = 0;
-        ctx_lens[b] = 1;
-        slot_mapping[b] = -1;
-        return;
-    }
-    input_tokens[b] = last_token[b];
-    positions[b] = pos;
-    ctx_lens[b] = L;
-    slot_mapping[b] = spec_slot(block_tables, bt_stride, b, pos, block_size, max_blocks);
+    spec_prepare_draft_row(b, block_size, max_blocks, last_token, seq_lens, nullptr, nullptr, block_tables, bt_stride, input_tokens,
+                           positions, slot_mapping, ctx_lens);
+}
+struct SpecEmbed {
+    const f16* table;   // [V, H]
+    f16* out;           // [rows, H]
+    int H, V;
+};
+__device__ __forceinline__ void spec_embed_row(const SpecEmbed& e, int row, int64_t tok_thread0) {
+    __shared__ int64_t s_tok;
+    if (threadIdx.x == 0) s_tok = tok_thread0;
+    __syncthreads();
+    int64_t id = s_tok;
+    if (id < 0 || id >= e.V) id = 0;  // padded slot (embedding_kernel's rule)
+    const f16* src = e.table + id * e.H;
+    for (int i = threadIdx.x; i < e.H / 8; i += blockDim.x)
+        *reinterpret_cast<f16x8*>(e.out + (size_t)row * e.H + 8 * i) = *reinterpret_cast<const f16x8*>(src + 8 * i);
+}
+__global__ __launch_bounds__(256) void spec_prepare_draft_embed_kernel(int block_size, int max_blocks, const int64_t* __restrict__ last_token,
+                                                                       const int32_t* __restrict__ seq_lens, const int32_t* __restrict__ step_mask,
+                                                                       int32_t* __restrict__ eff_lens, const int32_t* __restrict__ block_tables,
+                                                                       int64_t bt_stride, int64_t* __restrict__ input_tokens,
+                                                                       int64_t* __restrict__ positions, int64_t* __restrict__ slot_mapping,
+                                                                       int32_t* __restrict__ ctx_lens, SpecEmbed e) {
+    const int b = blockIdx.x;
+    int64_t tok = 0;
+    if (threadIdx.x == 0)
+        tok = spec_prepare_draft_row(b, block_size, max_blocks, last_token, seq_lens, step_mask, eff_lens, block_tables, bt_stride,
+                                     input_tokens, positions, slot_mapping, ctx_lens);
+    spec_embed_row(e, b, tok);
 }
 // _gpu_advance_step between two draft steps (draft_model_runner.py:78-135) with the two engine rules above: a row
 // whose slot is -1 (empty, or out of blocks) stays put; a new position beyond the block table gets slot -1.
+__device__ __forceinline__ int64_t spec_advance_draft_row(int i, int block_size, int max_blocks, int64_t* input_tokens,
+                                                          const int64_t* sampled, int64_t* positions, int32_t* ctx_lens,
+                                                          int64_t* slot_mapping, const int32_t* block_tables, int64_t bt_stride) {
+    if (slot_mapping[i] < 0) return input_tokens[i];
+    const int64_t tok = sampled[i];
+    input_tokens[i] = tok;
+    const int next_len = ctx_lens[i] + 1;
+    const int pos = next_len - 1;
+    const int64_t slot = spec_slot(block_tables, bt_stride, i, pos, block_size, max_blocks);
+    if (slot < 0) {   // out of blocks: freeze the row (its remaining draft steps recompute the same token)
+        slot_mapping[i] = -1;
+        return tok;
+    }
+    ctx_lens[i] = next_len;
+    positions[i] = pos;
+    slot_mapping[i] = slot;
+    return tok;
+}
 __global__ void spec_advance_draft_kernel(int n, int block_size, int max_blocks, int64_t* __restrict__ input_tokens,
                                           const int64_t* __restrict__ sampled, int64_t* __restrict__ positions,
                                           int32_t* __restrict__ ctx_lens, int64_t* __restrict__ slot_mapping,
                                           const int32_t* __restrict__ block_tables, int64_t bt_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (slot_mapping[i] < 0) return;
-    input_tokens[i] = sampled[i];
-    const int next_len = ctx_lens[i] + 1;
-    const int pos = next_len - 1;
-    const int64_t slot = spec_slot(block_tables, bt_stride, i, pos, block_size, max_blocks);
-    if (slot < 0) {   // out of blocks: freeze the row (its remaining draft steps recompute the same token)
-        slot_mapping[i] = -1;
-        return;
-    }
-    ctx_lens[i] = next_len;
-    positions[i] = pos;
-    slot_mapping[i] = slot;
+    spec_advance_draft_row(i, block_size, max_blocks, input_tokens, sampled, positions, ctx_lens, slot_mapping, block_tables, bt_stride);
+}
+__global__ __launch_bounds__(256) void spec_advance_draft_embed_kernel(int block_size, int max_blocks, int64_t* __restrict__ input_tokens,
+                                                                       const int64_t* __restrict__ sampled, int64_t* __restrict__ positions,
+                                                                       int32_t* __restrict__ ctx_lens, int64_t* __restrict__ slot_mapping,
+                                                                       const int32_t* __restrict__ block_tables, int64_t bt_stride, SpecEmbed e) {
+    const int i = blockIdx.x;
+    int64_t tok = 0;
+    if (threadIdx.x == 0)
+        tok = spec_advance_draft_row(i, block_size, max_blocks, input_tokens, sampled, positions, ctx_lens, slot_mapping, block_tables,
+                                     bt_stride);
+    spec_embed_row(e, i, tok);
 }
 // verify query of sequence b = [last_token, d_1 .. d_k] at positions L-1 .. L-1+k (mqa_scorer.py:42-60)
+__device__ __forceinline__ int64_t spec_prepare_verify_row(int i, int k, int block_size, int max_blocks, const int64_t* last_token,
+                                                           const int64_t* draft_ids, int64_t di_sb, int64_t di_sk, const int32_t* seq_lens,
+                                                           const int32_t* block_tables, int64_t bt_stride, int64_t* v_tokens,
+                                                           int64_t* v_positions, int64_t* v_slots, int32_t* v_ctx_lens) {
+    const int b = i / (k + 1), j = i % (k + 1);
+    const int L = seq_lens[b], pos = L - 1 + j;
+    if (L <= 0) {   // empty slot: k + 1 dummy queries over the first k + 1 keys of the row, nothing written
+        v_tokens[i] = 0;
+        v_positions[i] = j;
+        v_slots[i] = -1;
+        if (j == 0) v_ctx_lens[b] = k + 1;
+        return 0;
+    }
+    const int64_t tok = j == 0 ? last_token[b] : draft_ids[b * di_sb + (j - 1) * di_sk];
+    v_tokens[i] = tok;
+    v_positions[i] = pos;
+    v_slots[i] = spec_slot(block_tables, bt_stride, b, pos, block_size, max_blocks);
+    if (j == 0) v_ctx_lens[b] = L + k;
+    return tok;
+}
 __global__ void spec_prepare_verify_kernel(int B, int k, int block_size, int max_blocks, const int64_t* __restrict__ last_token,
                                            const int64_t* __restrict__ draft_ids, int64_t di_sb, int64_t di_sk,
                                            const int32_t* __restrict__ seq_lens,
@@ -835,19 +918,21 @@ __global__ void spec_prepare_verify_kernel(int B, int k, int block_size, int max
                                            int64_t* __restrict__ v_slots, int32_t* __restrict__ v_ctx_lens) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * (k + 1)) return;
-    const int b = i / (k + 1), j = i % (k + 1);
-    const int L = seq_lens[b], pos = L - 1 + j;
-    if (L <= 0) {   // empty slot: k + 1 dummy queries over the first k + 1 keys of the row, nothing written
-        v_tokens[i] = 0;
-        v_positions[i] = j;
-        v_slots[i] = -1;
-        if (j == 0) v_ctx_lens[b] = k + 1;
-        return;
-    }
-    v_tokens[i] = j == 0 ? last_token[b] : draft_ids[b * di_sb + (j - 1) * di_sk];
-    v_positions[i] = pos;
-    v_slots[i] = spec_slot(block_tables, bt_stride, b, pos, block_size, max_blocks);
-    if (j == 0) v_ctx_lens[b] = L + k;
+    spec_prepare_verify_row(i, k, block_size, max_blocks, last_token, draft_ids, di_sb, di_sk, seq_lens, block_tables, bt_stride, v_tokens,
+                            v_positions, v_slots, v_ctx_lens);
+}
+__global__ __launch_bounds__(256) void spec_prepare_verify_embed_kernel(int k, int block_size, int max_blocks, const int64_t* __restrict__ last_token,
+                                                                        const int64_t* __restrict__ draft_ids, int64_t di_sb, int64_t di_sk,
+                                                                        const int32_t* __restrict__ seq_lens,
+                                                                        const int32_t* __restrict__ block_tables, int64_t bt_stride,
+                                                                        int64_t* __restrict__ v_tokens, int64_t* __restrict__ v_positions,
+                                                                        int64_t* __restrict__ v_slots, int32_t* __restrict__ v_ctx_lens, SpecEmbed e) {
+    const int i = blockIdx.x;
+    int64_t tok = 0;
+    if (threadIdx.x == 0)
+        tok = spec_prepare_verify_row(i, k, block_size, max_blocks, last_token, draft_ids, di_sb, di_sk, seq_lens, block_tables, bt_stride,
+                                      v_tokens, v_positions, v_slots, v_ctx_lens);
+    spec_embed_row(e, i, tok);
 }
 // append the emitted tokens (out != -1, a prefix of the row) and advance the sequence state
 __global__ void spec_commit_kernel(int B, int k, const int64_t* __restrict__ out_tokens,
@@ -926,6 +1011,36 @@ int spec_snapshot(int B, int restore, int32_t* seq_lens, int32_t* gen_lens, int6
 }
 int collect_error_words(int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3, int clear, int64_t* out, hipStream_t st) {
     hipLaunchKernelGGL(collect_error_words_kernel, dim3(1), dim3(64), 0, st, w0, w1, w2, w3, clear, out);
+    return 0;
+}
+int spec_prepare_draft_embed(int B, int block_size, int max_blocks, const int64_t* last_token, const int32_t* seq_lens,
+                             const int32_t* step_mask, int32_t* eff_lens, const int32_t* block_tables, int64_t bt_stride,
+                             int64_t* input_tokens, int64_t* positions, int64_t* slot_mapping, int32_t* ctx_lens, const f16* table,
+                             f16* hidden_out, int H, int V, hipStream_t st) {
+    if (B == 0) return 0;
+    if (H % 8 || (step_mask && !eff_lens)) return -1;
+    hipLaunchKernelGGL(spec_prepare_draft_embed_kernel, dim3(B), dim3(256), 0, st, block_size, max_blocks, last_token, seq_lens, step_mask,
+                       eff_lens, block_tables, bt_stride, input_tokens, positions, slot_mapping, ctx_lens, SpecEmbed{table, hidden_out, H, V});
+    return 0;
+}
+int spec_advance_draft_embed(int n, int block_size, int max_blocks, int64_t* input_tokens, const int64_t* sampled, int64_t* positions,
+                             int32_t* ctx_lens, int64_t* slot_mapping, const int32_t* block_tables, int64_t bt_stride, const f16* table,
+                             f16* hidden_out, int H, int V, hipStream_t st) {
+    if (n == 0) return 0;
+    if (H % 8) return -1;
+    hipLaunchKernelGGL(spec_advance_draft_embed_kernel, dim3(n), dim3(256), 0, st, block_size, max_blocks, input_tokens, sampled, positions,
+                       ctx_lens, slot_mapping, block_tables, bt_stride, SpecEmbed{table, hidden_out, H, V});
+    return 0;
+}
+int spec_prepare_verify_embed(int B, int k, int block_size, int max_blocks, const int64_t* last_token, const int64_t* draft_ids,
+                              int64_t di_sb, int64_t di_sk, const int32_t* seq_lens, const int32_t* block_tables, int64_t bt_stride,
+                              int64_t* v_tokens, int64_t* v_positions, int64_t* v_slots, int32_t* v_ctx_lens, const f16* table,
+                              f16* hidden_out, int H, int V, hipStream_t st) {
+    if (B == 0) return 0;
+    if (H % 8) return -1;
+    hipLaunchKernelGGL(spec_prepare_verify_embed_kernel, dim3(B * (k + 1)), dim3(256), 0, st, k, block_size, max_blocks, last_token, draft_ids,
+                       di_sb, di_sk, seq_lens, block_tables, bt_stride, v_tokens, v_positions, v_slots, v_ctx_lens,
+                       SpecEmbed{table, hidden_out, H, V});
     return 0;
 }
 int spec_prepare_draft(int B, int block_size, int max_blocks, const int64_t* last_token, const int32_t* seq_lens,

@@ -258,13 +258,16 @@ class QuarotLlamaForCausalLM:
 
     # ------------------------------------------------------------------ fused product path
     def forward(self, input_ids, positions, kv_caches, attn_metadata: AttentionMetadata, scratch: Scratch,
-                w4a4: bool = False, **kwargs):
-        """LlamaModel.forward (quarot_llama.py:484-535) + final norm; returns the normed hidden states [T,H]."""
+                w4a4: bool = False, embedded: bool = False, **kwargs):
+        """LlamaModel.forward (quarot_llama.py:484-535) + final norm; returns the normed hidden states [T,H].
+        embedded: scratch.hidden[:T] already holds embed_tokens[input_ids] (the engine's bookkeeping launches write it:
+        ops.spec_prepare_draft / spec_advance_draft / spec_prepare_verify with embed=...)."""
         cfg, s, md = self.config, scratch, attn_metadata
         T = input_ids.numel()
         eps = cfg.rms_norm_eps
         hidden = s.hidden[:T]
-        ops.embedding(input_ids, self.embed_tokens, hidden)
+        if not embedded:
+            ops.embedding(input_ids, self.embed_tokens, hidden)
         delta = None
         qkv, attn, o, gu = s.act_buffer_qkv[:T], s.act_buffer_attn[:T], s.act_buffer_output[:T], s.act_buffer_gate_up[:T]
         q1, q3, sc = s.quantized_buffer_qkv[:T], s.quantized_buffer_mlp[:T], s.scale_buffer[:T]

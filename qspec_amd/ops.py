@@ -701,10 +701,22 @@ def advance_step_flashattn(num_seqs, num_queries, block_size, input_tokens, samp
 
 # ------------------------------------------------------------------ spec-decode cycle glue
 
-def spec_advance_draft(block_size, input_tokens, sampled_token_ids, positions, ctx_lens, slot_mapping, block_tables):
+def _embed_args(embed):
+    """embed = (embed_tokens [V, H], hidden_out [rows, H]): the forward's embedding lookup rides in the bookkeeping launch."""
+    table, out = embed
+    return (_chk(table, "embed_tokens", _F16), _chk(out, "hidden_out", _F16), table.shape[1], table.shape[0])
+
+
+def spec_advance_draft(block_size, input_tokens, sampled_token_ids, positions, ctx_lens, slot_mapping, block_tables, embed=None):
     """_gpu_advance_step between two draft steps (draft_model_runner.py:78-135) with the engine's empty-slot and
     out-of-blocks rules (include/qspec_hip.h)."""
     B = ctx_lens.numel()
+    if embed is not None:
+        _call("qspec_spec_advance_draft_embed", B, block_size, block_tables.shape[1], _chk(input_tokens, "input_tokens", _I64),
+              _chk(sampled_token_ids, "sampled_token_ids", _I64), _chk(positions, "positions", _I64),
+              _chk(ctx_lens, "ctx_lens", _I32), _chk(slot_mapping, "slot_mapping", _I64),
+              _chk(block_tables, "block_tables", _I32), block_tables.stride(0), *_embed_args(embed), _stream())
+        return
     _call("qspec_spec_advance_draft", B, block_size, block_tables.shape[1], _chk(input_tokens, "input_tokens", _I64),
           _chk(sampled_token_ids, "sampled_token_ids", _I64), _chk(positions, "positions", _I64),
           _chk(ctx_lens, "ctx_lens", _I32), _chk(slot_mapping, "slot_mapping", _I64),
@@ -712,8 +724,18 @@ def spec_advance_draft(block_size, input_tokens, sampled_token_ids, positions, c
 
 
 def spec_prepare_draft(last_token, seq_lens, block_tables, block_size, input_tokens, positions, slot_mapping,
-                       ctx_lens):
+                       ctx_lens, embed=None, step_mask=None, eff_lens=None):
+    """embed given: the fused form; step_mask / eff_lens (fused form only): eff_lens = seq_lens * step_mask, used as the lengths."""
     B = seq_lens.numel()
+    if embed is not None:
+        _call("qspec_spec_prepare_draft_embed", B, block_size, block_tables.shape[1], _chk(last_token, "last_token", _I64),
+              _chk(seq_lens, "seq_lens", _I32), _opt(step_mask, "step_mask", _I32), _opt(eff_lens, "eff_lens", _I32),
+              _chk(block_tables, "block_tables", _I32), block_tables.stride(0),
+              _chk(input_tokens, "input_tokens", _I64), _chk(positions, "positions", _I64),
+              _chk(slot_mapping, "slot_mapping", _I64), _chk(ctx_lens, "ctx_lens", _I32), *_embed_args(embed), _stream())
+        return
+    if step_mask is not None:
+        raise RuntimeError("step_mask rides in the fused form only (embed=...)")
     _call("qspec_spec_prepare_draft", B, block_size, block_tables.shape[1], _chk(last_token, "last_token", _I64),
           _chk(seq_lens, "seq_lens", _I32), _chk(block_tables, "block_tables", _I32), block_tables.stride(0),
           _chk(input_tokens, "input_tokens", _I64), _chk(positions, "positions", _I64),
@@ -721,8 +743,16 @@ def spec_prepare_draft(last_token, seq_lens, block_tables, block_size, input_tok
 
 
 def spec_prepare_verify(last_token, draft_token_ids, seq_lens, block_tables, block_size, tokens, positions,
-                        slot_mapping, ctx_lens):
+                        slot_mapping, ctx_lens, embed=None):
     B, k = draft_token_ids.shape
+    if embed is not None:
+        _call("qspec_spec_prepare_verify_embed", B, k, block_size, block_tables.shape[1], _chk(last_token, "last_token", _I64),
+              draft_token_ids.data_ptr(), draft_token_ids.stride(0), draft_token_ids.stride(1),
+              _chk(seq_lens, "seq_lens", _I32),
+              _chk(block_tables, "block_tables", _I32), block_tables.stride(0), _chk(tokens, "tokens", _I64),
+              _chk(positions, "positions", _I64), _chk(slot_mapping, "slot_mapping", _I64),
+              _chk(ctx_lens, "ctx_lens", _I32), *_embed_args(embed), _stream())
+        return
     _call("qspec_spec_prepare_verify", B, k, block_size, block_tables.shape[1], _chk(last_token, "last_token", _I64),
           draft_token_ids.data_ptr(), draft_token_ids.stride(0), draft_token_ids.stride(1),
           _chk(seq_lens, "seq_lens", _I32),

@@ -164,6 +164,8 @@ class QSpecEngine:
         self.inject_exponential: Optional[torch.Tensor] = None
         self._prefill_scratch: Optional[Scratch] = None
 
+    # the embedding lookups of the cycle's four forwards ride in the bookkeeping launches in front of them (5 launches less)
+    EMBED_IN_BOOKKEEPING = os.environ.get("QSPEC_EMBED_IN_BOOKKEEPING", "1") != "0"
     PREFILL_TOKEN_BUDGET = 4096   # tokens per prompt-pass forward when several requests are admitted together
 
     # ------------------------------------------------------------------ prefill (_run_no_spec, :666-720)
@@ -420,13 +422,20 @@ class QSpecEngine:
     def _draft_body(self):
         m, k, B, bs = self.model, self.k, self.B, self.block_size
         # proposer: k draft steps, W4A4  (execute_model_req.w4a4 = True, :799)
-        torch.mul(self.seq_lens, self.step_mask, out=self.eff_lens)
-        ops.spec_prepare_draft(self.last_token, self.eff_lens, self.block_tables, bs, self.d_tokens, self.d_pos,
-                               self.d_slots, self.d_ctx)
+        # (the lengths of the slots taking part, the first draft step's inputs and its embedding rows: one launch)
+        emb_d = (m.embed_tokens, self.scratch_draft.hidden[:B]) if self.EMBED_IN_BOOKKEEPING else None
+        if emb_d is not None:
+            ops.spec_prepare_draft(self.last_token, self.seq_lens, self.block_tables, bs, self.d_tokens, self.d_pos,
+                                   self.d_slots, self.d_ctx, embed=emb_d, step_mask=self.step_mask, eff_lens=self.eff_lens)
+        else:
+            torch.mul(self.seq_lens, self.step_mask, out=self.eff_lens)
+            ops.spec_prepare_draft(self.last_token, self.eff_lens, self.block_tables, bs, self.d_tokens, self.d_pos,
+                                   self.d_slots, self.d_ctx)
         tp = self._comm()
         draft_sv = tp is not None and getattr(tp, "shard_draft_vocab", False)   # vocab-parallel lm_head on the draft pass too
         for i in range(k):
-            hs = m.forward(self.d_tokens, self.d_pos, self.kv_caches, self.md_draft, self.scratch_draft, w4a4=True)
+            hs = m.forward(self.d_tokens, self.d_pos, self.kv_caches, self.md_draft, self.scratch_draft, w4a4=True,
+                           embedded=emb_d is not None)
             if self._mode_sampling:   # draft tokens are SAMPLED from the processed draft distribution (sampler.py:216-316)
                 m.sample(hs, self.scratch_draft, self.draft_probs_kbv[i], self.draft_ids_kb[i], self.samp_temp, self.samp_topk,
                          self.samp_topp, self.sampler.rng_state, shard_vocab=draft_sv)
@@ -434,16 +443,18 @@ class QSpecEngine:
                 m.sample_greedy(hs, self.scratch_draft, self.draft_probs_kbv[i], self.draft_ids_kb[i], shard_vocab=draft_sv)
             if i != k - 1:  # _gpu_advance_step (draft_model_runner.py:78-135)
                 ops.spec_advance_draft(bs, self.d_tokens, self.draft_ids_kb[i], self.d_pos, self.d_ctx, self.d_slots,
-                                       self.block_tables)
+                                       self.block_tables, embed=emb_d)
 
     def _verify_body(self):
         m, k, B, bs = self.model, self.k, self.B, self.block_size
         # scorer: one W4A16 pass over [last, d_1..d_k] per sequence  (w4a4 = False, :812; mqa_scorer.py)
         draft_ids = self.draft_ids_kb.transpose(0, 1)            # [B,k] view
         draft_probs = self.draft_probs_kbv.transpose(0, 1)       # [B,k,V] view
+        emb_v = (m.embed_tokens, self.scratch_verify.hidden[:B * (k + 1)]) if self.EMBED_IN_BOOKKEEPING else None
         ops.spec_prepare_verify(self.last_token, draft_ids, self.eff_lens, self.block_tables, bs, self.v_tokens,
-                                self.v_pos, self.v_slots, self.v_ctx)
-        hs = m.forward(self.v_tokens, self.v_pos, self.kv_caches, self.md_verify, self.scratch_verify, w4a4=False)
+                                self.v_pos, self.v_slots, self.v_ctx, embed=emb_v)
+        hs = m.forward(self.v_tokens, self.v_pos, self.kv_caches, self.md_verify, self.scratch_verify, w4a4=False,
+                       embedded=emb_v is not None)
         hook = self._verify_logits_hook(draft_ids)
         if self._mode_sampling:
             m.sample(hs, self.scratch_verify, self.target_probs.view(B * (k + 1), -1), self.target_tokens.view(-1),

@@ -1019,6 +1019,67 @@ def test_rejection_sampler_philox_path(ops):
     rej = ~(ids == tgt[:, :k])
     assert np.array_equal(outs[0][2][rej], tgt[:, :k][rej])
 
+def test_bookkeeping_launches_with_the_embedding_rows(ops):
+    """spec_prepare_draft / spec_advance_draft / spec_prepare_verify with embed=(table, hidden): the same index tensors as the
+    plain launches (empty slots, a slot sitting the step out, a row out of blocks included) and hidden[row] = table[token]
+    (row 0 for padded rows), i.e. what the plain launch followed by ops.embedding gives -- bit for bit."""
+    rng = np.random.default_rng(77)
+    B, k, bs, V, H, max_blocks = 6, 3, 16, 500, 256, 4
+    table = dev((rng.standard_normal((V, H))).astype(np.float16))
+    bt = dev(rng.permutation(B * max_blocks).reshape(B, max_blocks).astype(np.int32))
+    seq_lens = dev(np.array([37, 0, 5, 63, 64, 20], np.int32))     # slot 1 empty; slot 4: position 63 is its last slot
+    mask = dev(np.array([1, 1, 0, 1, 1, 1], np.int32))             # slot 2 sits the step out
+    last = dev(rng.integers(0, V, B).astype(np.int64))
+    i64, i32 = torch.int64, torch.int32
+
+    def bufs(n):
+        return [torch.full((n,), 7, dtype=i64, device=DEV) for _ in range(3)] + [torch.full((B,), 7, dtype=i32, device=DEV)]
+    # prepare_draft
+    eff0 = seq_lens * mask
+    t0, p0, s0, c0 = bufs(B)
+    ops.spec_prepare_draft(last, eff0, bt, bs, t0, p0, s0, c0)
+    h0 = torch.empty(B, H, dtype=torch.float16, device=DEV)
+    ops.embedding(t0, table, h0)
+    t1, p1, s1, c1 = bufs(B)
+    eff1 = torch.full((B,), -5, dtype=i32, device=DEV)
+    h1 = torch.full((B, H), 3.0, dtype=torch.float16, device=DEV)
+    ops.spec_prepare_draft(last, seq_lens, bt, bs, t1, p1, s1, c1, embed=(table, h1), step_mask=mask, eff_lens=eff1)
+    torch.cuda.synchronize()
+    for a, b in ((t0, t1), (p0, p1), (s0, s1), (c0, c1), (eff0, eff1)):
+        assert torch.equal(a, b)
+    assert torch.equal(h0.view(torch.int16), h1.view(torch.int16))
+    assert host(s1).tolist()[1] == -1 and host(s1).tolist()[2] == -1
+    # advance_draft (slot 4 runs out of blocks at position 64: frozen, its token still updated)
+    sampled = dev(rng.integers(0, V, B).astype(np.int64))
+    ta, pa, sa, ca = (x.clone() for x in (t0, p0, s0, c0))
+    ops.spec_advance_draft(bs, ta, sampled, pa, ca, sa, bt)
+    ha = torch.empty(B, H, dtype=torch.float16, device=DEV)
+    ops.embedding(ta, table, ha)
+    tb, pb, sb, cb = (x.clone() for x in (t0, p0, s0, c0))
+    hb = torch.full((B, H), 3.0, dtype=torch.float16, device=DEV)
+    ops.spec_advance_draft(bs, tb, sampled, pb, cb, sb, bt, embed=(table, hb))
+    torch.cuda.synchronize()
+    for a, b in ((ta, tb), (pa, pb), (sa, sb), (ca, cb)):
+        assert torch.equal(a, b)
+    assert torch.equal(ha.view(torch.int16), hb.view(torch.int16))
+    assert host(sb).tolist()[4] == -1 and host(tb).tolist()[4] == host(sampled).tolist()[4]
+    # prepare_verify (draft ids as a strided [B, k] view of a step-major buffer, as the engine passes them)
+    ids_kb = dev(rng.integers(0, V, (k, B)).astype(np.int64))
+    ids = ids_kb.transpose(0, 1)
+    n = B * (k + 1)
+    tv0, pv0, sv0, cv0 = bufs(n)
+    ops.spec_prepare_verify(last, ids, eff0, bt, bs, tv0, pv0, sv0, cv0)
+    hv0 = torch.empty(n, H, dtype=torch.float16, device=DEV)
+    ops.embedding(tv0, table, hv0)
+    tv1, pv1, sv1, cv1 = bufs(n)
+    hv1 = torch.full((n, H), 3.0, dtype=torch.float16, device=DEV)
+    ops.spec_prepare_verify(last, ids, eff0, bt, bs, tv1, pv1, sv1, cv1, embed=(table, hv1))
+    torch.cuda.synchronize()
+    for a, b in ((tv0, tv1), (pv0, pv1), (sv0, sv1), (cv0, cv1)):
+        assert torch.equal(a, b)
+    assert torch.equal(hv0.view(torch.int16), hv1.view(torch.int16))
+
+
 
 def test_advance_step(ops, oracle):
     rng = np.random.default_rng(1)
