@@ -510,6 +510,20 @@ int qspec_collect_error_words(int32_t* w0, int32_t* w1, int32_t* w2, int32_t* w3
  * at (M tokens, K) read the tile).  Producers: out / out_f16 is the tile (tokens <= 16; heads_hadamard_merged: 32 heads,
  * q == NULL; mlp_hadamard: workspace != NULL, q == NULL; mix_merged_spread: part_amax == NULL).  Consumers: x is the tile. */
 int qspec_w4a16_act_layout_supported(int M, int K);
+/* 17..32 tokens: x is TWO such tiles back to back (rows 0..15, then rows 16..31: tile t at x + t * 16 * K), read by a streaming
+ * kernel that takes two token tiles over one pass of the weights (K in several passes where the operand registers of one do not
+ * hold it: 8192, 14336, 28672).  qspec_w4a16_act_layout32_supported(M, N, K) = 1 where built; the `_xp32` entries have the
+ * argument meaning of their row-major twins (no workspace: nothing is split across workgroups), results within 1e-3 of them
+ * (another fp32 summation order than the M-tiled kernel's that 17+ tokens otherwise take). */
+int qspec_w4a16_act_layout32_supported(int M, int N, int K);
+int qspec_w4a16_linear_xp32(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* out, int M, int N, int K,
+                            void* stream);
+int qspec_qkv_rope_linear_w4a16_xp32(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M,
+                                     int N, int K, const int64_t* positions, const qspec_half* cos_sin_cache,
+                                     qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
+                                     int num_heads, int num_kv_heads, int head_size, int rot_dim, void* stream);
+int qspec_gate_up_silu_linear_w4a16_xp32(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
+                                         int intermediate, int K, void* stream);
 int qspec_mlp_hadamard_act_layout_supported(int tokens, int intermediate, int K);   /* 1: qspec_mlp_hadamard_xp exists here */
 int qspec_add_rms_norm_fp16_xp(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const qspec_half* delta,
                                float eps, int tokens, int hidden, void* stream);

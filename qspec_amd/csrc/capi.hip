@@ -91,7 +91,7 @@ int qspec_add_rms_norm_fp16(qspec_half* out, qspec_half* hidden_out, const qspec
     NONNULL(op, out); NONNULL(op, x);
     if (delta) NONNULL(op, hidden_out);
     if (hidden % 1024 || hidden > 8192 || hidden <= 0) return fail("%s: hidden=%d must be a multiple of 1024, <= 8192", op, hidden);
-    if (g_xp && tokens > 16) return fail("%s: the fragment-major layout is a 16-row tile (tokens=%d)", op, tokens);
+    if (g_xp && tokens > 32) return fail("%s: the fragment-major layout is one or two 16-row tiles (tokens=%d)", op, tokens);
     return finish(op, qspec::ln_fp16(CH(x), CH(delta), H(hidden_out), H(out), eps, tokens, hidden, ST, g_xp));
 }
 int qspec_add_rms_norm_fp16_xp(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const qspec_half* delta,
@@ -235,6 +235,38 @@ int qspec_w4a16_linear(const qspec_half* x, const int8_t* wq, const qspec_half* 
                                                   workspace ? qspec::gemm_w4a16_ws_bytes() - 8192 : 0, ST));
     return finish(op, qspec::gemm_w4a16(CH(x), wq, CH(ws), CH(bias), H(out), M, N, K, workspace, ST));
 }
+int qspec_w4a16_act_layout32_supported(int M, int N, int K) { return use_stream() && qspec::gemm_w4a16_stream32_supported(M, N, K) ? 1 : 0; }
+int qspec_w4a16_linear_xp32(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* out, int M, int N, int K,
+                            void* stream) {
+    const char* op = "qspec_w4a16_linear_xp32";
+    if (M == 0 || N == 0) return 0;
+    NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, out);
+    if (!qspec_w4a16_act_layout32_supported(M, N, K))
+        return fail("%s: no two-tile streaming form for (M=%d N=%d K=%d): ask qspec_w4a16_act_layout32_supported", op, M, N, K);
+    return finish(op, qspec::gemm_w4a16_stream32(CH(x), wq, CH(ws), H(out), M, N, K, ST));
+}
+int qspec_qkv_rope_linear_w4a16_xp32(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M,
+                                     int N, int K, const int64_t* positions, const qspec_half* cos_sin_cache,
+                                     qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
+                                     int num_heads, int num_kv_heads, int head_size, int rot_dim, void* stream) {
+    const char* op = "qspec_qkv_rope_linear_w4a16_xp32";
+    if (M == 0) return 0;
+    NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, qkv); NONNULL(op, positions);
+    NONNULL(op, cos_sin_cache); NONNULL(op, key_cache); NONNULL(op, value_cache); NONNULL(op, slot_mapping);
+    if ((head_size != 128 && head_size != 64) || rot_dim != head_size) return fail("%s: head_size = rot_dim = 128 or 64 only", op);
+    if (!qspec_w4a16_act_layout32_supported(M, N, K))
+        return fail("%s: no two-tile streaming form for (M=%d N=%d K=%d)", op, M, N, K);
+    return finish(op, qspec::gemm_w4a16_stream32_qkv_rope(CH(x), wq, CH(ws), H(qkv), M, N, K, positions, CH(cos_sin_cache), H(key_cache), H(value_cache), slot_mapping, num_heads, num_kv_heads, head_size, rot_dim, ST));
+}
+int qspec_gate_up_silu_linear_w4a16_xp32(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* act, int M,
+                                         int intermediate, int K, void* stream) {
+    const char* op = "qspec_gate_up_silu_linear_w4a16_xp32";
+    if (M == 0) return 0;
+    NONNULL(op, x); NONNULL(op, wq); NONNULL(op, ws); NONNULL(op, act);
+    if (intermediate % 8 || !qspec_w4a16_act_layout32_supported(M, 2 * intermediate, K))
+        return fail("%s: no two-tile streaming form for (M=%d I=%d K=%d)", op, M, intermediate, K);
+    return finish(op, qspec::gemm_w4a16_stream32_gate_up_silu(CH(x), wq, CH(ws), H(act), M, intermediate, K, ST));
+}
 int qspec_mlp_hadamard_act_layout_supported(int tokens, int intermediate, int K) {
     return qspec::mlp_hadamard_xperm_supported(tokens, intermediate, K) ? 1 : 0;
 }
@@ -314,8 +346,8 @@ int qspec_heads_hadamard_merged(const void* attn_workspace, int max_tokens, int 
     if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
     if (!((head_dim == 128 && (heads == 32 || heads == 64)) || (heads == 32 && head_dim % 8 == 0 && head_dim >= 8 && head_dim <= 256)))
         return fail("%s: built for 32 / 64 heads of 128 and 32 heads of another size %% 8 == 0 (got %d x %d)", op, heads, head_dim);
-    if (g_xp && (q || heads != 32 || tokens > 16 || head_dim != 128))
-        return fail("%s: the fragment-major fp16 output exists for 32 heads, <= 16 tokens, no quantiser", op);
+    if (g_xp && (q || !(heads == 32 || heads == 64) || tokens > 32 || head_dim != 128))
+        return fail("%s: the fragment-major fp16 output exists for 32 / 64 heads of 128, <= 32 tokens, no quantiser", op);
     return finish(op, qspec::heads_hadamard_merge((const float*)attn_workspace, max_tokens, n_splits, H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, heads, head_dim, ST, g_xp));
 }
 int qspec_heads_hadamard_merged_xp(const void* attn_workspace, int max_tokens, int n_splits, qspec_half* out_f16, int8_t* q,
@@ -353,7 +385,7 @@ int qspec_heads_hadamard_mix_merged_spread(const void* attn_workspace, int max_t
     if (!qspec::heads_hadamard_mix_merge_spread_supported(tokens, heads, head_dim, K))
         return fail("%s: needs head_dim 128, heads = K * 2^p <= 64 with 2 <= K <= 172, at most 128 tokens (got %d x %d, K = %d, %d tokens)",
                     op, heads, head_dim, K, tokens);
-    if (g_xp && (part_amax || tokens > 16)) return fail("%s: the fragment-major fp16 output: <= 16 tokens, no part_amax", op);
+    if (g_xp && (part_amax || tokens > 32)) return fail("%s: the fragment-major fp16 output: <= 32 tokens, no part_amax", op);
     return finish(op, qspec::heads_hadamard_mix_merge_spread((const float*)attn_workspace, max_tokens, n_splits, CH(hadK), H(out_f16),
                                                              part_amax, had_scale, tokens, heads, head_dim, K, ST, g_xp));
 }
@@ -759,7 +791,7 @@ int qspec_add_rms_norm_fp16_partial(qspec_half* out, qspec_half* hidden_out, con
     NONNULL(op, out); NONNULL(op, x); NONNULL(op, part); NONNULL(op, ws); NONNULL(op, hidden_out);
     if (slices < 1) return fail("%s: slices < 1", op);
     if (hidden % 1024 || hidden > 8192 || hidden <= 0) return fail("%s: hidden=%d must be a multiple of 1024, <= 8192", op, hidden);
-    if (g_xp && tokens > 16) return fail("%s: the fragment-major layout is a 16-row tile (tokens=%d)", op, tokens);
+    if (g_xp && tokens > 32) return fail("%s: the fragment-major layout is one or two 16-row tiles (tokens=%d)", op, tokens);
     return finish(op, qspec::ln_fp16_partial(CH(x), part, CH(ws), slices, H(hidden_out), H(out), eps, tokens, hidden, ST, g_xp));
 }
 int qspec_add_rms_norm_fp16_partial_xp(qspec_half* out, qspec_half* hidden_out, const qspec_half* x, const float* part,

@@ -16,6 +16,10 @@ __host__ __device__ __forceinline__ size_t w4a16_xperm_offset(int r, int k) {
     const int pos = ((e & 3) << 1) | (e >> 2);           // 0,1,2,3,4,5,6,7 -> 0,2,4,6,1,3,5,7
     return ((((size_t)kstep * 4 + dd) * 64 + g * 16 + r) << 3) + pos;
 }
+// 17..32 rows: two such tiles back to back (rows 0..15, rows 16..31), each 16 x K halves (gemm_w4a16_stream2_kernel reads both)
+__host__ __device__ __forceinline__ size_t w4a16_xperm_offset(int r, int k, int K) {
+    return (size_t)(r >> 4) * 16 * K + w4a16_xperm_offset(r & 15, k);
+}
 
 
 typedef _Float16 f16;

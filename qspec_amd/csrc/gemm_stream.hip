@@ -2174,6 +2174,243 @@ __global__ __launch_bounds__(256) void w4a16_partial_finish_kernel(const float* 
     out[i] = f2h(sum * h2f(ws[i % N]));
 }
 
+// ---- 17..32 tokens: TWO 16-token tiles over one pass of the weight stream, K in NB passes.
+// The M-tiled kernel (gemm_tiled.hip, built for prompt-sized M) dequantises every packed dword for one 32-token block only and
+// leaves a SIMD with one wave: Llama-3-70B's verify pass at 32 tokens spent 151 us per layer in its four GEMMs where the draft
+// pass streams the same bytes in 82.  Here the streaming kernel takes a second token tile: x is TWO fragment-major 16-row tiles
+// (common.cuh: w4a16_xperm_offset32; the producers write them), loaded straight into the MFMA operand registers -- 2 x UB x 16
+// VGPRs, which is why K is walked in NB passes of 128 * NW * UB k: pass p holds the fragments of its K range, streams that range
+// of EVERY tile of the workgroup and leaves the tile's fp32 sums in LDS (tsum; wave order, then pass order: deterministic); the
+// last pass adds its own and runs the epilogue.  8 waves: the tile's 32 x 16 outputs are one per thread.
+template <int EPI, int NW, int UB, int NB>
+__global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream2_kernel(StreamArgs a) {
+    static_assert(NW == 8, "one epilogue thread per output of the two-tile block");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const size_t ldw = (size_t)(a.K >> 1);
+    float* red = reinterpret_cast<float*>(smem);                     // [2][NW][2][256]
+    f16* ex = reinterpret_cast<f16*>(red + 2 * NW * 512);            // [2][512]
+    float* tsum = reinterpret_cast<float*>(ex + 2 * 512);            // [tiles of this workgroup][512] (NB > 1)
+    const int c = tid & 15, m = tid >> 4;                            // epilogue thread: (token m of 32, tile column c)
+    const bool ethread = m < a.M;
+    const int ridx = (m >> 4) * 256 + (m & 3) * 64 + ((m >> 2) & 3) * 16 + c;
+    const int mc = m < a.M ? m : 0;
+    int64_t pos_m = 0, slot_m = -1;
+    if (EPI == SEPI_QKV) {
+        pos_m = a.positions[mc];
+        slot_m = a.slot_mapping[mc];
+    }
+    struct Pre {
+        f16 swn, cf, sf;
+    };
+    auto load_pre = [&](Pre& pre, int tile) {
+        pre.swn = a.ws[stile_row<EPI>(tile, c, a.I, a.hdl)];
+        if (EPI == SEPI_QKV) {
+            const int o = qkv_pair(tile, c & 7, a.I, a.hdl).i;
+            const f16* cs = a.cos_sin_cache + (pos_m << a.hdl);
+            pre.cf = cs[o];
+            pre.sf = cs[(1 << (a.hdl - 1)) + o];
+        }
+    };
+    auto wptr = [&](int tile, int p) -> const uint8_t* {
+        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I, a.hdl) * ldw + (size_t)p * (NW * UB * 64) + g * 16;
+    };
+    const int tile_first = blockIdx.x;
+    const int my_tiles = (a.ntiles - tile_first + (int)gridDim.x - 1) / (int)gridDim.x;
+    f16x8 af[2][UB][4];
+    auto load_af = [&](int p) {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            const f16* xp = a.x + (size_t)mt * 16 * a.K + (size_t)lane * 8;
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                const int kstep = p * (NW * UB) + (step_off<NW, UB>(wave, u) >> 6);
+#pragma unroll
+                for (int dd = 0; dd < 4; dd++) af[mt][u][dd] = *reinterpret_cast<const f16x8*>(xp + ((size_t)kstep * 4 + dd) * 512);
+            }
+        }
+    };
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto use = [&](const u32x4& wv, int u) {
+#pragma unroll
+        for (int dd = 0; dd < 4; dd++) {
+            const f16x8 b = sdequant_s4x8(wv[dd]);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][u][dd], b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1][u][dd], b, acc[1], 0, 0, 0);
+        }
+    };
+    int par = 0;
+    auto finish = [&](int tile, int ti, int p, const Pre& pre) {
+        float* rb = red + par * NW * 512;
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) rb[(wave * 2 + mt) * 256 + i * 64 + lane] = acc[mt][i];
+            acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        float sum = rb[ridx];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; w2++) sum = sum + rb[w2 * 512 + ridx];   // wave order: deterministic
+        par ^= 1;
+        if (NB > 1) {
+            if (p > 0) sum = tsum[ti * 512 + tid] + sum;                   // pass order
+            if (p < NB - 1) {
+                tsum[ti * 512 + tid] = sum;
+                return;
+            }
+        }
+        const f16 hv = f2h(sum * h2f(pre.swn));
+        if (EPI == SEPI_PLAIN) {
+            if (ethread) a.out[(size_t)m * a.N + tile * 16 + c] = hv;
+            return;
+        }
+        f16* e = ex + (par ^ 1) * 512;
+        e[tid] = hv;
+        __syncthreads();
+        if (!ethread) return;
+        const f16 partner = e[tid ^ 8];
+        if (EPI == SEPI_GATEUP) {
+            if (c < 8) {
+                const float gt = h2f(partner);
+                const float act = h2f(f2h(gt / (1.0f + qexpf(-gt))));
+                a.out[(size_t)m * a.I + tile * 8 + c] = f2h(act * h2f(hv));
+            }
+            return;
+        }
+        const QkvPair qp = qkv_pair(tile, c & 7, a.I, a.hdl);
+        const int head = qp.head, o = qp.i;
+        const int n = (head << a.hdl) + ((c >> 3) << (a.hdl - 1)) + o;
+        f16 res = hv;
+        if (head < a.nq + a.nkv) {
+            const float cff = h2f(pre.cf), sff = h2f(pre.sf);
+            const float xf = h2f(c < 8 ? hv : partner), yf = h2f(c < 8 ? partner : hv);
+            res = c < 8 ? f2h(h2f(f2h(xf * cff)) - h2f(f2h(yf * sff))) : f2h(h2f(f2h(yf * cff)) + h2f(f2h(xf * sff)));
+        }
+        a.out[(size_t)m * a.N + n] = res;
+        if (head >= a.nq && slot_m >= 0) {
+            const bool is_k = head < a.nq + a.nkv;
+            const int kvh = is_k ? head - a.nq : head - a.nq - a.nkv;
+            f16* cache = is_k ? a.key_cache : a.value_cache;
+            cache[((slot_m * a.nkv + kvh) << a.hdl) + ((c >> 3) << (a.hdl - 1)) + o] = res;
+        }
+    };
+    // the (pass, tile) units of this workgroup in order; the weights of unit q + 1 are requested behind the use of unit q's
+    const int n_units = NB * my_tiles;
+    u32x4 w[UB];
+    Pre pre = {};
+    load_af(0);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const uint8_t* wp0 = wptr(tile_first, 0);
+#pragma unroll
+        for (int u = 0; u < UB; u++) w[u] = wload<u32x4>(wp0 + step_off<NW, UB>(wave, u));
+        if (NB == 1) load_pre(pre, tile_first);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int p = 0, ti = 0, tile = tile_first;
+    for (int q = 0; q < n_units - 1; q++) {
+        int np = p, nti = ti + 1, ntile = tile + (int)gridDim.x;
+        if (nti == my_tiles) {
+            np = p + 1;
+            nti = 0;
+            ntile = tile_first;
+        }
+        const uint8_t* wp = wptr(ntile, np);
+        Pre npre = {};
+        if (np == NB - 1) load_pre(npre, ntile);
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            use(w[u], u);
+            __builtin_amdgcn_sched_barrier(0);
+            w[u] = wload<u32x4>(wp + step_off<NW, UB>(wave, u));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        finish(tile, ti, p, pre);
+        if (np != p) load_af(np);   // (behind the last use of pass p's fragments)
+        pre = npre;
+        p = np;
+        ti = nti;
+        tile = ntile;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; u++) use(w[u], u);
+    finish(tile, ti, p, pre);
+}
+
+// shapes of the two-tile kernel: K = 128 * 8 * UB * NB
+static bool stream32_shape(int K, int* UB, int* NB) {
+    static const int cand[][3] = {{4096, 4, 1}, {8192, 4, 2}, {28672, 4, 7}, {14336, 2, 7}, {5120, 5, 1}};
+    for (const auto& cnd : cand)
+        if (K == cnd[0]) {
+            *UB = cnd[1];
+            *NB = cnd[2];
+            return true;
+        }
+    return false;
+}
+bool gemm_w4a16_stream32_supported(int M, int N, int K) {
+    int UB, NB;
+    if (M < 17 || M > 32 || N % 16 || !stream32_shape(K, &UB, &NB)) return false;
+    const int cap = stream_cap(), nt = N / 16;
+    const int per = (nt + cap - 1) / cap;
+    return NB == 1 || (size_t)per * 2048 <= 96 * 1024;   // tsum: 2 KB per tile of a workgroup
+}
+template <int EPI, int UB, int NB>
+static int launch_stream32_inst(const StreamArgs& a, hipStream_t st) {
+    const int cap = stream_cap();
+    int grid = a.ntiles, per = 1;
+    if (grid > cap) {
+        per = (a.ntiles + cap - 1) / cap;
+        grid = (a.ntiles + per - 1) / per;
+    }
+    const size_t lds = (size_t)2 * 8 * 512 * 4 + 2 * 512 * 2 + (NB > 1 ? (size_t)per * 2048 : 0);
+    static size_t attr_set = 0;
+    if (lds > 64 * 1024 && lds > attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4a16_stream2_kernel<EPI, 8, UB, NB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -8;
+        attr_set = lds;
+    }
+    hipLaunchKernelGGL((gemm_w4a16_stream2_kernel<EPI, 8, UB, NB>), dim3(grid), dim3(8 * 64), lds, st, a);
+    return 0;
+}
+template <int EPI>
+static int launch_stream32(const StreamArgs& a, hipStream_t st) {
+    int UB, NB;
+    if (!gemm_w4a16_stream32_supported(a.M, a.N, a.K) || !stream32_shape(a.K, &UB, &NB)) return -1;
+#define QS_S32(UBV, NBV) if (UB == UBV && NB == NBV) return launch_stream32_inst<EPI, UBV, NBV>(a, st);
+    QS_S32(4, 1) QS_S32(4, 2) QS_S32(4, 7) QS_S32(2, 7) QS_S32(5, 1)
+#undef QS_S32
+    return -1;
+}
+// x: two fragment-major 16-row tiles (rows 0..15, 16..31), each 16 x K halves
+int gemm_w4a16_stream32(const f16* x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K, hipStream_t st) {
+    StreamArgs a{};
+    a.x = x; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = out; a.M = M; a.N = N; a.K = K; a.ntiles = N / 16;
+    return launch_stream32<SEPI_PLAIN>(a, st);
+}
+int gemm_w4a16_stream32_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
+                                 const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
+                                 const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st) {
+    if ((d != 128 && d != 64) || rot_dim != d || N != (nq + 2 * nkv) * d) return -1;
+    StreamArgs a{};
+    a.hdl = d == 64 ? 6 : 7;
+    a.x = x; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = qkv; a.M = M; a.N = N; a.K = K;
+    a.ntiles = N / 16; a.positions = positions; a.cos_sin_cache = cos_sin_cache; a.key_cache = key_cache;
+    a.value_cache = value_cache; a.slot_mapping = slot_mapping; a.nq = nq; a.nkv = nkv;
+    return launch_stream32<SEPI_QKV>(a, st);
+}
+int gemm_w4a16_stream32_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K, hipStream_t st) {
+    if (I % 8) return -1;
+    StreamArgs a{};
+    a.x = x; a.wq = reinterpret_cast<const uint8_t*>(wq); a.ws = ws; a.out = act; a.M = M; a.N = 2 * I; a.K = K; a.I = I;
+    a.ntiles = 2 * I / 16;
+    return launch_stream32<SEPI_GATEUP>(a, st);
+}
+
 template <int EPI, int NW, int UB>
 static int launch_stream16_inst(const StreamArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * NW * 1024 + 1024 + (size_t)2 * 16 * NW * 512;   // reduction + activation staging

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(1024) void heads_hadamard_merge_kernel(const float*
                                                                         const float* __restrict__ ws_ml, int S,
                                                                         f16* __restrict__ out16, int8_t* __restrict__ q,
                                                                         f16* __restrict__ scale, float had_scale,
-                                                                        float clip) {
+                                                                        float clip, int xp = 0) {
     // 1024 threads merge (CP = 4 or 8 columns each: 4x / 2x fewer loads and instructions per wave than with NH * 8
     // threads, and 4 waves per SIMD to hide them); the first NH * 8 threads then run the head transform, the others
     // retire.
@@ -451,7 +451,13 @@ __global__ __launch_bounds__(1024) void heads_hadamard_merge_kernel(const float*
 #pragma unroll
         for (int h = 0; h < 8; h++) {
             f16x2 o = {f2h(v0[h]), f2h(v1[h])};
-            *reinterpret_cast<f16x2*>(out16 + obase + (size_t)h * D) = o;
+            if (xp) {   // verify pass at <= 32 tokens: fragment-major tiles (columns k, k + 1 with k even sit two halves apart)
+                f16* po = out16 + w4a16_xperm_offset(t, (hg * 8 + h) * D + 2 * dc, NH * D);
+                po[0] = o[0];
+                po[2] = o[1];
+            } else {
+                *reinterpret_cast<f16x2*>(out16 + obase + (size_t)h * D) = o;
+            }
         }
         return;
     }
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(512) void heads_hadamard_merge_spread32_kernel(cons
     const f16 y = f2h(r * had_scale);
     if (xp) {   // verify pass: the o_proj launch's fragment-major layout (T <= 16): k and k + 4 are neighbours there
         const f16 y4 = f2h(dpp_xor<4>(h2f(y)));
-        if (!(col & 4)) *reinterpret_cast<f16x2*>(out16 + w4a16_xperm_offset(t, head * D + d)) = f16x2{y, y4};
+        if (!(col & 4)) *reinterpret_cast<f16x2*>(out16 + w4a16_xperm_offset(t, head * D + d, NH * D)) = f16x2{y, y4};
     } else {
         out16[(size_t)t * NH * D + (size_t)head * D + d] = y;
     }
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(1024) void heads_hadamard_mix_merge_spread_kernel(c
     const f16 y = f2h(acc);
     if (xp) {   // (k, k + 4) pairs, as in heads_hadamard_merge_spread32_kernel; heads in whole 16-lane groups
         const f16 y4 = f2h(dpp_xor<4>(h2f(y)));
-        if (act && !(col & 4)) *reinterpret_cast<f16x2*>(out16 + w4a16_xperm_offset(t, head * D + d)) = f16x2{y, y4};
+        if (act && !(col & 4)) *reinterpret_cast<f16x2*>(out16 + w4a16_xperm_offset(t, head * D + d, heads * D)) = f16x2{y, y4};
     } else if (act) {
         out16[(size_t)t * heads * D + (size_t)head * D + d] = y;
     }
@@ -663,7 +669,7 @@ bool heads_hadamard_mix_merge_spread_supported(int T, int heads, int d, int K) {
 int heads_hadamard_mix_merge_spread(const float* ws, int max_tokens, int n_splits, const f16* hadK, f16* out_f16,
                                     float* part_amax, float had_scale, int T, int heads, int d, int K, hipStream_t st, int xp) {
     if (T == 0) return 0;
-    if (xp && (part_amax != nullptr || T > 16)) return -1;
+    if (xp && (part_amax != nullptr || T > 32)) return -1;
     if (!heads_hadamard_mix_merge_spread_supported(T, heads, d, K) || n_splits < 1 || T > max_tokens) return -1;
     const float* ws_o = ws + paged_attention_ws_o_offset();
     const float* ws_ml = ws + paged_attention_ws_ml_offset(max_tokens, heads, d, n_splits);
@@ -799,7 +805,7 @@ __global__ __launch_bounds__(512) void heads_hadamard_merge_cols_kernel(const fl
 int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out_f16, int8_t* q, f16* scale,
                          float had_scale, float clip, int T, int heads, int d, hipStream_t st, int xp) {
     if (T == 0) return 0;
-    if (xp && (q != nullptr || heads != 32 || T > 16 || d != 128)) return -1;   // fragment-major fp16 rows: the spread 32-head form only
+    if (xp && (q != nullptr || !(heads == 32 || heads == 64) || T > 32 || d != 128)) return -1;   // fragment-major fp16 rows (no quantiser)
     if (d != 128) {   // generic head sizes (TinyLlama: 32 heads of 64): partials of paged_attention_generic_vec_kernel
         if (heads != 32 || d % 8 || d < 8 || d > 256 || n_splits < 1 || T > max_tokens) return -1;
         const int S = paged_attention_generic_splits(n_splits);
@@ -824,7 +830,7 @@ int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out
                            out_f16, had_scale, (float*)nullptr, xp);
         return 0;
     }
-    if (xp) return -1;
+    if (xp && heads != 64) return -1;
 #define QS_HHM(NHV)                                                                                                \
     if (heads == NHV) {                                                                                             \
         if (quant)                                                                                                  \
@@ -832,7 +838,7 @@ int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out
                                n_splits, out_f16, q, scale, had_scale, clip);                                       \
         else                                                                                                        \
             hipLaunchKernelGGL((heads_hadamard_merge_kernel<NHV, false>), dim3(T), dim3(1024), 0, st, ws_o, ws_ml, \
-                               n_splits, out_f16, q, scale, had_scale, clip);                                       \
+                               n_splits, out_f16, q, scale, had_scale, clip, xp);                                   \
         return 0;                                                                                                   \
     }
     QS_HHM(32) QS_HHM(64)
@@ -1149,7 +1155,7 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, mine, 0x50, 0xF, 0xF, false);   // quad_perm:[0,0,1,1]
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, mine, 0xFA, 0xF, 0xF, false);   // quad_perm:[2,2,3,3]
                 const uint32_t pair = (j & 1) ? ((lo >> 16) | (hi & 0xFFFF0000u)) : ((lo & 0xFFFFu) | (hi << 16));
-                if (active) *reinterpret_cast<uint32_t*>(out16 + w4a16_xperm_offset(t, (int)e0 - 2 * j) + 2 * j) = pair;
+                if (active) *reinterpret_cast<uint32_t*>(out16 + w4a16_xperm_offset(t, (int)e0 - 2 * j, I) + 2 * j) = pair;
             } else if (active) {
                 *reinterpret_cast<f16x2*>(out16 + (size_t)t * I + e0) = zz;
             }

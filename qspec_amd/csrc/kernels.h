@@ -39,6 +39,13 @@ int heads_hadamard_merge(const float* ws, int max_tokens, int n_splits, f16* out
                          float had_scale, float clip, int T, int heads, int d, hipStream_t st, int xp = 0);
 int silu_mul(const f16* gate_up, f16* out, int T, int I, hipStream_t st);
 bool mlp_hadamard_xperm_supported(int T, int I, int K);
+// 17..32 tokens: two fragment-major 16-row tiles, the two-token-tile streaming kernel (gemm_stream.hip: gemm_w4a16_stream2_kernel)
+bool gemm_w4a16_stream32_supported(int M, int N, int K);
+int gemm_w4a16_stream32(const f16* x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K, hipStream_t st);
+int gemm_w4a16_stream32_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
+                                 const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,
+                                 const int64_t* slot_mapping, int nq, int nkv, int d, int rot_dim, hipStream_t st);
+int gemm_w4a16_stream32_gate_up_silu(const f16* x, const int8_t* wq, const f16* ws, f16* act, int M, int I, int K, hipStream_t st);
 int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,
                       float clip, int T, int I, int K, int pre_activated, void* xws, hipStream_t st, int xp = 0);
 size_t xwg_workspace_bytes();

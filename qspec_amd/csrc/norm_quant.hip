@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* x, const f16* __rest
                 const f16x2 mine = __builtin_bit_cast(f16x2, odd ? hi : lo), other = __builtin_bit_cast(f16x2, got);
                 const f16x4 w4 = odd ? f16x4{other[0], mine[0], other[1], mine[1]} : f16x4{mine[0], other[0], mine[1], other[1]};
                 const int k0 = it * 1024 + 8 * (j >> 1);
-                *reinterpret_cast<f16x4*>(out + w4a16_xperm_offset(row, k0) + 4 * (j & 1)) = w4;
+                *reinterpret_cast<f16x4*>(out + w4a16_xperm_offset(row, k0, H) + 4 * (j & 1)) = w4;
             } else {
                 *reinterpret_cast<f16x4*>(out + (size_t)row * H + it * 1024 + 4 * j) = o;
             }
@@ -243,7 +243,7 @@ template <int MODE>
 static int launch_ln(const f16* x, const f16* delta, f16* hidden_out, f16* out, int8_t* q, f16* scale, f16* isum,
                      float eps, int T, int H, hipStream_t st, int xp = 0) {
     if (T == 0) return 0;
-    if (xp && (MODE != 1 || T > 16 || H % 128)) return -1;
+    if (xp && (MODE != 1 || T > 32 || H % 128)) return -1;
 #define QS_LN_CASE(NI)                                                                                        \
     case NI:                                                                                                  \
         hipLaunchKernelGGL((ln_kernel<NI, MODE>), dim3(T), dim3(256), 0, st, x, delta, hidden_out, out, q, scale, \
@@ -293,7 +293,7 @@ int ln_fp16_partial(const f16* x, const float* part, const f16* ws, int S, f16* 
                     int H, hipStream_t st, int xp) {
     if (T == 0) return 0;
     if (S < 1 || !part || !ws) return -1;
-    if (xp && (T > 16 || H % 128)) return -1;
+    if (xp && (T > 32 || H % 128)) return -1;
 #define QS_LNP_CASE(NI)                                                                                              \
     case NI:                                                                                                         \
         hipLaunchKernelGGL((ln_kernel<NI, 1>), dim3(T), dim3(256), 0, st, x, (const f16*)nullptr, hidden_out, out,   \

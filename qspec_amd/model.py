@@ -105,6 +105,9 @@ class Scratch:
         # (ops.w4a16_act_layout_supported); rows past T are never read back into a result
         z = lambda k: torch.zeros(16, k, dtype=f16, device=device)  # noqa: E731
         self.xp_normed, self.xp_had, self.xp_had_mlp = (z(H), z(cfg.q_size), z(I)) if T <= 16 else (None, None, None)
+        if 16 < T <= 32:   # two tiles each: the two-token-tile W4A16 streaming kernel (ops.w4a16_act_layout32_supported)
+            self.xp_normed = torch.zeros(32, H, dtype=f16, device=device)
+            self.xp_had = torch.zeros(32, cfg.q_size, dtype=f16, device=device)
         self.tp_part = e(1, min(T, 32), H, dtype=torch.float32)   # TP verify pass (T <= 32): fp32 row-parallel partials
         self.had_part_amax = e(min(T, 16), 8, dtype=torch.float32)  # draft pass (T <= 4): partial row maxima of the spread head Hadamard
         # draft pass at 17..32 tokens: int32 K-slice sums of down_proj + the activation scales they were computed with
@@ -298,6 +301,18 @@ class QuarotLlamaForCausalLM:
         xp = not w4a4 and fuse and not tp_on and self._fragment_major_ok(T, md, s)
         if xp:
             normed_x, had_x = s.xp_normed, s.xp_had
+        # verify pass at 17..32 tokens (one GPU): qkv / o_proj / gate_up on the two-token-tile W4A16 streaming kernel over two
+        # fragment-major tiles (fused epilogues as at <= 16 tokens); down_proj stays on the M-tiled kernel (its K passes lose)
+        xp32 = (not w4a4 and not fuse and not tp_sharded and 16 < T <= 32 and self.ACT_FRAGMENT_MAJOR and self.MERGE_IN_HADAMARD
+                and hd == 128 and md.n_splits <= 64 and s.xp_normed is not None and s.xp_normed.shape[0] == 32
+                and ops.w4a16_act_layout32_supported(T, row, cfg.hidden_size)
+                and ops.w4a16_act_layout32_supported(T, cfg.hidden_size, cfg.q_size)
+                and ops.w4a16_act_layout32_supported(T, 2 * cfg.intermediate_size, cfg.hidden_size)
+                and (nh in (32, 64) if self.head_had_K == 1 else
+                     ops.heads_hadamard_mix_merged_spread_supported(T, nh, hd, self.head_had_K)))
+        if xp32:
+            normed_x, had_x = s.xp_normed, s.xp_had
+        self.last_forward_form = "two-tile" if xp32 else ("fragment-major" if xp else ("fused" if fuse else "unfused"))   # (tests)
         # draft pass at 17..32 tokens: down_proj as K slices (0 / 1 = the plain launch)
         S_down = (ops.rowwise_scaled_linear_s4s4_partial_slices(T, cfg.hidden_size, cfg.intermediate_size)
                   if (w4a4 and fuse and not ln_fused and s.down_ipart is not None and self.DOWN_K_SLICES) else 0)
@@ -340,13 +355,15 @@ class QuarotLlamaForCausalLM:
                 else:
                     ops.add_rms_norm_i4(q1, sc, hidden, hidden, delta, eps)
                 x, xs = q1, sc
-            elif xp:
+            elif xp or xp32:
                 self._add_norm_fp16(normed_x, hidden, delta, eps, xp=True)
                 x, xs = normed_x, None
             else:
                 self._add_norm_fp16(normed, hidden, delta, eps)
                 x, xs = normed, None
-            if fuse:
+            if xp32:
+                ops.qkv_rope_linear_xp32(x, qkv_w, qkv_s, qkv, positions, self.cos_sin_cache, kc, vc, md.slot_mapping, nh, nkv, hd, T)
+            elif fuse:
                 ops.qkv_rope_linear(x, xs, qkv_w, qkv_s, qkv, positions, self.cos_sin_cache, kc, vc, md.slot_mapping,
                                     nh, nkv, hd, xp=xp, tokens=T)
             else:
@@ -364,6 +381,11 @@ class QuarotLlamaForCausalLM:
             elif xp:
                 self._attention_hadamard(qkv, row, kc, vc, md, T, s, attn, None, None, had_x, xp=True)
                 self._w4a16(had_x, layer.o_proj, o, xp=True, tokens=T)
+                ops.add_rms_norm_fp16(normed_x, hidden, hidden, o, eps, xp=True)
+                x, xs = normed_x, None
+            elif xp32:
+                self._attention_hadamard(qkv, row, kc, vc, md, T, s, attn, None, None, had_x, xp=True)
+                ops.w4a16_linear_xp32(had_x, layer.o_proj.weight, layer.o_proj._scales(), o, T)
                 ops.add_rms_norm_fp16(normed_x, hidden, hidden, o, eps, xp=True)
                 x, xs = normed_x, None
             else:
@@ -397,7 +419,11 @@ class QuarotLlamaForCausalLM:
                         ops.add_rms_norm_fp16(normed, hidden, hidden, o, eps)
                 x, xs = normed, None
             # gate_up -> silu*up -> online hadamard (+ quant) -> down_proj                              :266-299
-            if fuse:
+            if xp32:
+                ops.gate_up_silu_linear_xp32(x, gu_w, gu_s, act, T)
+                had_mlp_in = s.act_buffer_gate_up.view(-1)[:T * cfg.intermediate_size].view(T, cfg.intermediate_size)
+                ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, out_f16=had_mlp_in)
+            elif fuse:
                 if tp_on:   # column-parallel gate_up: own channels of [T, I], then all-gather of the channel ranges
                     c0, c1 = self.tp.channel_range(cfg.intermediate_size)
                     ops.gate_up_silu_linear_shard(x, gu_w, gu_s, act, c0, c1 - c0)

@@ -79,10 +79,11 @@ def add_rms_norm_i4(out_q, scaling, hidden_out, x, delta, eps: float):
           _stream())
 
 
-def _xp_tile(t, name, K):
-    """A fragment-major activation tile always holds 16 rows (w4a16_act_layout_supported)."""
-    if t.numel() < 16 * K:
-        raise RuntimeError(f"{name}: a fragment-major tile is 16 x {K} halves, got {tuple(t.shape)}")
+def _xp_tile(t, name, K, tokens: int = 16):
+    """A fragment-major activation tile always holds 16 rows (w4a16_act_layout_supported); 17..32 tokens: two tiles."""
+    rows = 16 if tokens <= 16 else 32
+    if t.numel() < rows * K:
+        raise RuntimeError(f"{name}: {rows // 16} fragment-major tile(s) of 16 x {K} halves, got {tuple(t.shape)}")
     return t
 
 
@@ -93,6 +94,41 @@ def w4a16_act_layout_supported(M: int, K: int) -> bool:
     return bool(_lib.load().qspec_w4a16_act_layout_supported(M, K))
 
 
+def w4a16_act_layout32_supported(M: int, N: int, K: int) -> bool:
+    """17..32 tokens: the two-token-tile W4A16 streaming kernel takes (M, N, K); x is then two fragment-major tiles [2, 16, K]."""
+    return bool(_lib.load().qspec_w4a16_act_layout32_supported(M, N, K))
+
+
+def _xp32_tiles(t, name, K):
+    if t.numel() < 32 * K:
+        raise RuntimeError(f"{name}: two fragment-major tiles are 2 x 16 x {K} halves, got {tuple(t.shape)}")
+    return _chk(t, name, _F16)
+
+
+def w4a16_linear_xp32(x, wq, w_scale, out, tokens: int):
+    N, K = wq.shape[0], wq.shape[1] * 2
+    _call("qspec_w4a16_linear_xp32", _xp32_tiles(x, "x", K), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
+          _chk(out, "out", _F16), tokens, N, K, _stream())
+    return out
+
+
+def qkv_rope_linear_xp32(x, wq, w_scale, qkv, positions, cos_sin_cache, key_cache, value_cache, slot_mapping, num_heads,
+                         num_kv_heads, head_size, tokens: int):
+    N, K = wq.shape[0], wq.shape[1] * 2
+    _call("qspec_qkv_rope_linear_w4a16_xp32", _xp32_tiles(x, "x", K), _chk(wq, "wq", (_I8, _U8)), _chk(w_scale, "w_scale", _F16),
+          _chk(qkv, "qkv", _F16), tokens, N, K, _chk(positions, "positions", _I64), _chk(cos_sin_cache, "cos_sin_cache", _F16),
+          _chk(key_cache, "key_cache", _F16), _chk(value_cache, "value_cache", _F16), _chk(slot_mapping, "slot_mapping", _I64),
+          num_heads, num_kv_heads, head_size, cos_sin_cache.shape[-1], _stream())
+    return qkv
+
+
+def gate_up_silu_linear_xp32(x, wq, w_scale, act, tokens: int):
+    I, K = wq.shape[0] // 2, wq.shape[1] * 2
+    _call("qspec_gate_up_silu_linear_w4a16_xp32", _xp32_tiles(x, "x", K), _chk(wq, "wq", (_I8, _U8)),
+          _chk(w_scale, "w_scale", _F16), _chk(act, "act", _F16), tokens, I, K, _stream())
+    return act
+
+
 def mlp_hadamard_act_layout_supported(T: int, I: int, K: int) -> bool:
     return XWG_SPREAD and bool(_lib.load().qspec_mlp_hadamard_act_layout_supported(T, I, K))
 
@@ -101,7 +137,7 @@ def add_rms_norm_fp16(out, hidden_out, x, delta, eps: float, xp: bool = False):
     H = x.shape[-1]
     T = x.numel() // H
     if xp:
-        _xp_tile(out, "out", H)
+        _xp_tile(out, "out", H, T)
     _call("qspec_add_rms_norm_fp16" + ("_xp" if xp else ""), _chk(out, "out", _F16), _opt(hidden_out, "hidden_out", _F16),
           _chk(x, "x", _F16), _opt(delta, "delta", _F16), float(eps), T, H, _stream())
 
@@ -420,7 +456,7 @@ def add_rms_norm_fp16_partial(out, hidden_out, x, part, w_scale, slices: int, ep
     H = x.shape[-1]
     T = x.numel() // H
     if xp:
-        _xp_tile(out, "out", H)
+        _xp_tile(out, "out", H, T)
     _call("qspec_add_rms_norm_fp16_partial" + ("_xp" if xp else ""), _chk(out, "out", _F16), _chk(hidden_out, "hidden_out", _F16),
           _chk(x, "x", _F16), _chk(part, "part", _F32), _chk(w_scale, "w_scale", _F16), slices, float(eps), T, H, _stream())
 
@@ -548,7 +584,7 @@ def heads_hadamard_merged(workspace, max_tokens, n_splits, tokens, heads, head_d
                           q=None, scale=None, clip_ratio: float = 1.0, xp: bool = False):
     """Split merge of paged_attention(..., out=None) + heads_hadamard in one launch."""
     if xp:
-        _xp_tile(out_f16, "out_f16", heads * head_dim)
+        _xp_tile(out_f16, "out_f16", heads * head_dim, tokens)
     _call("qspec_heads_hadamard_merged" + ("_xp" if xp else ""), workspace.data_ptr(), max_tokens, n_splits, _opt(out_f16, "out_f16", _F16),
           _opt(q, "q", _I8), _opt(scale, "scale", _F16), float(had_scale), float(clip_ratio), tokens, heads, head_dim,
           _stream())
@@ -570,7 +606,7 @@ def heads_hadamard_mix_merged_spread(workspace, max_tokens, n_splits, tokens, he
     """The spread merge + head transform for head counts with a table factor (40 heads = had40): fp16 rows, and with
     part_amax [tokens, 8] the partial row maxima for rowwise_scaled_linear_s4s4_residual_hq."""
     if xp:
-        _xp_tile(out_f16, "out_f16", heads * head_dim)
+        _xp_tile(out_f16, "out_f16", heads * head_dim, tokens)
     _call("qspec_heads_hadamard_mix_merged_spread" + ("_xp" if xp else ""), workspace.data_ptr(), max_tokens, n_splits, _chk(hadK, "hadK", _F16), K,
           _chk(out_f16, "out_f16", _F16), _opt(part_amax, "part_amax", _F32), float(had_scale), tokens, heads, head_dim,
           _stream())

@@ -224,3 +224,74 @@ def test_unsupported_shapes_fail_loudly(ops, oracle):
     with pytest.raises(RuntimeError):   # a tile always has 16 rows
         ops.add_rms_norm_fp16(torch.empty(4, 4096, dtype=torch.float16, device=DEV), None, dev(rand_hidden(rng, 4, 4096)), None,
                               1e-5, xp=True)
+
+
+# ------------------------------------------------------------------ 17..32 tokens: two tiles, the two-token-tile streaming kernel
+
+def to_tiles32(x):
+    """Row-major [M <= 32, K] fp16 (numpy) -> device [2, 16, K]: rows 0..15 and 16..31 as fragment-major tiles (NaN padding)."""
+    M, K = x.shape
+    flat = np.full(2 * 16 * K, np.nan, np.float16)
+    off = xp_offsets(K)
+    for t in range(2):
+        rows = x[16 * t: min(M, 16 * t + 16)]
+        if len(rows):
+            flat[16 * K * t + off[:len(rows)].ravel()] = rows.ravel()
+    return dev(flat.reshape(2, 16, K))
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 4096, 4096), (17, 1024, 4096), (24, 10240, 8192), (32, 8192, 8192), (32, 2048, 28672),
+                                   (20, 4096, 14336), (32, 5120, 5120), (32, 57344, 8192)])
+def test_two_tile_linear_within_1e3(ops, oracle, M, N, K):
+    """The two-token-tile W4A16 streaming kernel (K in 1 / 2 / 7 passes) against the oracle, and deterministic."""
+    assert ops.w4a16_act_layout32_supported(M, N, K)
+    rng = np.random.default_rng(M + N + K)
+    x = rand_hidden(rng, M, K)
+    wq_np = oracle.pack_i4(rand_w4(rng, N, K))
+    ws_np = (rng.random(N) * 0.002 + 0.0005).astype(np.float16)
+    wq, ws = dev(wq_np), dev(ws_np)
+    out = torch.full((M + 1, N), 7.0, dtype=torch.float16, device=DEV)
+    ops.w4a16_linear_xp32(to_tiles32(x), wq, ws, out[:M], M)
+    if N * K <= 10240 * 8192:
+        from test_kernels_gpu import assert_close_1e3
+        assert_close_1e3(host(out[:M]), oracle.gemm_w4a16(x, wq_np, ws_np))
+    ref = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.w4a16_linear(dev(x), wq, ws, ref)     # the M-tiled kernel: another summation order
+    d = (out[:M].float() - ref.float()).abs() / (1e-3 * ref.float().abs().clamp(min=1.0))
+    assert float(d.max()) <= 2.0, float(d.max())
+    assert torch.all(out[M] == 7.0)
+    again = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.w4a16_linear_xp32(to_tiles32(x), wq, ws, again, M)
+    assert same_bits(again, out[:M])
+
+
+@pytest.mark.parametrize("M,K,nq,nkv,I", [(32, 4096, 32, 8, 14336), (19, 8192, 16, 2, 3584)])
+def test_two_tile_fused_epilogues(ops, oracle, M, K, nq, nkv, I):
+    """qkv + RoPE + KV write and gate_up + silu on the two-tile kernel == its plain form followed by the separate ops."""
+    rng = np.random.default_rng(M + K)
+    d, bs = 128, 16
+    N = (nq + 2 * nkv) * d
+    x = to_tiles32(rand_hidden(rng, M, K))
+    wq = dev(oracle.pack_i4(rand_w4(rng, N, K)))
+    ws = dev((rng.random(N) * 0.002 + 0.0005).astype(np.float16))
+    pos = dev(rng.integers(0, 2000, M).astype(np.int64))
+    cs = dev(oracle.make_cos_sin_cache(d, 2048, 10000.0))
+    slots_np = rng.permutation(64 * bs)[:M].astype(np.int64)
+    slots_np[1] = -1
+    slots = dev(slots_np)
+    ref = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.w4a16_linear_xp32(x, wq, ws, ref, M)
+    kc0 = torch.zeros(64, bs, nkv, d, dtype=torch.float16, device=DEV); vc0 = torch.zeros_like(kc0)
+    ops.rope_kv_write(pos, ref, cs, kc0, vc0, slots, nq, nkv, d)
+    out = torch.empty_like(ref)
+    kc1 = torch.zeros_like(kc0); vc1 = torch.zeros_like(kc0)
+    ops.qkv_rope_linear_xp32(x, wq, ws, out, pos, cs, kc1, vc1, slots, nq, nkv, d, M)
+    torch.cuda.synchronize()
+    assert same_bits(out, ref) and torch.equal(kc1, kc0) and torch.equal(vc1, vc0)
+    gw = dev(oracle.pack_i4(rand_w4(rng, 2 * I, K)))
+    gs = dev((rng.random(2 * I) * 0.002 + 0.0005).astype(np.float16))
+    gu = torch.empty(M, 2 * I, dtype=torch.float16, device=DEV)
+    ops.w4a16_linear_xp32(x, gw, gs, gu, M)
+    a0 = ops.silu_mul(gu, torch.empty(M, I, dtype=torch.float16, device=DEV))
+    a1 = ops.gate_up_silu_linear_xp32(x, gw, gs, torch.empty(M, I, dtype=torch.float16, device=DEV), M)
+    assert same_bits(a0, a1)

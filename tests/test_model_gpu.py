@@ -707,6 +707,43 @@ def test_fragment_major_activation_tiles_change_no_bit(family, ctx_lens, q_len, 
         assert torch.equal(ka, kb) and torch.equal(va, vb)
 
 
+@pytest.mark.parametrize("family,n_seqs,q_len", [("llama-3-8b", 8, 4), ("llama-3-8b", 5, 4), ("llama-3-70b", 8, 4), ("llama-2-13b", 6, 4)])
+def test_two_tile_verify_layers_at_17_to_32_tokens(oracle, family, n_seqs, q_len, monkeypatch):
+    """Verify pass at 17..32 tokens: qkv / o_proj / gate_up on the two-token-tile W4A16 streaming kernel over two fragment-major
+    tiles (model.forward picks it where every layer shape has the form) against the M-tiled path (ACT_FRAGMENT_MAJOR off): two
+    fp32 summation orders, so the normed hidden state within the W4A16 bar of the fused-vs-module-wise tests and the KV rows
+    within 1e-3; and against the oracle within the noise floor, as test_model_family_layer_matches_oracle does."""
+    from oracle.model import OracleModel
+    from qspec_amd.model import QuarotLlamaConfig, QuarotLlamaForCausalLM, Scratch
+    H, I, nh, nkv, theta = FAMILIES[family]
+    cfg = QuarotLlamaConfig(H, I, nh, nkv, 1, 1024, 1e-5, theta, 512, family + "-1layer")
+    model = QuarotLlamaForCausalLM(cfg, DEV).init_synthetic(seed=9, lm_head_std=0.05)
+    rng = np.random.default_rng(10)
+    ctx_lens = [33 + 17 * i for i in range(n_seqs)]
+    inp = make_inputs(model, rng, ctx_lens, q_len)
+    T = inp["T"]
+    assert 16 < T <= 32
+    s = Scratch(cfg, T, n_seqs, q_len, inp["n_splits"], DEV)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(model, "ACT_FRAGMENT_MAJOR", on)
+        kv = [(k.clone(), v.clone()) for k, v in inp["kv_t"]]
+        outs.append((model.forward(inp["ids_t"], inp["pos_t"], kv, inp["md"], s, w4a4=False).clone(), kv))
+        assert model.last_forward_form == ("two-tile" if on else "unfused")
+    torch.cuda.synchronize()
+    (a, kva), (b, kvb) = outs
+    assert (a.float() - b.float()).abs().max().item() < 2e-2
+    for (ka, va), (kb, vb) in zip(kva, kvb):
+        assert (ka.float() - kb.float()).abs().max().item() <= 1e-3 * max(1.0, kb.float().abs().max().item())
+        assert (va.float() - vb.float()).abs().max().item() <= 1e-3 * max(1.0, vb.float().abs().max().item())
+    om = OracleModel.from_torch_model(model, 16)
+    kv_np = [(k.copy(), v.copy()) for k, v in inp["kv_np"]]
+    ref = om.forward(inp["ids"], inp["pos"], kv_np, inp["slots"], inp["bt"], inp["ctx"], inp["q_start"], False)
+    floor, rel = _w4a16_noise_floor(om, inp, ref), _rel3(a.cpu().numpy(), ref)
+    assert np.quantile(rel, 0.99) < max(1.5 * np.quantile(floor, 0.99), 2.0) and rel.max() < max(2.0 * floor.max(), 4.0), \
+        (np.quantile(rel, 0.99), np.quantile(floor, 0.99), rel.max(), floor.max())
+
+
 def test_verify_o_proj_k_sliced_dev_knob_meets_the_same_bar(oracle, monkeypatch):
     """QSPEC_VERIFY_O_SLICES (model.py, dev knob; measured in rounds 1 and 3 and left off: DESIGN.md section 4): the verify pass's
     o_proj as K slices whose raw fp32 sums the following norm finishes, as down_proj's are.  Same comparison and bars as
