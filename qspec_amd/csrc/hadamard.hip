@@ -451,10 +451,13 @@ __global__ __launch_bounds__(1024) void heads_hadamard_merge_kernel(const float*
 #pragma unroll
         for (int h = 0; h < 8; h++) {
             f16x2 o = {f2h(v0[h]), f2h(v1[h])};
-            if (xp) {   // verify pass at <= 32 tokens: fragment-major tiles (columns k, k + 1 with k even sit two halves apart)
-                f16* po = out16 + w4a16_xperm_offset(t, (hg * 8 + h) * D + 2 * dc, NH * D);
-                po[0] = o[0];
-                po[2] = o[1];
+            if (xp) {   // verify pass at <= 32 tokens: fragment-major tiles.  Lane dc holds columns (2 dc, 2 dc + 1); the layout
+                // wants (k, k + 4) side by side: lanes with dc & 2 == 0 take their partner's pair (lane ^ 2) and store the four
+                // halves k, k + 4, k + 1, k + 5 as one 8-byte group
+                const f16x2 po = __builtin_bit_cast(f16x2, dpp_xor<2>(__builtin_bit_cast(float, o)));
+                if (!(dc & 2))
+                    *reinterpret_cast<f16x4*>(out16 + w4a16_xperm_offset(t, (hg * 8 + h) * D + 2 * dc, NH * D)) =
+                        f16x4{o[0], po[0], o[1], po[1]};
             } else {
                 *reinterpret_cast<f16x2*>(out16 + obase + (size_t)h * D) = o;
             }

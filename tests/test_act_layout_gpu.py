@@ -295,3 +295,45 @@ def test_two_tile_fused_epilogues(ops, oracle, M, K, nq, nkv, I):
     a0 = ops.silu_mul(gu, torch.empty(M, I, dtype=torch.float16, device=DEV))
     a1 = ops.gate_up_silu_linear_xp32(x, gw, gs, torch.empty(M, I, dtype=torch.float16, device=DEV), M)
     assert same_bits(a0, a1)
+
+
+def from_tiles32(t, M):
+    """Device [2, 16, K] (two fragment-major tiles) -> row-major numpy [M, K]."""
+    K = t.shape[-1]
+    flat = host(t).ravel()
+    off = xp_offsets(K)
+    rows = [flat[16 * K * (r >> 4) + off[r & 15]] for r in range(M)]
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("T,H", [(17, 4096), (32, 8192), (24, 5120)])
+def test_norm_writes_two_tiles(ops, T, H):
+    rng = np.random.default_rng(T + H)
+    x = dev(rand_hidden(rng, T, H)); delta = dev(rand_hidden(rng, T, H))
+    n0 = torch.empty(T, H, dtype=torch.float16, device=DEV); h0 = torch.empty_like(n0)
+    ops.add_rms_norm_fp16(n0, h0, x, delta, 1e-5)
+    n1 = torch.full((2, 16, H), float("nan"), dtype=torch.float16, device=DEV); h1 = torch.empty_like(n0)
+    ops.add_rms_norm_fp16(n1, h1, x, delta, 1e-5, xp=True)
+    assert same_bits(from_tiles32(n1, T), n0) and same_bits(h0, h1)
+    S = 3
+    part = dev((rng.standard_normal((S, T, H)) * 300).astype(np.float32))
+    ws = dev((rng.random(H) * 0.002 + 0.0005).astype(np.float16))
+    ops.add_rms_norm_fp16_partial(n0, h0, x, part, ws, S, 1e-5)
+    n1.fill_(float("nan"))
+    ops.add_rms_norm_fp16_partial(n1, h1, x, part, ws, S, 1e-5, xp=True)
+    assert same_bits(from_tiles32(n1, T), n0) and same_bits(h0, h1)
+
+
+@pytest.mark.parametrize("nq,nkv,ctx_lens,q_len", [(32, 8, [37, 128, 129, 500, 77], 4), (64, 8, [600, 40, 300, 90, 17, 260, 33, 511], 4),
+                                                   (64, 8, [70, 200, 45], 4)])
+def test_head_transform_writes_two_tiles(ops, oracle, nq, nkv, ctx_lens, q_len):
+    """32 heads: the spread kernel; 64 heads (Llama-3-70B): the one-workgroup kernel's 8-byte groups."""
+    rng = np.random.default_rng(sum(ctx_lens) + nq)
+    d, n_splits = 128, 4
+    ws, T = _attention_partials(ops, rng, nq, nkv, ctx_lens, q_len, n_splits)
+    sc = oracle.rsqrt_scale(nq)
+    o0 = torch.empty(T, nq * d, dtype=torch.float16, device=DEV)
+    ops.heads_hadamard_merged(ws, T, n_splits, T, nq, d, sc, out_f16=o0)
+    o1 = torch.full((2, 16, nq * d), float("nan"), dtype=torch.float16, device=DEV)
+    ops.heads_hadamard_merged(ws, T, n_splits, T, nq, d, sc, out_f16=o1, xp=True)
+    assert same_bits(from_tiles32(o1, T), o0)
