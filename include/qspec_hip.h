@@ -518,6 +518,9 @@ int qspec_w4a16_act_layout_supported(int M, int K);
 int qspec_w4a16_act_layout32_supported(int M, int N, int K);
 int qspec_w4a16_linear_xp32(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* out, int M, int N, int K,
                             void* stream);
+/* long-K layers (down_proj): K slices across the workgroups, raw fp32 sums part [slices][M][N] for qspec_add_rms_norm_fp16_partial */
+int qspec_w4a16_linear_partial_slices_xp32(int M, int N, int K);
+int qspec_w4a16_linear_partial_xp32(const qspec_half* x, const int8_t* wq, float* part, int M, int N, int K, int slices, void* stream);
 int qspec_qkv_rope_linear_w4a16_xp32(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M,
                                      int N, int K, const int64_t* positions, const qspec_half* cos_sin_cache,
                                      qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,

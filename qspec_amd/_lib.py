@@ -114,6 +114,8 @@ SIGNATURES.update({name + "_xp": SIGNATURES[name] for name in XP_TWINS})
 SIGNATURES["qspec_w4a16_act_layout_supported"] = (_i, [_i, _i])
 SIGNATURES["qspec_w4a16_act_layout32_supported"] = (_i, [_i, _i, _i])
 SIGNATURES["qspec_w4a16_linear_xp32"] = (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp])
+SIGNATURES["qspec_w4a16_linear_partial_slices_xp32"] = (_i, [_i, _i, _i])
+SIGNATURES["qspec_w4a16_linear_partial_xp32"] = (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp])
 SIGNATURES["qspec_qkv_rope_linear_w4a16_xp32"] = (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp])
 SIGNATURES["qspec_gate_up_silu_linear_w4a16_xp32"] = (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp])
 SIGNATURES["qspec_mlp_hadamard_act_layout_supported"] = (_i, [_i, _i, _i])

@@ -245,6 +245,16 @@ int qspec_w4a16_linear_xp32(const qspec_half* x, const int8_t* wq, const qspec_h
         return fail("%s: no two-tile streaming form for (M=%d N=%d K=%d): ask qspec_w4a16_act_layout32_supported", op, M, N, K);
     return finish(op, qspec::gemm_w4a16_stream32(CH(x), wq, CH(ws), H(out), M, N, K, ST));
 }
+int qspec_w4a16_linear_partial_slices_xp32(int M, int N, int K) { return use_stream() ? qspec::gemm_w4a16_stream32_partial_slices(M, N, K) : 0; }
+int qspec_w4a16_linear_partial_xp32(const qspec_half* x, const int8_t* wq, float* part, int M, int N, int K, int slices, void* stream) {
+    const char* op = "qspec_w4a16_linear_partial_xp32";
+    if (M == 0 || N == 0) return 0;
+    NONNULL(op, x); NONNULL(op, wq); NONNULL(op, part);
+    if (slices < 2 || slices != qspec_w4a16_linear_partial_slices_xp32(M, N, K))
+        return fail("%s: (M=%d N=%d K=%d) takes %d slices (qspec_w4a16_linear_partial_slices_xp32), got %d", op, M, N, K,
+                    qspec_w4a16_linear_partial_slices_xp32(M, N, K), slices);
+    return finish(op, qspec::gemm_w4a16_stream32_partial(CH(x), wq, part, M, N, K, slices, ST));
+}
 int qspec_qkv_rope_linear_w4a16_xp32(const qspec_half* x, const int8_t* wq, const qspec_half* ws, qspec_half* qkv, int M,
                                      int N, int K, const int64_t* positions, const qspec_half* cos_sin_cache,
                                      qspec_half* key_cache, qspec_half* value_cache, const int64_t* slot_mapping,
@@ -587,8 +597,8 @@ int qspec_mlp_hadamard(const qspec_half* act, const qspec_half* hadK, qspec_half
     if (K > 1) NONNULL(op, hadK);
     if (q) { NONNULL(op, scale); } else { NONNULL(op, out_f16); }
     if (intermediate % 8) return fail("%s: intermediate %% 8 != 0", op);
-    if (g_xp && (q || tokens > 16 || !workspace))
-        return fail("%s: the fragment-major fp16 output exists in the spread forms (workspace), <= 16 tokens, no quantiser", op);
+    if (g_xp && (q || tokens > 32))
+        return fail("%s: the fragment-major fp16 output: <= 32 tokens, no quantiser", op);
     return finish(op, qspec::silu_mul_hadamard(CH(act), CH(hadK), H(out_f16), q, H(scale), had_scale, clip_ratio, tokens, intermediate, K, 1, workspace, ST, g_xp));
 }
 int qspec_mlp_hadamard_xp(const qspec_half* act, const qspec_half* hadK, qspec_half* out_f16, int8_t* q, qspec_half* scale,

@@ -2189,7 +2189,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream2_kernel(StreamArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const size_t ldw = (size_t)(a.K >> 1);
+    // SEPI_PARTIAL (NB = 1): blockIdx.y picks one of gridDim.y K slices of length K out of rows of ldx halves (x tiles) / ldw bytes
+    // (weights); the raw fp32 sums go to part[blockIdx.y] and are combined in slice order by the norm that follows
+    const size_t kofs = EPI == SEPI_PARTIAL ? (size_t)blockIdx.y * a.K : 0;
+    const size_t ldw = a.ldw ? (size_t)a.ldw : (size_t)(a.K >> 1), Kx = a.ldx ? (size_t)a.ldx : (size_t)a.K;
     float* red = reinterpret_cast<float*>(smem);                     // [2][NW][2][256]
     f16* ex = reinterpret_cast<f16*>(red + 2 * NW * 512);            // [2][512]
     float* tsum = reinterpret_cast<float*>(ex + 2 * 512);            // [tiles of this workgroup][512] (NB > 1)
@@ -2206,7 +2209,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream2_kernel(StreamArgs 
         f16 swn, cf, sf;
     };
     auto load_pre = [&](Pre& pre, int tile) {
-        pre.swn = a.ws[stile_row<EPI>(tile, c, a.I, a.hdl)];
+        if (EPI != SEPI_PARTIAL) pre.swn = a.ws[stile_row<EPI>(tile, c, a.I, a.hdl)];
         if (EPI == SEPI_QKV) {
             const int o = qkv_pair(tile, c & 7, a.I, a.hdl).i;
             const f16* cs = a.cos_sin_cache + (pos_m << a.hdl);
@@ -2215,7 +2218,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream2_kernel(StreamArgs 
         }
     };
     auto wptr = [&](int tile, int p) -> const uint8_t* {
-        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I, a.hdl) * ldw + (size_t)p * (NW * UB * 64) + g * 16;
+        return a.wq + (size_t)stile_row<EPI>(tile, r, a.I, a.hdl) * ldw + (kofs >> 1) + (size_t)p * (NW * UB * 64) + g * 16;
     };
     const int tile_first = blockIdx.x;
     const int my_tiles = (a.ntiles - tile_first + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -2223,7 +2226,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream2_kernel(StreamArgs 
     auto load_af = [&](int p) {
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
-            const f16* xp = a.x + (size_t)mt * 16 * a.K + (size_t)lane * 8;
+            const f16* xp = a.x + (size_t)mt * 16 * Kx + (kofs >> 7) * 2048 + (size_t)lane * 8;
 #pragma unroll
             for (int u = 0; u < UB; u++) {
                 const int kstep = p * (NW * UB) + (step_off<NW, UB>(wave, u) >> 6);
@@ -2261,6 +2264,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_w4a16_stream2_kernel(StreamArgs 
                 tsum[ti * 512 + tid] = sum;
                 return;
             }
+        }
+        if (EPI == SEPI_PARTIAL) {
+            if (ethread) a.part[((size_t)blockIdx.y * a.M + m) * a.N + tile * 16 + c] = sum;
+            return;
         }
         const f16 hv = f2h(sum * h2f(pre.swn));
         if (EPI == SEPI_PLAIN) {
@@ -2360,7 +2367,8 @@ bool gemm_w4a16_stream32_supported(int M, int N, int K) {
 }
 template <int EPI, int UB, int NB>
 static int launch_stream32_inst(const StreamArgs& a, hipStream_t st) {
-    const int cap = stream_cap();
+    const int slices = EPI == SEPI_PARTIAL ? a.nq : 1;   // (nq carries the slice count for SEPI_PARTIAL)
+    const int cap = slices > 1 ? (stream_cap() / slices > 0 ? stream_cap() / slices : 1) : stream_cap();   // one workgroup per CU in all
     int grid = a.ntiles, per = 1;
     if (grid > cap) {
         per = (a.ntiles + cap - 1) / cap;
@@ -2374,8 +2382,24 @@ static int launch_stream32_inst(const StreamArgs& a, hipStream_t st) {
             return -8;
         attr_set = lds;
     }
-    hipLaunchKernelGGL((gemm_w4a16_stream2_kernel<EPI, 8, UB, NB>), dim3(grid), dim3(8 * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_w4a16_stream2_kernel<EPI, 8, UB, NB>), dim3(grid, slices), dim3(8 * 64), lds, st, a);
     return 0;
+}
+// K slices of the two-tile kernel for a long-K layer whose sums the following norm finishes (down_proj at 17..32 tokens): S one-pass
+// slices of 4096 (UB = 4) or 2048 (UB = 2) k across the workgroups instead of S passes inside one -- 0 where no such cut exists
+int gemm_w4a16_stream32_partial_slices(int M, int N, int K) {
+    if (M < 17 || M > 32 || N % 16) return 0;
+    for (int len : {4096, 2048})
+        if (K % len == 0 && K / len >= 2 && K / len <= 8) return K / len;
+    return 0;
+}
+int gemm_w4a16_stream32_partial(const f16* x, const int8_t* wq, float* part, int M, int N, int K, int S, hipStream_t st) {
+    if (S < 2 || S != gemm_w4a16_stream32_partial_slices(M, N, K) || !part) return -1;
+    StreamArgs a{};
+    a.x = x; a.ldx = K; a.ldw = K / 2; a.wq = reinterpret_cast<const uint8_t*>(wq); a.M = M; a.N = N; a.K = K / S; a.ntiles = N / 16;
+    a.part = part; a.nq = S;
+    if (a.K == 4096) return launch_stream32_inst<SEPI_PARTIAL, 4, 1>(a, st);
+    return launch_stream32_inst<SEPI_PARTIAL, 2, 1>(a, st);
 }
 template <int EPI>
 static int launch_stream32(const StreamArgs& a, hipStream_t st) {

@@ -1299,8 +1299,13 @@ __global__ __launch_bounds__(QS_SMH_THREADS) void silu_mul_hadamard_kernel(const
     // phase C: fp16 out, or abs-max + int4
     const int nvec = I / 8;
     if (q == nullptr) {
-        for (int i = tid; i < nvec; i += NT)
-            *reinterpret_cast<f16x8*>(out16 + (size_t)t * I + 8 * i) = *reinterpret_cast<const f16x8*>(zsrc + 8 * i);
+        for (int i = tid; i < nvec; i += NT) {
+            const f16x8 z8 = *reinterpret_cast<const f16x8*>(zsrc + 8 * i);
+            if (xp)   // fragment-major tiles (<= 32 tokens): the eight halves k .. k + 7 are one 16-byte group in the order 0,4,1,5,2,6,3,7
+                *reinterpret_cast<f16x8*>(out16 + w4a16_xperm_offset(t, 8 * i, I)) = f16x8{z8[0], z8[4], z8[1], z8[5], z8[2], z8[6], z8[3], z8[7]};
+            else
+                *reinterpret_cast<f16x8*>(out16 + (size_t)t * I + 8 * i) = z8;
+        }
         return;
     }
     float amax = 0.0f;
@@ -1357,9 +1362,12 @@ static int smh_spread(int T, int P, int K, int pre_activated, const void* xws) {
 
 // the forms that can write the fragment-major tile: the spread ones (a workspace is given), at most 16 tokens
 bool mlp_hadamard_xperm_supported(int T, int I, int K) {
-    if (T < 1 || T > 16 || K < 1 || I % K) return false;
+    if (T < 1 || T > 32 || K < 1 || K > 172 || I % K) return false;
+    const int P = I / K;
+    if (P & (P - 1)) return false;
     static const int dummy = 0;
-    return smh_spread(T, I / K, K, 1, &dummy) > 1;
+    if (smh_spread(T, P, K, 1, &dummy) > 1) return true;      // the spread forms
+    return T > 16 && (P == 128 || P == 256 || P == 512 || P == 1024 || P == 2048) && I % 128 == 0;   // 17..32 tokens: also the one-workgroup form
 }
 
 int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t* q, f16* scale, float had_scale,
@@ -1393,7 +1401,7 @@ int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t*
     }
     QS_SMH_108(8) QS_SMH_108(16)
 #undef QS_SMH_108
-    if (xp) return -1;   // the fragment-major fp16 output exists in the spread forms only
+    if (xp && (q != nullptr || T > 32)) return -1;   // fragment-major fp16 rows: one or two 16-row tiles
 #define QS_SMH2(EPLV, KHV)                                                                                      \
     {                                                                                                            \
         if (pre_activated) QS_SMH3(EPLV, KHV, true)                                                              \
@@ -1405,7 +1413,7 @@ int silu_mul_hadamard(const f16* gate_up, const f16* hadK, f16* out_f16, int8_t*
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&silu_mul_hadamard_kernel<EPLV, KHV, PAV>),  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
         hipLaunchKernelGGL((silu_mul_hadamard_kernel<EPLV, KHV, PAV>), dim3(T), dim3(QS_SMH_THREADS), lds, st, gate_up, \
-                           hadK, out_f16, q, scale, had_scale, clip, I, K, (uint32_t*)nullptr);                  \
+                           hadK, out_f16, q, scale, had_scale, clip, I, K, (uint32_t*)nullptr, xp);              \
         return 0;                                                                                                \
     }
 #define QS_SMH(EPLV)                                                                                            \

@@ -41,6 +41,8 @@ int silu_mul(const f16* gate_up, f16* out, int T, int I, hipStream_t st);
 bool mlp_hadamard_xperm_supported(int T, int I, int K);
 // 17..32 tokens: two fragment-major 16-row tiles, the two-token-tile streaming kernel (gemm_stream.hip: gemm_w4a16_stream2_kernel)
 bool gemm_w4a16_stream32_supported(int M, int N, int K);
+int gemm_w4a16_stream32_partial_slices(int M, int N, int K);
+int gemm_w4a16_stream32_partial(const f16* x, const int8_t* wq, float* part, int M, int N, int K, int S, hipStream_t st);
 int gemm_w4a16_stream32(const f16* x, const int8_t* wq, const f16* ws, f16* out, int M, int N, int K, hipStream_t st);
 int gemm_w4a16_stream32_qkv_rope(const f16* x, const int8_t* wq, const f16* ws, f16* qkv, int M, int N, int K,
                                  const int64_t* positions, const f16* cos_sin_cache, f16* key_cache, f16* value_cache,

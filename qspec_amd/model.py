@@ -108,6 +108,7 @@ class Scratch:
         if 16 < T <= 32:   # two tiles each: the two-token-tile W4A16 streaming kernel (ops.w4a16_act_layout32_supported)
             self.xp_normed = torch.zeros(32, H, dtype=f16, device=device)
             self.xp_had = torch.zeros(32, cfg.q_size, dtype=f16, device=device)
+            self.xp_had_mlp = torch.zeros(32, I, dtype=f16, device=device)
         self.tp_part = e(1, min(T, 32), H, dtype=torch.float32)   # TP verify pass (T <= 32): fp32 row-parallel partials
         self.had_part_amax = e(min(T, 16), 8, dtype=torch.float32)  # draft pass (T <= 4): partial row maxima of the spread head Hadamard
         # draft pass at 17..32 tokens: int32 K-slice sums of down_proj + the activation scales they were computed with
@@ -220,6 +221,7 @@ class QuarotLlamaForCausalLM:
                     and ops.w4a16_act_layout_supported(T, cfg.q_size) and ops.w4a16_act_layout_supported(T, down_k)
                     and ops.mlp_hadamard_act_layout_supported(T, I, self.had_K))
 
+    XP32_DOWN_SLICES = __import__("os").environ.get("QSPEC_XP32_DOWN_SLICES", "1") != "0"
     TILED_PARTIAL_IN_NORM = __import__("os").environ.get("QSPEC_TILED_PARTIAL_IN_NORM", "1") != "0"
     MERGE_IN_HADAMARD = True   # False: the attention kernel merges its context splits itself (ticket + fences)
     DOWN_K_SLICES = __import__("os").environ.get("QSPEC_DOWN_K_SLICES", "1") != "0"   # draft down_proj at 17..32 tokens as K slices
@@ -310,6 +312,10 @@ class QuarotLlamaForCausalLM:
                 and ops.w4a16_act_layout32_supported(T, 2 * cfg.intermediate_size, cfg.hidden_size)
                 and (nh in (32, 64) if self.head_had_K == 1 else
                      ops.heads_hadamard_mix_merged_spread_supported(T, nh, hd, self.head_had_K)))
+        # ... and down_proj as one-pass K slices of the same kernel across the workgroups, finished inside the next norm
+        S32 = (ops.w4a16_linear_partial_slices_xp32(T, cfg.hidden_size, cfg.intermediate_size)
+               if (xp32 and s.down_part is not None and self.XP32_DOWN_SLICES
+                   and ops.mlp_hadamard_act_layout_supported(T, cfg.intermediate_size, self.had_K)) else 0)
         if xp32:
             normed_x, had_x = s.xp_normed, s.xp_had
         self.last_forward_form = "two-tile" if xp32 else ("fragment-major" if xp else ("fused" if fuse else "unfused"))   # (tests)
@@ -421,6 +427,12 @@ class QuarotLlamaForCausalLM:
             # gate_up -> silu*up -> online hadamard (+ quant) -> down_proj                              :266-299
             if xp32:
                 ops.gate_up_silu_linear_xp32(x, gu_w, gu_s, act, T)
+                if 1 < S32 <= 8:
+                    ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, out_f16=s.xp_had_mlp, xp=True)
+                    part = s.down_part.view(-1)[:S32 * T * cfg.hidden_size].view(S32, T, cfg.hidden_size)
+                    ops.w4a16_linear_partial_xp32(s.xp_had_mlp, layer.down_proj.weight, part, S32, T)
+                    delta = ("partial", part, layer.down_proj._scales(), S32)
+                    continue
                 had_mlp_in = s.act_buffer_gate_up.view(-1)[:T * cfg.intermediate_size].view(T, cfg.intermediate_size)
                 ops.mlp_hadamard(act, self.had_rem_dim, self.had_K, self.mlp_had_scale, out_f16=had_mlp_in)
             elif fuse:

@@ -112,6 +112,17 @@ def w4a16_linear_xp32(x, wq, w_scale, out, tokens: int):
     return out
 
 
+def w4a16_linear_partial_slices_xp32(M: int, N: int, K: int) -> int:
+    return int(_lib.load().qspec_w4a16_linear_partial_slices_xp32(M, N, K))
+
+
+def w4a16_linear_partial_xp32(x, wq, part, slices: int, tokens: int):
+    N, K = wq.shape[0], wq.shape[1] * 2
+    _call("qspec_w4a16_linear_partial_xp32", _xp32_tiles(x, "x", K), _chk(wq, "wq", (_I8, _U8)), _chk(part, "part", _F32), tokens, N, K,
+          slices, _stream())
+    return part
+
+
 def qkv_rope_linear_xp32(x, wq, w_scale, qkv, positions, cos_sin_cache, key_cache, value_cache, slot_mapping, num_heads,
                          num_kv_heads, head_size, tokens: int):
     N, K = wq.shape[0], wq.shape[1] * 2
@@ -243,7 +254,7 @@ def mlp_hadamard(act, hadK, K: int, had_scale: float, out_f16=None, q=None, scal
     T, I = act.shape
     ws = xwg_workspace(act.device) if isinstance(workspace, str) else workspace
     if xp:
-        _xp_tile(out_f16, "out_f16", I)
+        _xp_tile(out_f16, "out_f16", I, T)
     _call("qspec_mlp_hadamard" + ("_xp" if xp else ""), _chk(act, "act", _F16), _opt(hadK, "hadK", _F16), _opt(out_f16, "out_f16", _F16),
           _opt(q, "q", _I8), _opt(scale, "scale", _F16), float(had_scale), float(clip_ratio), T, I, K,
           None if ws is None else ws.data_ptr(), _stream())

@@ -337,3 +337,44 @@ def test_head_transform_writes_two_tiles(ops, oracle, nq, nkv, ctx_lens, q_len):
     o1 = torch.full((2, 16, nq * d), float("nan"), dtype=torch.float16, device=DEV)
     ops.heads_hadamard_merged(ws, T, n_splits, T, nq, d, sc, out_f16=o1, xp=True)
     assert same_bits(from_tiles32(o1, T), o0)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 8192, 28672), (20, 4096, 14336), (32, 1024, 8192)])
+def test_two_tile_k_sliced_linear_and_norm_finish(ops, oracle, M, N, K):
+    """down_proj at 17..32 tokens: one-pass K slices of the two-tile kernel across the workgroups, raw fp32 sums finished in the
+    norm: hidden / normed rows within the W4A16 bar of w4a16_linear + add_rms_norm_fp16 (another summation order)."""
+    rng = np.random.default_rng(M + N)
+    x = rand_hidden(rng, M, K)
+    wq = dev(oracle.pack_i4(rand_w4(rng, N, K)))
+    ws = dev((rng.random(N) * 0.002 + 0.0005).astype(np.float16))
+    S = ops.w4a16_linear_partial_slices_xp32(M, N, K)
+    assert S == K // 4096 if K % 4096 == 0 and K // 4096 <= 8 else S == K // 2048
+    part = torch.empty(S, M, N, dtype=torch.float32, device=DEV)
+    ops.w4a16_linear_partial_xp32(to_tiles32(x), wq, part, S, M)
+    hidden = dev(rand_hidden(rng, M, N))
+    n1 = torch.empty_like(hidden); h1 = torch.empty_like(hidden)
+    ops.add_rms_norm_fp16_partial(n1, h1, hidden, part, ws, S, 1e-5)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.w4a16_linear(dev(x), wq, ws, out)
+    n0 = torch.empty_like(hidden); h0 = torch.empty_like(hidden)
+    ops.add_rms_norm_fp16(n0, h0, hidden, out, 1e-5)
+    torch.cuda.synchronize()
+    d = (h1.float() - h0.float()).abs() / (1e-3 * h0.float().abs().clamp(min=1.0))
+    assert float(d.max()) <= 2.0, float(d.max())
+    assert (n1.float() - n0.float()).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("T,I,K", [(32, 14336, 28), (20, 28672, 28), (17, 13824, 108)])
+def test_mlp_transform_writes_two_tiles(ops, oracle, T, I, K):
+    from qspec_amd import hadamard_tables
+    rng = np.random.default_rng(T + I)
+    hadK, K2 = hadamard_tables.get_hadK(I)
+    assert K2 == K and ops.mlp_hadamard_act_layout_supported(T, I, K)
+    had = hadK.to(torch.float16).to(DEV)
+    act = dev(rand_hidden(rng, T, I, 0.5))
+    sc = oracle.rsqrt_scale(I)
+    o0 = torch.empty(T, I, dtype=torch.float16, device=DEV)
+    ops.mlp_hadamard(act, had, K, sc, out_f16=o0)
+    o1 = torch.full((2, 16, I), float("nan"), dtype=torch.float16, device=DEV)
+    ops.mlp_hadamard(act, had, K, sc, out_f16=o1, xp=True)
+    assert same_bits(from_tiles32(o1, T), o0)
