@@ -141,7 +141,9 @@ def gate_up_silu_linear_xp32(x, wq, w_scale, act, tokens: int):
 
 
 def mlp_hadamard_act_layout_supported(T: int, I: int, K: int) -> bool:
-    return XWG_SPREAD and bool(_lib.load().qspec_mlp_hadamard_act_layout_supported(T, I, K))
+    """mlp_hadamard(..., xp=True) exists at this shape (the spread forms and the one-workgroup form both store the tiles, so the
+    answer does not depend on XWG_SPREAD: a recovery replay without hand-off kernels takes the same GEMM forms)."""
+    return bool(_lib.load().qspec_mlp_hadamard_act_layout_supported(T, I, K))
 
 
 def add_rms_norm_fp16(out, hidden_out, x, delta, eps: float, xp: bool = False):

@@ -1230,22 +1230,31 @@ def test_correctly_calls_spec_decode_sampler(tiny, k, batch_size):
     assert torch.equal(a.target_with_bonus_probs[:, -1].argmax(-1), a.bonus_token_ids.reshape(-1))
 
 
-def test_cycle_recovery_replay_is_bit_identical(tiny):
+@pytest.mark.parametrize("width,B", [("tiny", 4), ("llama-3-8b", 4), ("llama-3-8b", 8)])
+def test_cycle_recovery_replay_is_bit_identical(tiny, width, B):
     """A cycle whose error word is non-zero (a device-side hand-off timed out) is re-run from the state snapshot taken at
     its start, without hand-offs (engine.recover): the replay must emit exactly what an undisturbed engine emits --
-    sequence state, sampler counters and the Philox state restored, the one-workgroup kernel forms bit-identical."""
+    sequence state, sampler counters and the Philox state restored, the one-workgroup kernel forms bit-identical.  At the
+    Llama-3-8B width the verify pass runs on fragment-major tiles (B = 4: 16 tokens) / the two-token-tile kernel (B = 8: 32
+    tokens): the replay must take the same GEMM forms (the MLP transform's one-workgroup form stores the tiles too)."""
     from qspec_amd import ops
+    from qspec_amd.model import QuarotLlamaConfig, QuarotLlamaForCausalLM
     from qspec_amd.spec_decode import QSpecEngine
     rng = np.random.default_rng(14)
-    prompts = [rng.integers(0, tiny.config.vocab_size, n).tolist() for n in (20, 31, 8, 50)]
+    if width != "tiny":
+        cfg = QuarotLlamaConfig(4096, 14336, 32, 8, 2, 1024, 1e-5, 500000.0, 512, "llama-3-8b-2layer")
+        tiny = QuarotLlamaForCausalLM(cfg, DEV).init_synthetic(seed=4, lm_head_std=0.05)
+    prompts = [rng.integers(0, tiny.config.vocab_size, n).tolist() for n in (20, 31, 8, 50, 13, 27, 9, 40)[:B]]
     runs = []
     for poke in (False, True):
-        eng = QSpecEngine(tiny, 3, 4, max_model_len=256, block_size=16, max_new_tokens=64, use_graph=False, seed=11)
+        eng = QSpecEngine(tiny, 3, B, max_model_len=256, block_size=16, max_new_tokens=64, use_graph=False, seed=11)
         eng.add_sequences(prompts)
         eng.step()
+        if width != "tiny":
+            assert tiny.last_forward_form == ("fragment-major" if B == 4 else "two-tile")
         out0, err = eng.read_outputs()
         assert err == 0
-        eng.note_emitted([int((out0[b] != -1).sum()) for b in range(4)])
+        eng.note_emitted([int((out0[b] != -1).sum()) for b in range(B)])
         if poke:   # raise this stream's sticky exchange-workspace error word: the next cycle reports it
             ops.xwg_workspace(DEV)[:1].fill_(1)
         eng.step()
@@ -1255,7 +1264,7 @@ def test_cycle_recovery_replay_is_bit_identical(tiny):
             eng.recover()
             out, err = eng.read_outputs()
             assert err == 0 and eng.recoveries == 1
-        eng.note_emitted([int((out[b] != -1).sum()) for b in range(4)])
+        eng.note_emitted([int((out[b] != -1).sum()) for b in range(B)])
         eng.step()                                                # and the engine carries on from the recovered state
         out2, err2 = eng.read_outputs()
         assert err2 == 0
